@@ -1,0 +1,211 @@
+/*
+ * moonshine_amd.h — C ABI of libmoonshine_amd.so, the MI355X (gfx950) drop-in for the
+ * shaders/hrtsystem + engine/hrtsystem hot path of ashpil/moonshine.
+ *
+ * Part 1 is, symbol for symbol and layout for layout, the reference's existing C ABI
+ * (hydra/moonshine.h:10-95, implemented by hydra/hydra.zig:107-558): hydra/*.cpp links
+ * against this library unchanged.  Part 2 ("Msne*") exposes the parts of the Zig API of
+ * engine/hrtsystem that the reference's `offline`, `online` and engine/tests.zig call
+ * directly and that moonshine.h never exported (material variants, backgrounds, pipeline
+ * specialization constants, batched launches, sharded films); each entry cites the
+ * reference interface it stands in for.
+ *
+ * Conventions (README.md:56-58): +z up, Mat3x4 = 3 rows of float4, row-major object->world.
+ * All handles are dense uint32_t indices.  Calls on one context are serialized by one
+ * mutex (hydra.zig:76-78).  Nothing throws across the ABI; functions that can fail return
+ * false / NULL / negative codes.  Plain pointers and sizes only — no torch, no HIP types.
+ */
+#ifndef MOONSHINE_AMD_H
+#define MOONSHINE_AMD_H
+
+#include <stdint.h>
+#include <stddef.h>
+#include <stdbool.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ------------------------------------------------------------------ */
+/* Part 1 — hydra/moonshine.h, verbatim layouts                        */
+/* ------------------------------------------------------------------ */
+typedef uint32_t MeshHandle;      /* moonshine.h:10 */
+typedef uint32_t ImageHandle;     /* :11 */
+typedef uint32_t MaterialHandle;  /* :12 */
+typedef uint32_t SensorHandle;    /* :13 */
+typedef uint32_t LensHandle;      /* :14 */
+typedef uint32_t InstanceHandle;  /* :15 */
+
+typedef struct F32x2 { float x, y; } F32x2;                 /* :17 */
+typedef struct F32x3 { float x, y, z; } F32x3;              /* :21 */
+typedef struct F32x4 { float x, y, z, w; } F32x4;           /* :25 */
+typedef struct U32x3 { uint32_t x, y, z; } U32x3;           /* :29 */
+typedef struct Mat3x4 { F32x4 x, y, z; } Mat3x4;            /* :33 */
+typedef struct Geometry {                                   /* :37  (Accel.zig:40-44) */
+    MeshHandle mesh;
+    MaterialHandle material;
+    bool sampled;
+} Geometry;
+typedef struct Extent2D { uint32_t width, height; } Extent2D; /* :43 */
+typedef struct Lens {                                       /* :48  (Camera.zig:18-25) */
+    F32x3 origin;
+    F32x3 forward;
+    F32x3 up;
+    float vfov;          /* radians */
+    float aperture;
+    float focus_distance;
+} Lens;
+typedef struct Material {                                   /* :57  (hydra.zig:38-42) StandardPBR only */
+    ImageHandle normal;
+    ImageHandle emissive;
+    ImageHandle color;
+    ImageHandle metalness;
+    ImageHandle roughness;
+    float ior;
+} Material;
+typedef enum TextureFormat { f16x4, u8x4_srgb } TextureFormat; /* :66 */
+
+typedef struct HdMoonshine HdMoonshine;                      /* :71 */
+
+/* :72  hydra.zig:107-143.  Device 0 (or $MSNE_DEVICE); pipeline constants {1,1024,0,0,false,false,false}
+ * (hydra.zig:97-105); 1x1 white default background (BackgroundManager.zig:116).  NULL on failure. */
+HdMoonshine* HdMoonshineCreate(void);
+void HdMoonshineDestroy(HdMoonshine*);                                          /* :73  hydra.zig:542 */
+/* :74  hydra.zig:145-363.  Synchronous: flush deferred material edits, rebuild the acceleration
+ * structure if instances changed, one launch of samples_per_run samples per pixel, copy the film
+ * into the sensor's host buffer, sample_count += samples_per_run. */
+bool HdMoonshineRender(HdMoonshine*, SensorHandle, LensHandle);
+bool HdMoonshineRebuildPipeline(HdMoonshine*);                                  /* :75  hydra.zig:365 — clears all sensors */
+/* :76  hydra.zig:374-384.  normals/texcoords are face-varying (index_count*3 entries) or NULL. Data is copied. */
+MeshHandle HdMoonshineCreateMesh(HdMoonshine*, const F32x3* positions, const F32x3* normals, const F32x2* texcoords,
+                                 size_t position_count, const U32x3* indices, size_t index_count);
+ImageHandle HdMoonshineCreateSolidTexture1(HdMoonshine*, float, const char* name);     /* :77 */
+ImageHandle HdMoonshineCreateSolidTexture2(HdMoonshine*, F32x2, const char* name);     /* :78 */
+ImageHandle HdMoonshineCreateSolidTexture3(HdMoonshine*, F32x3, const char* name);     /* :79 */
+ImageHandle HdMoonshineCreateRawTexture(HdMoonshine*, uint8_t* data, Extent2D, TextureFormat, const char* name); /* :80 */
+MaterialHandle HdMoonshineCreateMaterial(HdMoonshine*, Material);                      /* :81 */
+void HdMoonshineSetMaterialNormal(HdMoonshine*, MaterialHandle, ImageHandle);          /* :82  deferred to next Render */
+void HdMoonshineSetMaterialEmissive(HdMoonshine*, MaterialHandle, ImageHandle);        /* :83 */
+void HdMoonshineSetMaterialColor(HdMoonshine*, MaterialHandle, ImageHandle);           /* :84 */
+void HdMoonshineSetMaterialMetalness(HdMoonshine*, MaterialHandle, ImageHandle);       /* :85 */
+void HdMoonshineSetMaterialRoughness(HdMoonshine*, MaterialHandle, ImageHandle);       /* :86 */
+void HdMoonshineSetMaterialIOR(HdMoonshine*, MaterialHandle, float);                   /* :87 */
+/* :88  hydra.zig:483-493 → Accel.uploadInstance (Accel.zig:189); clears all sensors */
+InstanceHandle HdMoonshineCreateInstance(HdMoonshine*, Mat3x4, const Geometry*, size_t geometry_count, bool visible);
+void HdMoonshineDestroyInstance(HdMoonshine*, InstanceHandle);                         /* :89  = hide (hydra.zig:495) */
+void HdMoonshineSetInstanceTransform(HdMoonshine*, InstanceHandle, Mat3x4);            /* :90 */
+void HdMoonshineSetInstanceVisibility(HdMoonshine*, InstanceHandle, bool);             /* :91 */
+SensorHandle HdMoonshineCreateSensor(HdMoonshine*, Extent2D);                          /* :92 */
+/* :93  float4[w*h], row-major, library-owned pinned host memory, valid until Destroy; alpha = launches */
+float* HdMoonshineGetSensorData(const HdMoonshine*, SensorHandle);
+LensHandle HdMoonshineCreateLens(HdMoonshine*, Lens);                                  /* :94 */
+void HdMoonshineSetLens(HdMoonshine*, LensHandle, Lens);                               /* :95  clears all sensors */
+
+/* ------------------------------------------------------------------ */
+/* Part 2 — engine/hrtsystem Zig API that moonshine.h does not export  */
+/* ------------------------------------------------------------------ */
+
+/* MaterialManager.zig:45-50 ≡ shaders/hrtsystem/world.hlsl:31-36 */
+typedef enum MsneMaterialType {
+    MSNE_MATERIAL_GLASS = 0,
+    MSNE_MATERIAL_LAMBERT = 1,
+    MSNE_MATERIAL_PERFECT_MIRROR = 2,
+    MSNE_MATERIAL_STANDARD_PBR = 3,
+} MsneMaterialType;
+
+/* MaterialManager.MaterialInfo (MaterialManager.zig:22-77): normal + emissive + tagged variant.
+ * glass uses {ior}; lambert {color}; perfect_mirror nothing; standard_pbr {color,metalness,roughness,ior}. */
+typedef struct MsneMaterialDesc {
+    ImageHandle normal;
+    ImageHandle emissive;
+    uint32_t type;        /* MsneMaterialType */
+    ImageHandle color;
+    ImageHandle metalness;
+    ImageHandle roughness;
+    float ior;
+} MsneMaterialDesc;
+
+/* vk.Format values the Zig API is called with (World.zig:72,101,146,184,196; MaterialManager.zig:364-388; hydra.zig:47-52) */
+typedef enum MsneTextureFormat {
+    MSNE_FORMAT_R8G8B8A8_SRGB = 0,
+    MSNE_FORMAT_R8G8_UNORM = 1,
+    MSNE_FORMAT_R8_UNORM = 2,
+    MSNE_FORMAT_R32G32B32A32_SFLOAT = 3,
+    MSNE_FORMAT_R32G32_SFLOAT = 4,
+    MSNE_FORMAT_R32_SFLOAT = 5,
+    MSNE_FORMAT_R16G16B16A16_SFLOAT = 6,
+} MsneTextureFormat;
+
+/* StandardPipeline.SpecConstants (pipeline.zig:319-327 ↔ shaders/hrtsystem/main.hlsl:34-40).
+ * Reference defaults {1,4,1,1,true,true,true}; offline uses max_bounces=1024 (offline/main.zig:106-111). */
+typedef struct MsnePipelineOpts {
+    uint32_t samples_per_run;
+    uint32_t max_bounces;
+    uint32_t env_samples_per_bounce;
+    uint32_t mesh_samples_per_bounce;
+    uint32_t flip_image;                    /* bool32 */
+    uint32_t indexed_attributes;            /* bool32 */
+    uint32_t two_component_normal_texture;  /* bool32 */
+} MsnePipelineOpts;
+
+/* Context creation with explicit placement.  The image is cut into tile_size² tiles; tile t belongs to
+ * shard (t mod shard_count); this context renders only the tiles of `shard_index`.
+ * shard_count=1 renders everything (the reference's single-device behaviour, VulkanContext.zig:313-326). */
+typedef struct MsneConfig {
+    int32_t device;        /* HIP device ordinal; -1 = $MSNE_DEVICE or 0 */
+    uint32_t tile_size;    /* 0 = 64 */
+    uint32_t shard_index;
+    uint32_t shard_count;  /* 0 = 1 */
+} MsneConfig;
+
+typedef struct MsneStats {
+    uint64_t closest_rays;   /* Intersection::find equivalents traced (intersection.hlsl:18-22) */
+    uint64_t shadow_rays;    /* ShadowIntersection::hit equivalents traced (intersection.hlsl:33-46) */
+    uint64_t samples;        /* camera paths started (main.hlsl:83-92) */
+    uint64_t launches;       /* recordTraceRays equivalents (pipeline.zig:269-271) */
+    double   trace_closest_ms; /* HIP-event time inside k_trace_closest since the last reset (on the render stream) */
+    double   trace_shadow_ms;
+    double   shade_ms;
+    double   render_ms;        /* first raygen launch → film complete, summed over MsneRender calls */
+    uint64_t trace_closest_launches;
+} MsneStats;
+
+HdMoonshine* MsneCreate(const MsneConfig*);                       /* HdMoonshineCreate with placement */
+
+/* MeshManager.upload (MeshManager.zig:70-156).  attribute_count = length of normals/texcoords:
+ * position_count when the pipeline has indexed_attributes=true (glTF mode, world.hlsl:130),
+ * index_count*3 when false (Hydra mode).  Negative on error. */
+int64_t MsneCreateMesh(HdMoonshine*, const F32x3* positions, const F32x3* normals, const F32x2* texcoords,
+                       size_t position_count, size_t attribute_count, const U32x3* indices, size_t index_count);
+/* TextureManager.upload with a .raw source (MaterialManager.zig:351-445) */
+int64_t MsneCreateTexture(HdMoonshine*, const void* bytes, Extent2D, MsneTextureFormat);
+/* MaterialManager.upload (MaterialManager.zig:140-170) with any variant */
+int64_t MsneCreateMaterial(HdMoonshine*, const MsneMaterialDesc*);
+/* StandardPipeline.create / recreate (pipeline.zig:85,180): change specialization constants; clears all sensors */
+int MsneSetPipeline(HdMoonshine*, const MsnePipelineOpts*);
+int MsneGetPipeline(const HdMoonshine*, MsnePipelineOpts*);
+/* BackgroundManager.addBackground (BackgroundManager.zig:142-394): equirectangular RGBA32F, row 0 = top (theta=0).
+ * Runs the three shaders/background kernels' equivalents on the GPU; clears all sensors. */
+int MsneSetBackground(HdMoonshine*, const float* rgba, Extent2D);
+/* `launches` back-to-back HdMoonshineRender-equivalents without host round trips (offline/main.zig:131-165 spp loop);
+ * one film readback at the end when `readback` is nonzero.  0 on success. */
+int MsneRender(HdMoonshine*, SensorHandle, LensHandle, uint32_t launches, int readback);
+void MsneClearSensor(HdMoonshine*, SensorHandle);                 /* Sensor.clear (core/Sensor.zig:81-83) */
+uint32_t MsneGetSampleCount(const HdMoonshine*, SensorHandle);    /* Sensor.sample_count (core/Sensor.zig:12) */
+
+/* Sharded film access for multi-GPU gathers (no reference equivalent: the reference is single-device).
+ * The packed film holds this shard's tiles in tile order, each tile tile_size² float4, row-major inside the tile. */
+uint64_t MsneGetShardTileCount(const HdMoonshine*, SensorHandle);
+void* MsneGetPackedFilmDevicePtr(const HdMoonshine*, SensorHandle);            /* device pointer, float4[tiles*ts*ts] */
+/* root side: scatter `shard_count` packed films (concatenated in shard order, each padded to max tiles per shard)
+ * from device memory into the sensor's full row-major film and its host buffer */
+int MsneUnpackGatheredFilm(HdMoonshine*, SensorHandle, const void* gathered_device_ptr, uint32_t shard_count);
+
+int MsneGetStats(const HdMoonshine*, MsneStats*);
+void MsneResetStats(HdMoonshine*);
+const char* MsneGetLastError(const HdMoonshine*);   /* NULL ctx → last creation error */
+
+#ifdef __cplusplus
+}
+#endif
+#endif

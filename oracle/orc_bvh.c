@@ -1,0 +1,339 @@
+/*
+ * ORACLE — test infrastructure only (see orc_math.h header).
+ * orc_bvh.c: the canonical CPU BVH of SURVEY.md §8(d) and the intersection contract of
+ * shaders/hrtsystem/intersection.hlsl:18-46 + main.hlsl:102-118 (closest hit: instanceIndex,
+ * geometryIndex, primitiveIndex, barycentrics; shadow: any hit in (0,tmax)).
+ * The reference delegates this to the Vulkan driver's BLAS/TLAS (Accel.zig:94-184,484); what is
+ * restated here is the *contract*: all geometry opaque, no culling, invisible instances (mask 0,
+ * Accel.zig:402) skipped, ray transformed to instance space with t preserved.
+ * Result determinism: hits are decided only by tri_intersect(); equal-t ties go to the smallest
+ * (instance, geometry, primitive), so any BVH over the same triangles returns the same hit.
+ */
+#include <stdlib.h>
+#include <stdio.h>
+#include "orc_scene.h"
+
+typedef struct { v3 lo, hi; } aabb;
+
+static inline aabb aabb_empty(void) { aabb b = { { 1e30f, 1e30f, 1e30f }, { -1e30f, -1e30f, -1e30f } }; return b; }
+static inline void aabb_grow(aabb *b, v3 p) {
+    b->lo.x = orc_minf(b->lo.x, p.x); b->lo.y = orc_minf(b->lo.y, p.y); b->lo.z = orc_minf(b->lo.z, p.z);
+    b->hi.x = orc_maxf(b->hi.x, p.x); b->hi.y = orc_maxf(b->hi.y, p.y); b->hi.z = orc_maxf(b->hi.z, p.z);
+}
+static inline void aabb_merge(aabb *b, const aabb *o) { aabb_grow(b, o->lo); aabb_grow(b, o->hi); }
+static inline float aabb_area(const aabb *b) {
+    float dx = b->hi.x - b->lo.x, dy = b->hi.y - b->lo.y, dz = b->hi.z - b->lo.z;
+    return dx * dy + dy * dz + dz * dx;
+}
+
+static inline uint32_t expand_bits10(uint32_t v) {
+    v = (v * 0x00010001u) & 0xFF0000FFu;
+    v = (v * 0x00000101u) & 0x0F00F00Fu;
+    v = (v * 0x00000011u) & 0xC30C30C3u;
+    v = (v * 0x00000005u) & 0x49249249u;
+    return v;
+}
+static inline uint32_t morton30(float x, float y, float z) {
+    x = orc_minf(orc_maxf(x * 1024.0f, 0.0f), 1023.0f);
+    y = orc_minf(orc_maxf(y * 1024.0f, 0.0f), 1023.0f);
+    z = orc_minf(orc_maxf(z * 1024.0f, 0.0f), 1023.0f);
+    return expand_bits10((uint32_t)x) * 4u + expand_bits10((uint32_t)y) * 2u + expand_bits10((uint32_t)z);
+}
+
+typedef struct { uint32_t left, right; aabb box; uint32_t first, count; } bnode; /* count>0 => leaf */
+typedef struct {
+    const uint64_t *keys; const aabb *boxes; bnode *nodes; uint32_t nnodes; uint32_t leaf_max;
+} bbuild;
+
+static int cmp_u64(const void *a, const void *b) {
+    uint64_t x = *(const uint64_t *)a, y = *(const uint64_t *)b;
+    return x < y ? -1 : (x > y ? 1 : 0);
+}
+
+static uint32_t build_range(bbuild *B, uint32_t a, uint32_t b) {
+    uint32_t id = B->nnodes++;
+    bnode *n = &B->nodes[id];
+    if (b - a <= B->leaf_max) {
+        n->left = n->right = 0; n->first = a; n->count = b - a;
+        aabb bx = aabb_empty();
+        for (uint32_t i = a; i < b; i++) aabb_merge(&bx, &B->boxes[(uint32_t)B->keys[i]]);
+        B->nodes[id].box = bx;
+        return id;
+    }
+    uint32_t ca = (uint32_t)(B->keys[a] >> 32), cb = (uint32_t)(B->keys[b - 1] >> 32);
+    uint32_t split;
+    if (ca == cb) split = (a + b) / 2;
+    else {
+        uint32_t diff = ca ^ cb; int bit = 31; while (!((diff >> bit) & 1u)) bit--;
+        uint32_t lo = a, hi = b - 1; /* first index whose `bit` is set */
+        while (lo < hi) { uint32_t mid = (lo + hi) / 2; if (((uint32_t)(B->keys[mid] >> 32) >> bit) & 1u) hi = mid; else lo = mid + 1; }
+        split = lo;
+    }
+    uint32_t l = build_range(B, a, split);
+    uint32_t r = build_range(B, split, b);
+    n = &B->nodes[id];
+    n->left = l; n->right = r; n->count = 0; n->first = 0;
+    n->box = B->nodes[l].box; aabb_merge(&n->box, &B->nodes[r].box);
+    return id;
+}
+
+static uint32_t collapse(const bnode *bn, uint32_t root, orc_wnode *wn, uint32_t *nw) {
+    uint32_t id = (*nw)++;
+    uint32_t ch[8]; int nch = 0;
+    if (bn[root].count > 0) { ch[nch++] = root; }
+    else { ch[nch++] = bn[root].left; ch[nch++] = bn[root].right; }
+    while (nch < 8) {
+        int best = -1; float ba = -1.0f;
+        for (int i = 0; i < nch; i++) if (bn[ch[i]].count == 0) { float ar = aabb_area(&bn[ch[i]].box); if (ar > ba) { ba = ar; best = i; } }
+        if (best < 0) break;
+        uint32_t c = ch[best];
+        ch[best] = bn[c].left; ch[nch++] = bn[c].right;
+    }
+    orc_wnode w; memset(&w, 0, sizeof w);
+    w.nchild = (uint8_t)nch;
+    for (int i = 0; i < nch; i++) {
+        const bnode *c = &bn[ch[i]];
+        w.lo[i][0] = c->box.lo.x; w.lo[i][1] = c->box.lo.y; w.lo[i][2] = c->box.lo.z;
+        w.hi[i][0] = c->box.hi.x; w.hi[i][1] = c->box.hi.y; w.hi[i][2] = c->box.hi.z;
+        if (c->count > 0) { w.child[i] = c->first; w.count[i] = (uint8_t)c->count; }
+    }
+    for (int i = 0; i < nch; i++) if (bn[ch[i]].count == 0) w.child[i] = collapse(bn, ch[i], wn, nw);
+    wn[id] = w;
+    return id;
+}
+
+/* builds the wide BVH over n boxes; returns the permutation (item i of the BVH = original index order[i]) */
+static uint32_t *bvh_build_boxes(orc_bvh *out, const aabb *boxes, uint32_t n, uint32_t leaf_max) {
+    memset(out, 0, sizeof *out);
+    uint32_t *order = (uint32_t *)malloc(sizeof(uint32_t) * (n ? n : 1));
+    if (n == 0) { out->lo = V3(0, 0, 0); out->hi = V3(0, 0, 0); return order; }
+    aabb all = aabb_empty();
+    for (uint32_t i = 0; i < n; i++) aabb_merge(&all, &boxes[i]);
+    out->lo = all.lo; out->hi = all.hi;
+    v3 ext = v3sub(all.hi, all.lo);
+    float sx = ext.x > 0.0f ? 1.0f / ext.x : 0.0f, sy = ext.y > 0.0f ? 1.0f / ext.y : 0.0f, sz = ext.z > 0.0f ? 1.0f / ext.z : 0.0f;
+    uint64_t *keys = (uint64_t *)malloc(sizeof(uint64_t) * n);
+    for (uint32_t i = 0; i < n; i++) {
+        v3 c = v3scale(v3add(boxes[i].lo, boxes[i].hi), 0.5f);
+        uint32_t code = morton30((c.x - all.lo.x) * sx, (c.y - all.lo.y) * sy, (c.z - all.lo.z) * sz);
+        keys[i] = ((uint64_t)code << 32) | i;
+    }
+    qsort(keys, n, sizeof(uint64_t), cmp_u64);
+    bbuild B; B.keys = keys; B.boxes = boxes; B.nnodes = 0; B.leaf_max = leaf_max;
+    B.nodes = (bnode *)malloc(sizeof(bnode) * (2 * (size_t)n + 1));
+    uint32_t root = build_range(&B, 0, n);
+    out->nodes = (orc_wnode *)malloc(sizeof(orc_wnode) * (B.nnodes));
+    out->node_count = 0;
+    collapse(B.nodes, root, out->nodes, &out->node_count);
+    for (uint32_t i = 0; i < n; i++) order[i] = (uint32_t)keys[i];
+    free(B.nodes); free(keys);
+    return order;
+}
+
+void orc_bvh_free(orc_bvh *b) { free(b->nodes); free(b->tris); free(b->inst); memset(b, 0, sizeof *b); }
+
+/* BLAS over the triangles of a geometry list (one BLAS per unique mesh list, Accel.zig:315-343) */
+void orc_build_blas(OrcContext *c, orc_bvh *out, const uint32_t *mesh_ids, uint32_t ngeo) {
+    uint32_t total = 0;
+    for (uint32_t g = 0; g < ngeo; g++) total += c->meshes[mesh_ids[g]].index_count;
+    orc_tri *tris = (orc_tri *)malloc(sizeof(orc_tri) * (total ? total : 1));
+    aabb *boxes = (aabb *)malloc(sizeof(aabb) * (total ? total : 1));
+    uint32_t k = 0;
+    for (uint32_t g = 0; g < ngeo; g++) {
+        const orc_mesh *m = &c->meshes[mesh_ids[g]];
+        for (uint32_t p = 0; p < m->index_count; p++, k++) {
+            v3 p0 = m->positions[m->indices[3 * p + 0]], p1 = m->positions[m->indices[3 * p + 1]], p2 = m->positions[m->indices[3 * p + 2]];
+            tris[k].v0 = p0; tris[k].v1 = p1; tris[k].v2 = p2; tris[k].geo = g; tris[k].prim = p;
+            boxes[k] = aabb_empty(); aabb_grow(&boxes[k], p0); aabb_grow(&boxes[k], p1); aabb_grow(&boxes[k], p2);
+        }
+    }
+    uint32_t *order = bvh_build_boxes(out, boxes, total, 4);
+    out->tris = (orc_tri *)malloc(sizeof(orc_tri) * (total ? total : 1));
+    out->tri_count = total;
+    for (uint32_t i = 0; i < total; i++) out->tris[i] = tris[order[i]];
+    free(order); free(tris); free(boxes);
+}
+
+static aabb transform_aabb(const m34 *m, v3 lo, v3 hi) {
+    aabb b = aabb_empty();
+    for (int i = 0; i < 8; i++) {
+        v3 p = V3((i & 1) ? hi.x : lo.x, (i & 2) ? hi.y : lo.y, (i & 4) ? hi.z : lo.z);
+        aabb_grow(&b, m34_mul_point(m, p));
+    }
+    /* pad: the transform above rounds; keep the box conservative */
+    v3 e = v3sub(b.hi, b.lo); float pad = 1e-6f * (fabsf(e.x) + fabsf(e.y) + fabsf(e.z)) + 1e-30f;
+    pad += 1e-6f * (fabsf(b.hi.x) + fabsf(b.hi.y) + fabsf(b.hi.z) + fabsf(b.lo.x) + fabsf(b.lo.y) + fabsf(b.lo.z));
+    b.lo = v3sub(b.lo, V3(pad, pad, pad)); b.hi = v3add(b.hi, V3(pad, pad, pad));
+    return b;
+}
+
+void orc_build_tlas(OrcContext *c) {
+    orc_bvh_free(&c->tlas);
+    uint32_t n = 0;
+    aabb *boxes = (aabb *)malloc(sizeof(aabb) * (c->instance_count ? c->instance_count : 1));
+    uint32_t *ids = (uint32_t *)malloc(sizeof(uint32_t) * (c->instance_count ? c->instance_count : 1));
+    for (uint32_t i = 0; i < c->instance_count; i++) {
+        const orc_instance *in = &c->instances[i];
+        if (!in->visible) continue;
+        const orc_bvh *b = &c->blases[in->blas];
+        if (b->tri_count == 0) continue;
+        boxes[n] = transform_aabb(&in->transform, b->lo, b->hi);
+        ids[n++] = i;
+    }
+    uint32_t *order = bvh_build_boxes(&c->tlas, boxes, n, 1);
+    c->tlas.inst = (uint32_t *)malloc(sizeof(uint32_t) * (n ? n : 1));
+    c->tlas.inst_count = n;
+    for (uint32_t i = 0; i < n; i++) c->tlas.inst[i] = ids[order[i]];
+    free(order); free(boxes); free(ids);
+}
+
+/* ---------------- intersection ---------------- */
+
+/* THE canonical triangle test: watertight ray/triangle intersection (Woop, Benthin, Wald, JCGT 2013),
+ * no culling.  Product kernels evaluate the same expression tree, so hits are bit-identical.
+ * Why not Möller–Trumbore: hardware ray tracing (the reference's TraceRay) is watertight, MT is not —
+ * with MT the reference's own furnace test (tests.zig:257-344, ==1 +-1e-5) fails on this mesh (a camera
+ * ray slips between two silhouette triangles, enters the sphere and is killed by Russian roulette).
+ * Returns 1 with t > 0 and Vulkan barycentrics (u,v) = weights of vertices 1 and 2 (world.hlsl:118). */
+typedef struct { int kx, ky, kz; float Sx, Sy, Sz; } orc_rayk;
+static inline float v3idx(v3 v, int i) { return i == 0 ? v.x : (i == 1 ? v.y : v.z); }
+static inline orc_rayk rayk_make(v3 d) {
+    orc_rayk k;
+    k.kz = 0;
+    if (fabsf(d.y) > fabsf(d.x)) k.kz = 1;
+    if (fabsf(d.z) > fabsf(v3idx(d, k.kz))) k.kz = 2;
+    k.kx = k.kz + 1; if (k.kx == 3) k.kx = 0;
+    k.ky = k.kx + 1; if (k.ky == 3) k.ky = 0;
+    if (v3idx(d, k.kz) < 0.0f) { int t = k.kx; k.kx = k.ky; k.ky = t; }
+    float dz = v3idx(d, k.kz);
+    k.Sx = v3idx(d, k.kx) / dz; k.Sy = v3idx(d, k.ky) / dz; k.Sz = 1.0f / dz;
+    return k;
+}
+static inline int tri_intersect(v3 o, const orc_rayk *k, const orc_tri *tr, float *t, float *u, float *v) {
+    const v3 A = v3sub(tr->v0, o), B = v3sub(tr->v1, o), C = v3sub(tr->v2, o);
+    const float Akz = v3idx(A, k->kz), Bkz = v3idx(B, k->kz), Ckz = v3idx(C, k->kz);
+    const float Ax = v3idx(A, k->kx) - k->Sx * Akz, Ay = v3idx(A, k->ky) - k->Sy * Akz;
+    const float Bx = v3idx(B, k->kx) - k->Sx * Bkz, By = v3idx(B, k->ky) - k->Sy * Bkz;
+    const float Cx = v3idx(C, k->kx) - k->Sx * Ckz, Cy = v3idx(C, k->ky) - k->Sy * Ckz;
+    float U = Cx * By - Cy * Bx, V = Ax * Cy - Ay * Cx, W = Bx * Ay - By * Ax;
+    if (U == 0.0f || V == 0.0f || W == 0.0f) {
+        double CxBy = (double)Cx * (double)By, CyBx = (double)Cy * (double)Bx; U = (float)(CxBy - CyBx);
+        double AxCy = (double)Ax * (double)Cy, AyCx = (double)Ay * (double)Cx; V = (float)(AxCy - AyCx);
+        double BxAy = (double)Bx * (double)Ay, ByAx = (double)By * (double)Ax; W = (float)(BxAy - ByAx);
+    }
+    if ((U < 0.0f || V < 0.0f || W < 0.0f) && (U > 0.0f || V > 0.0f || W > 0.0f)) return 0;
+    const float det = U + V + W;
+    if (det == 0.0f) return 0;
+    const float Az = k->Sz * Akz, Bz = k->Sz * Bkz, Cz = k->Sz * Ckz;
+    const float T = U * Az + V * Bz + W * Cz;
+    const float rcp = 1.0f / det;
+    const float tt = T * rcp;
+    if (!(tt > 0.0f)) return 0;
+    *t = tt; *u = V * rcp; *v = W * rcp;
+    return 1;
+}
+
+static inline float safe_inv(float d) { return fabsf(d) < 1e-30f ? (d < 0.0f ? -1e30f : 1e30f) : 1.0f / d; }
+
+/* slab test with a relative slack so equal-t candidates are never culled */
+static inline int box_hit(const float lo[3], const float hi[3], v3 o, v3 id, float tmax, float *tnear) {
+    float t1 = (lo[0] - o.x) * id.x, t2 = (hi[0] - o.x) * id.x;
+    float tn = orc_minf(t1, t2), tf = orc_maxf(t1, t2);
+    t1 = (lo[1] - o.y) * id.y; t2 = (hi[1] - o.y) * id.y;
+    tn = orc_maxf(tn, orc_minf(t1, t2)); tf = orc_minf(tf, orc_maxf(t1, t2));
+    t1 = (lo[2] - o.z) * id.z; t2 = (hi[2] - o.z) * id.z;
+    tn = orc_maxf(tn, orc_minf(t1, t2)); tf = orc_minf(tf, orc_maxf(t1, t2));
+    tn = tn - fabsf(tn) * 1e-5f; tf = tf + fabsf(tf) * 1e-5f;
+    *tnear = tn;
+    return tn <= tf && tf >= 0.0f && tn <= tmax;
+}
+
+/* traverse one BLAS in instance space. any_hit: return at the first triangle with t < tmax */
+static int blas_traverse(const orc_bvh *b, v3 o, v3 d, uint32_t inst, orc_hit *best, int any_hit, orc_counters *cnt) {
+    if (b->node_count == 0) return 0;
+    v3 id = V3(safe_inv(d.x), safe_inv(d.y), safe_inv(d.z));
+    const orc_rayk rk = rayk_make(d);
+    uint32_t stack[256]; int sp = 0; int found = 0;
+    stack[sp++] = 0;
+    while (sp > 0) {
+        const orc_wnode *n = &b->nodes[stack[--sp]];
+        cnt->node_visits++;
+        float tn[8]; int idx[8]; int nh = 0;
+        for (int i = 0; i < n->nchild; i++) {
+            float t;
+            if (box_hit(n->lo[i], n->hi[i], o, id, best->t, &t)) {
+                int j = nh++;
+                while (j > 0 && tn[j - 1] < t) { tn[j] = tn[j - 1]; idx[j] = idx[j - 1]; j--; } /* far first */
+                tn[j] = t; idx[j] = i;
+            }
+        }
+        for (int k = 0; k < nh; k++) {
+            int i = idx[k];
+            if (n->count[i] == 0) { if (sp < 255) stack[sp++] = n->child[i]; else { fprintf(stderr, "orc: bvh stack overflow\n"); abort(); } }
+        }
+        for (int k = nh - 1; k >= 0; k--) { /* leaves: near first */
+            int i = idx[k];
+            if (n->count[i] == 0) continue;
+            for (uint32_t q = 0; q < n->count[i]; q++) {
+                const orc_tri *tr = &b->tris[n->child[i] + q];
+                float t, u, v;
+                cnt->tri_tests++;
+                if (!tri_intersect(o, &rk, tr, &t, &u, &v)) continue;
+                if (any_hit) { if (t < best->t) return 1; continue; }
+                int closer = t < best->t;
+                if (!closer && t == best->t && best->inst != ORC_MAX_UINT) {
+                    closer = inst < best->inst || (inst == best->inst && (tr->geo < best->geo || (tr->geo == best->geo && tr->prim < best->prim)));
+                }
+                if (closer) { best->t = t; best->u = u; best->v = v; best->inst = inst; best->geo = tr->geo; best->prim = tr->prim; found = 1; }
+            }
+        }
+    }
+    return found;
+}
+
+static int scene_traverse(const OrcContext *c, v3 o, v3 d, float tmax, orc_hit *best, int any_hit, orc_counters *cnt) {
+    best->inst = ORC_MAX_UINT; best->t = tmax; best->geo = best->prim = 0; best->u = best->v = 0.0f;
+    const orc_bvh *tl = &c->tlas;
+    if (tl->node_count == 0) return 0;
+    v3 id = V3(safe_inv(d.x), safe_inv(d.y), safe_inv(d.z));
+    uint32_t stack[256]; int sp = 0; int found = 0;
+    stack[sp++] = 0;
+    while (sp > 0) {
+        const orc_wnode *n = &tl->nodes[stack[--sp]];
+        cnt->node_visits++;
+        float tn[8]; int idx[8]; int nh = 0;
+        for (int i = 0; i < n->nchild; i++) {
+            float t;
+            if (box_hit(n->lo[i], n->hi[i], o, id, best->t, &t)) {
+                int j = nh++;
+                while (j > 0 && tn[j - 1] < t) { tn[j] = tn[j - 1]; idx[j] = idx[j - 1]; j--; }
+                tn[j] = t; idx[j] = i;
+            }
+        }
+        for (int k = 0; k < nh; k++) { int i = idx[k]; if (n->count[i] == 0) stack[sp++] = n->child[i]; }
+        for (int k = nh - 1; k >= 0; k--) {
+            int i = idx[k];
+            if (n->count[i] == 0) continue;
+            for (uint32_t q = 0; q < n->count[i]; q++) {
+                uint32_t ii = tl->inst[n->child[i] + q];
+                const orc_instance *in = &c->instances[ii];
+                v3 oo = m34_mul_point(&in->world_to_instance, o);
+                v3 dd = m34_mul_vec(&in->world_to_instance, d);
+                if (blas_traverse(&c->blases[in->blas], oo, dd, ii, best, any_hit, cnt)) { found = 1; if (any_hit) return 1; }
+            }
+        }
+    }
+    return found;
+}
+
+/* Intersection::find (intersection.hlsl:18-22): tmin = 0, tmax = ray.tmax */
+int orc_closest_hit(const OrcContext *c, v3 o, v3 d, float tmax, orc_hit *h, orc_counters *cnt) {
+    cnt->closest_rays++;
+    return scene_traverse(c, o, d, tmax, h, 0, cnt);
+}
+/* ShadowIntersection::hit (intersection.hlsl:33-46) */
+int orc_shadow_hit(const OrcContext *c, v3 o, v3 d, float tmax, orc_counters *cnt) {
+    orc_hit h;
+    cnt->shadow_rays++;
+    return scene_traverse(c, o, d, tmax, &h, 1, cnt);
+}
