@@ -205,6 +205,22 @@ int MsneGetStats(const HdMoonshine*, MsneStats*);
 void MsneResetStats(HdMoonshine*);
 const char* MsneGetLastError(const HdMoonshine*);   /* NULL ctx → last creation error */
 
+/* ------------------------------------------------------------------ */
+/* Part 3 — diagnostics for parity tests and profiling (no reference   */
+/* equivalent; never needed by a renderer front end)                   */
+/* ------------------------------------------------------------------ */
+/* kernel_events: bracket every trace/shade launch with HIP events on the render stream (MsneStats *_ms fields);
+ * traversal_counters: count BVH node visits / triangle tests inside the trace kernels. */
+void MsneSetProfiling(HdMoonshine*, int kernel_events, int traversal_counters);
+int MsneGetTraversalCounters(HdMoonshine*, uint64_t out[4]); /* closest {nodes,tris}, shadow {nodes,tris} */
+/* rays: 7 floats each (origin, direction, tmax); out_ids: 4 per ray {hit, instance, geometry, primitive}; out_tuv: 3 per ray */
+int MsneTraceRays(HdMoonshine*, const float* rays, uint32_t n, int any_hit, uint32_t* out_ids, float* out_tuv);
+uint32_t MsneGetEnvSize(const HdMoonshine*);
+int MsneReadEnv(HdMoonshine*, float* rgb_out, float* lum_pyramid_out);
+uint32_t MsneGetAliasTable(HdMoonshine*, void* out_entries_20B, uint32_t max_entries);
+int MsneReadBvh(HdMoonshine*, void* nodes_out, uint32_t* node_count, void* tris_out, uint32_t* tri_count,
+                uint32_t* tlas_root, uint32_t* tlas_items_out, uint32_t* tlas_item_count);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,446 @@
+// bvh_build.hip — GPU LBVH build: replaces the driver's vkCmdBuildAccelerationStructuresKHR for BLAS and
+// TLAS (engine/hrtsystem/Accel.zig:94-184 makeBlases, :484 TLAS build, :629-679 recordRebuild).
+//
+// Pipeline (all HIP kernels, host only sequences launches and reads level counts):
+//   k_prim_boxes / k_bounds → k_morton (30-bit) → LSD radix sort 4 x 8 bit (k_radix_hist / _scan / _scatter)
+//   → k_hierarchy (Karras 2012) → k_fit (bottom-up AABBs, agent-scope release/acquire hand-off)
+//   → k_collapse (level-synchronous collapse to 8-wide, leaves <= leaf_max items, quantised 80-B nodes)
+//   → k_emit_tris / k_emit_items.
+// The same builder serves BLAS (items = triangles) and TLAS (items = instances).
+#include "msne_device.h"
+#include <vector>
+#include <cstdio>
+#include <algorithm>
+
+namespace msne {
+
+struct Box { float lo[3]; float hi[3]; };
+
+// ---------------- helpers ----------------
+__device__ __forceinline__ uint32_t float_to_ordered(float f) { uint32_t u = f2u(f); return (u & 0x80000000u) ? ~u : (u | 0x80000000u); }
+__host__ __device__ __forceinline__ float ordered_to_float(uint32_t u) { return u2f((u & 0x80000000u) ? (u & 0x7fffffffu) : ~u); }
+
+__device__ __forceinline__ uint32_t expand_bits10(uint32_t v) {
+    v = (v * 0x00010001u) & 0xFF0000FFu;
+    v = (v * 0x00000101u) & 0x0F00F00Fu;
+    v = (v * 0x00000011u) & 0xC30C30C3u;
+    v = (v * 0x00000005u) & 0x49249249u;
+    return v;
+}
+
+// ---------------- primitive boxes ----------------
+// triangles of one BLAS: geometry g -> mesh; prim boxes + source records
+struct BlasGeo { const float* positions; const uint32_t* indices; uint32_t tri_offset, tri_count; };
+
+__global__ void k_prim_boxes_tris(const BlasGeo* geos, uint32_t ngeo, uint32_t n, Box* boxes) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    uint32_t g = 0;
+    while (g + 1 < ngeo && i >= geos[g + 1].tri_offset) g++;
+    const BlasGeo ge = geos[g];
+    const uint32_t p = i - ge.tri_offset;
+    const uint32_t i0 = ge.indices[3 * p], i1 = ge.indices[3 * p + 1], i2 = ge.indices[3 * p + 2];
+    Box b;
+    for (int k = 0; k < 3; k++) {
+        float a = ge.positions[3 * (size_t)i0 + k], bb = ge.positions[3 * (size_t)i1 + k], c = ge.positions[3 * (size_t)i2 + k];
+        b.lo[k] = fminf(a, fminf(bb, c)); b.hi[k] = fmaxf(a, fmaxf(bb, c));
+    }
+    boxes[i] = b;
+}
+
+__global__ void k_bounds(const Box* boxes, uint32_t n, uint32_t* bounds /*6 ordered uints: lo xyz, hi xyz*/) {
+    __shared__ uint32_t s[6];
+    if (threadIdx.x < 6) s[threadIdx.x] = threadIdx.x < 3 ? 0xFFFFFFFFu : 0u;
+    __syncthreads();
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const Box b = boxes[i];
+        for (int k = 0; k < 3; k++) { atomicMin(&s[k], float_to_ordered(b.lo[k])); atomicMax(&s[3 + k], float_to_ordered(b.hi[k])); }
+    }
+    __syncthreads();
+    if (threadIdx.x < 3) atomicMin(&bounds[threadIdx.x], s[threadIdx.x]);
+    else if (threadIdx.x < 6) atomicMax(&bounds[threadIdx.x], s[threadIdx.x]);
+}
+
+__global__ void k_morton(const Box* boxes, uint32_t n, const uint32_t* bounds, uint32_t* keys, uint32_t* idx) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const Box b = boxes[i];
+    uint32_t code = 0;
+    for (int k = 0; k < 3; k++) {
+        const float lo = ordered_to_float(bounds[k]), hi = ordered_to_float(bounds[3 + k]);
+        const float ext = hi - lo;
+        const float c = (b.lo[k] + b.hi[k]) * 0.5f;
+        float x = ext > 0.0f ? (c - lo) / ext : 0.0f;
+        x = fminf(fmaxf(x * 1024.0f, 0.0f), 1023.0f);
+        code |= expand_bits10((uint32_t)x) << (2 - k);
+    }
+    keys[i] = code; idx[i] = i;
+}
+
+// ---------------- LSD radix sort (stable), 8 bits per pass ----------------
+constexpr int RS_TILE = 2048;
+__global__ __launch_bounds__(256) void k_radix_hist(const uint32_t* keys, uint32_t n, int shift, uint32_t* ghist, uint32_t ntiles) {
+    __shared__ uint32_t h[256];
+    h[threadIdx.x] = 0;
+    __syncthreads();
+    const uint32_t base = blockIdx.x * RS_TILE;
+    for (uint32_t j = threadIdx.x; j < RS_TILE; j += 256) { uint32_t i = base + j; if (i < n) atomicAdd(&h[(keys[i] >> shift) & 255u], 1u); }
+    __syncthreads();
+    ghist[threadIdx.x * ntiles + blockIdx.x] = h[threadIdx.x];
+}
+__global__ __launch_bounds__(1024) void k_radix_scan(uint32_t* ghist, uint32_t total) {
+    __shared__ uint32_t part[1024];
+    const uint32_t per = (total + 1023u) / 1024u;
+    const uint32_t a = threadIdx.x * per, b = a + per < total ? a + per : total;
+    uint32_t s = 0;
+    for (uint32_t i = a; i < b; i++) s += ghist[i];
+    part[threadIdx.x] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) { uint32_t run = 0; for (int i = 0; i < 1024; i++) { uint32_t v = part[i]; part[i] = run; run += v; } }
+    __syncthreads();
+    uint32_t run = part[threadIdx.x];
+    for (uint32_t i = a; i < b; i++) { uint32_t v = ghist[i]; ghist[i] = run; run += v; }
+}
+// one wave per tile, elements scattered in order → stable
+__global__ __launch_bounds__(64) void k_radix_scatter(const uint32_t* keys, const uint32_t* vals, uint32_t n, int shift,
+                                                       const uint32_t* ghist, uint32_t ntiles, uint32_t* okeys, uint32_t* ovals) {
+    __shared__ uint32_t base[256];
+    for (int j = threadIdx.x; j < 256; j += 64) base[j] = ghist[j * ntiles + blockIdx.x];
+    __syncthreads();
+    const uint32_t lane = threadIdx.x;
+    const unsigned long long lt = lane == 0 ? 0ull : (~0ull >> (64 - lane));
+    const uint32_t tbase = blockIdx.x * RS_TILE;
+    for (uint32_t c = 0; c < RS_TILE; c += 64) {
+        const uint32_t i = tbase + c + lane;
+        const bool valid = i < n;
+        const uint32_t k = valid ? keys[i] : 0u, v = valid ? vals[i] : 0u;
+        const uint32_t d = (k >> shift) & 255u;
+        unsigned long long peers = __ballot(valid);
+#pragma unroll
+        for (int b = 0; b < 8; b++) {
+            const unsigned long long bm = __ballot((d >> b) & 1u);
+            peers &= ((d >> b) & 1u) ? bm : ~bm;
+        }
+        const uint32_t rank = __popcll(peers & lt);
+        uint32_t pos = 0;
+        if (valid) pos = base[d] + rank;
+        __syncthreads();
+        if (valid && rank == 0) base[d] += (uint32_t)__popcll(peers);
+        __syncthreads();
+        if (valid) { okeys[pos] = k; ovals[pos] = v; }
+    }
+}
+
+// ---------------- Karras 2012 hierarchy ----------------
+constexpr uint32_t REF_LEAF = 0x80000000u;
+struct BinTree {
+    uint32_t* left; uint32_t* right;         // refs (bit31 = leaf)
+    uint32_t* parent_int; uint32_t* parent_leaf;
+    uint32_t* first; uint32_t* last;         // sorted range covered by internal node i
+    Box* box;                                // internal node boxes
+    uint32_t* flag;
+};
+
+__device__ __forceinline__ int delta(const uint32_t* keys, int n, int i, int j) {
+    if (j < 0 || j >= n) return -1;
+    const uint32_t a = keys[i], b = keys[j];
+    if (a == b) return 32 + __clz((uint32_t)i ^ (uint32_t)j);
+    return __clz(a ^ b);
+}
+__global__ void k_hierarchy(const uint32_t* keys, int n, BinTree t) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n - 1) return;
+    const int d = (delta(keys, n, i, i + 1) - delta(keys, n, i, i - 1)) >= 0 ? 1 : -1;
+    const int dmin = delta(keys, n, i, i - d);
+    int lmax = 2;
+    while (delta(keys, n, i, i + lmax * d) > dmin) lmax *= 2;
+    int l = 0;
+    for (int s = lmax / 2; s >= 1; s /= 2) if (delta(keys, n, i, i + (l + s) * d) > dmin) l += s;
+    const int j = i + l * d;
+    const int dnode = delta(keys, n, i, j);
+    int s = 0, tt = l;
+    do { tt = (tt + 1) / 2; if (delta(keys, n, i, i + (s + tt) * d) > dnode) s += tt; } while (tt > 1);
+    const int gamma = i + s * d + (d < 0 ? d : 0);
+    const int lo = i < j ? i : j, hi = i < j ? j : i;
+    const uint32_t L = (lo == gamma) ? (REF_LEAF | (uint32_t)gamma) : (uint32_t)gamma;
+    const uint32_t R = (hi == gamma + 1) ? (REF_LEAF | (uint32_t)(gamma + 1)) : (uint32_t)(gamma + 1);
+    t.left[i] = L; t.right[i] = R; t.first[i] = (uint32_t)lo; t.last[i] = (uint32_t)hi;
+    if (L & REF_LEAF) t.parent_leaf[gamma] = (uint32_t)i; else t.parent_int[gamma] = (uint32_t)i;
+    if (R & REF_LEAF) t.parent_leaf[gamma + 1] = (uint32_t)i; else t.parent_int[gamma + 1] = (uint32_t)i;
+    if (i == 0) t.parent_int[0] = MAX_UINT;
+}
+
+__global__ void k_gather_boxes(const Box* boxes, const uint32_t* idx, uint32_t n, Box* sorted) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) sorted[i] = boxes[idx[i]];
+}
+
+__device__ __forceinline__ Box load_box_agent(const Box* p) {   // L1-bypassing loads of another workgroup's result
+    Box b;
+    const float* f = reinterpret_cast<const float*>(p);
+    for (int k = 0; k < 3; k++) { b.lo[k] = __hip_atomic_load(f + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); b.hi[k] = __hip_atomic_load(f + 3 + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+    return b;
+}
+// bottom-up fit: the second arriver at a node owns it.  Hand-off = plain stores → agent release fence →
+// relaxed agent atomic; consumer: atomic → agent acquire fence → L1-bypassing loads.
+__global__ void k_fit(const Box* leaf_boxes, uint32_t n, BinTree t) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    uint32_t node = t.parent_leaf[i];
+    while (node != MAX_UINT) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const uint32_t old = __hip_atomic_fetch_add(&t.flag[node], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (old == 0) return;
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        const uint32_t L = t.left[node], R = t.right[node];
+        const Box a = (L & REF_LEAF) ? leaf_boxes[L & ~REF_LEAF] : load_box_agent(&t.box[L]);
+        const Box b = (R & REF_LEAF) ? leaf_boxes[R & ~REF_LEAF] : load_box_agent(&t.box[R]);
+        Box u;
+        for (int k = 0; k < 3; k++) { u.lo[k] = fminf(a.lo[k], b.lo[k]); u.hi[k] = fmaxf(a.hi[k], b.hi[k]); }
+        t.box[node] = u;
+        node = t.parent_int[node];
+    }
+}
+
+// ---------------- collapse to 8-wide + quantise ----------------
+struct CollapseWork { uint32_t bin; uint32_t wide; };
+
+__device__ __forceinline__ float box_area(const Box& b) {
+    const float dx = b.hi[0] - b.lo[0], dy = b.hi[1] - b.lo[1], dz = b.hi[2] - b.lo[2];
+    return dx * dy + dy * dz + dz * dx;
+}
+
+__global__ void k_collapse(const CollapseWork* work, uint32_t nwork, CollapseWork* next, uint32_t* next_count,
+                           BinTree t, const Box* leaf_boxes, const uint32_t* sorted_idx, uint32_t leaf_max,
+                           Node8* nodes, uint32_t* node_counter, uint32_t* item_counter, uint32_t* item_src) {
+    const uint32_t w = blockIdx.x * blockDim.x + threadIdx.x;
+    if (w >= nwork) return;
+    const uint32_t bin = work[w].bin, widx = work[w].wide;
+    uint32_t ch[8]; int nch = 0;
+    auto leaf_like = [&](uint32_t r) -> bool { return (r & REF_LEAF) || (t.last[r] - t.first[r] + 1u) <= leaf_max; };
+    auto ref_box = [&](uint32_t r) -> Box { return (r & REF_LEAF) ? leaf_boxes[r & ~REF_LEAF] : t.box[r]; };
+    if (leaf_like(bin)) ch[nch++] = bin;
+    else { ch[nch++] = t.left[bin]; ch[nch++] = t.right[bin]; }
+    while (nch < 8) {
+        int best = -1; float ba = -1.0f;
+        for (int i = 0; i < nch; i++) if (!leaf_like(ch[i])) { Box b = ref_box(ch[i]); float ar = box_area(b); if (ar > ba) { ba = ar; best = i; } }
+        if (best < 0) break;
+        const uint32_t c = ch[best];
+        ch[best] = t.left[c]; ch[nch++] = t.right[c];
+    }
+    Box cb[8]; Box nb;
+    for (int k = 0; k < 3; k++) { nb.lo[k] = 3.0e38f; nb.hi[k] = -3.0e38f; }
+    uint32_t n_internal = 0, n_items = 0;
+    for (int i = 0; i < nch; i++) {
+        cb[i] = ref_box(ch[i]);
+        for (int k = 0; k < 3; k++) { nb.lo[k] = fminf(nb.lo[k], cb[i].lo[k]); nb.hi[k] = fmaxf(nb.hi[k], cb[i].hi[k]); }
+        if (leaf_like(ch[i])) n_items += (ch[i] & REF_LEAF) ? 1u : (t.last[ch[i]] - t.first[ch[i]] + 1u);
+        else n_internal++;
+    }
+    const uint32_t child_base = n_internal ? atomicAdd(node_counter, n_internal) : 0u;
+    const uint32_t item_base = n_items ? atomicAdd(item_counter, n_items) : 0u;
+    const uint32_t qpos = n_internal ? atomicAdd(next_count, n_internal) : 0u;
+
+    Node8 nd;
+    nd.ox = nb.lo[0]; nd.oy = nb.lo[1]; nd.oz = nb.lo[2];
+    uint8_t e[3]; float inv_s[3];
+    for (int k = 0; k < 3; k++) {
+        const float ext = nb.hi[k] - nb.lo[k];
+        // smallest power of two s with ext/s <= 254 (one step of headroom for the outward rounding below)
+        int ex = 0;
+        if (ext > 0.0f) { const float q = ext / 254.0f; ex = (int)((f2u(q) >> 23) & 0xff) + 1; } else ex = 1;
+        if (ex < 1) ex = 1;
+        if (ex > 254) ex = 254;
+        e[k] = (uint8_t)ex;
+        inv_s[k] = u2f((uint32_t)(254 - ex) << 23);   // 2^-(ex-127)
+    }
+    nd.ex = e[0]; nd.ey = e[1]; nd.ez = e[2];
+    uint32_t imask = 0, ii = 0, io = 0;
+    for (int i = 0; i < 8; i++) {
+        nd.meta[i] = 0xff;
+        for (int k = 0; k < 3; k++) { nd.qlo[k][i] = 255; nd.qhi[k][i] = 0; }
+    }
+    for (int i = 0; i < nch; i++) {
+        for (int k = 0; k < 3; k++) {
+            const float origin = k == 0 ? nd.ox : (k == 1 ? nd.oy : nd.oz);
+            float ql = floorf((cb[i].lo[k] - origin) * inv_s[k] - 1e-3f);
+            float qh = ceilf((cb[i].hi[k] - origin) * inv_s[k] + 1e-3f);
+            ql = fminf(fmaxf(ql, 0.0f), 255.0f); qh = fminf(fmaxf(qh, 0.0f), 255.0f);
+            nd.qlo[k][i] = (uint8_t)ql; nd.qhi[k][i] = (uint8_t)qh;
+        }
+        if (leaf_like(ch[i])) {
+            const uint32_t first = (ch[i] & REF_LEAF) ? (ch[i] & ~REF_LEAF) : t.first[ch[i]];
+            const uint32_t cnt = (ch[i] & REF_LEAF) ? 1u : (t.last[ch[i]] - t.first[ch[i]] + 1u);
+            nd.meta[i] = (uint8_t)(((cnt - 1u) << 5) | io);
+            for (uint32_t q = 0; q < cnt; q++) item_src[item_base + io + q] = sorted_idx[first + q];
+            io += cnt;
+        } else {
+            imask |= 1u << i;
+            nd.meta[i] = 0;
+            next[qpos + ii].bin = ch[i]; next[qpos + ii].wide = child_base + ii;
+            ii++;
+        }
+    }
+    nd.imask = (uint8_t)imask;
+    nd.child_base = child_base; nd.item_base = item_base;
+    nodes[widx] = nd;
+}
+
+__global__ void k_emit_tris(const BlasGeo* geos, uint32_t ngeo, const uint32_t* item_src, uint32_t item_begin, uint32_t n, TriRec* tris) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t src = item_src[item_begin + i];
+    uint32_t g = 0;
+    while (g + 1 < ngeo && src >= geos[g + 1].tri_offset) g++;
+    const BlasGeo ge = geos[g];
+    const uint32_t p = src - ge.tri_offset;
+    const uint32_t i0 = ge.indices[3 * p], i1 = ge.indices[3 * p + 1], i2 = ge.indices[3 * p + 2];
+    const float* P = ge.positions;
+    TriRec r;
+    r.v0x = P[3 * (size_t)i0]; r.v0y = P[3 * (size_t)i0 + 1]; r.v0z = P[3 * (size_t)i0 + 2];
+    r.v1x = P[3 * (size_t)i1]; r.v1y = P[3 * (size_t)i1 + 1]; r.v1z = P[3 * (size_t)i1 + 2];
+    r.v2x = P[3 * (size_t)i2]; r.v2y = P[3 * (size_t)i2 + 1]; r.v2z = P[3 * (size_t)i2 + 2];
+    r.geo = g; r.prim = p; r.pad = 0;
+    tris[item_begin + i] = r;
+}
+__global__ void k_emit_items(const uint32_t* item_src, uint32_t item_begin, uint32_t n, const uint32_t* ids, uint32_t* out) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[item_begin + i] = ids[item_src[item_begin + i]];
+}
+
+// ---------------- host orchestration ----------------
+#define HIPCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "moonshine_amd: HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); return false; } } while (0)
+
+struct BuildScratch {
+    uint32_t cap = 0;
+    Box *boxes = nullptr, *sorted = nullptr, *ibox = nullptr;
+    uint32_t *keys = nullptr, *keys2 = nullptr, *idx = nullptr, *idx2 = nullptr, *ghist = nullptr, *bounds = nullptr;
+    uint32_t *left = nullptr, *right = nullptr, *pint = nullptr, *pleaf = nullptr, *first = nullptr, *last = nullptr, *flag = nullptr;
+    CollapseWork *wa = nullptr, *wb = nullptr;
+    uint32_t* next_count = nullptr;
+    void release() {
+        void* p[] = { boxes, sorted, ibox, keys, keys2, idx, idx2, ghist, bounds, left, right, pint, pleaf, first, last, flag, wa, wb, next_count };
+        for (void* q : p) if (q) (void)hipFree(q);
+        *this = BuildScratch();
+    }
+    bool reserve(uint32_t n) {
+        if (n <= cap) return true;
+        release();
+        const size_t N = n;
+        const uint32_t ntiles = (n + RS_TILE - 1) / RS_TILE;
+        HIPCHK(hipMalloc(&boxes, N * sizeof(Box))); HIPCHK(hipMalloc(&sorted, N * sizeof(Box))); HIPCHK(hipMalloc(&ibox, N * sizeof(Box)));
+        HIPCHK(hipMalloc(&keys, N * 4)); HIPCHK(hipMalloc(&keys2, N * 4)); HIPCHK(hipMalloc(&idx, N * 4)); HIPCHK(hipMalloc(&idx2, N * 4));
+        HIPCHK(hipMalloc(&ghist, (size_t)ntiles * 256 * 4)); HIPCHK(hipMalloc(&bounds, 6 * 4));
+        HIPCHK(hipMalloc(&left, N * 4)); HIPCHK(hipMalloc(&right, N * 4)); HIPCHK(hipMalloc(&pint, N * 4)); HIPCHK(hipMalloc(&pleaf, N * 4));
+        HIPCHK(hipMalloc(&first, N * 4)); HIPCHK(hipMalloc(&last, N * 4)); HIPCHK(hipMalloc(&flag, N * 4));
+        HIPCHK(hipMalloc(&wa, N * sizeof(CollapseWork))); HIPCHK(hipMalloc(&wb, N * sizeof(CollapseWork)));
+        HIPCHK(hipMalloc(&next_count, 4));
+        cap = n;
+        return true;
+    }
+};
+
+static BuildScratch g_scratch;   // guarded by the context mutex of the caller
+void bvh_release_scratch() { g_scratch.release(); }
+
+// Builds a wide BVH over the n boxes in g_scratch.boxes.  Nodes are appended at *node_counter (device),
+// items at *item_counter; item_src[pos] = source box index for final item position pos.
+// Returns the root node index and the root box (host).
+static bool build_from_boxes(hipStream_t s, uint32_t n, uint32_t leaf_max, Node8* nodes, uint32_t* node_counter, uint32_t node_capacity,
+                             uint32_t* item_counter, uint32_t* item_src, uint32_t* root_out, Box* root_box) {
+    BuildScratch& S = g_scratch;
+    const uint32_t ntiles = (n + RS_TILE - 1) / RS_TILE;
+    const uint32_t init_bounds[6] = { 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0u, 0u, 0u };
+    HIPCHK(hipMemcpyAsync(S.bounds, init_bounds, sizeof init_bounds, hipMemcpyHostToDevice, s));
+    hipLaunchKernelGGL(k_bounds, dim3(std::min<uint32_t>((n + 255) / 256, 1024)), dim3(256), 0, s, S.boxes, n, S.bounds);
+    hipLaunchKernelGGL(k_morton, dim3((n + 255) / 256), dim3(256), 0, s, S.boxes, n, S.bounds, S.keys, S.idx);
+    uint32_t *ka = S.keys, *kb = S.keys2, *va = S.idx, *vb = S.idx2;
+    for (int pass = 0; pass < 4; pass++) {
+        const int shift = pass * 8;
+        hipLaunchKernelGGL(k_radix_hist, dim3(ntiles), dim3(256), 0, s, ka, n, shift, S.ghist, ntiles);
+        hipLaunchKernelGGL(k_radix_scan, dim3(1), dim3(1024), 0, s, S.ghist, ntiles * 256u);
+        hipLaunchKernelGGL(k_radix_scatter, dim3(ntiles), dim3(64), 0, s, ka, va, n, shift, S.ghist, ntiles, kb, vb);
+        std::swap(ka, kb); std::swap(va, vb);
+    }
+    // after 4 passes (ka,va) are back in (keys, idx)
+    hipLaunchKernelGGL(k_gather_boxes, dim3((n + 255) / 256), dim3(256), 0, s, S.boxes, va, n, S.sorted);
+    BinTree t{ S.left, S.right, S.pint, S.pleaf, S.first, S.last, S.ibox, S.flag };
+    uint32_t root_ref;
+    if (n >= 2) {
+        HIPCHK(hipMemsetAsync(S.flag, 0, (size_t)n * 4, s));
+        hipLaunchKernelGGL(k_hierarchy, dim3((n - 1 + 255) / 256), dim3(256), 0, s, ka, (int)n, t);
+        hipLaunchKernelGGL(k_fit, dim3((n + 255) / 256), dim3(256), 0, s, S.sorted, n, t);
+        root_ref = 0;
+        HIPCHK(hipMemcpyAsync(root_box, S.ibox, sizeof(Box), hipMemcpyDeviceToHost, s));
+    } else {
+        root_ref = REF_LEAF | 0u;
+        HIPCHK(hipMemcpyAsync(root_box, S.sorted, sizeof(Box), hipMemcpyDeviceToHost, s));
+    }
+    // root wide node
+    uint32_t root_wide = 0;
+    HIPCHK(hipMemcpyAsync(&root_wide, node_counter, 4, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    if (root_wide + n + 1 > node_capacity) { fprintf(stderr, "moonshine_amd: node pool exhausted\n"); return false; }
+    const uint32_t after = root_wide + 1;
+    HIPCHK(hipMemcpyAsync(node_counter, &after, 4, hipMemcpyHostToDevice, s));
+    CollapseWork w0{ root_ref, root_wide };
+    HIPCHK(hipMemcpyAsync(S.wa, &w0, sizeof w0, hipMemcpyHostToDevice, s));
+    uint32_t nwork = 1;
+    CollapseWork *cur = S.wa, *nxt = S.wb;
+    while (nwork) {
+        HIPCHK(hipMemsetAsync(S.next_count, 0, 4, s));
+        hipLaunchKernelGGL(k_collapse, dim3((nwork + 63) / 64), dim3(64), 0, s, cur, nwork, nxt, S.next_count, t, S.sorted, va, leaf_max,
+                           nodes, node_counter, item_counter, item_src);
+        HIPCHK(hipMemcpyAsync(&nwork, S.next_count, 4, hipMemcpyDeviceToHost, s));
+        HIPCHK(hipStreamSynchronize(s));
+        std::swap(cur, nxt);
+    }
+    *root_out = root_wide;
+    return true;
+}
+
+// BLAS over the triangles of a geometry list (Accel.zig:94-184; one BLAS per unique mesh list, :315-343)
+bool bvh_build_blas(hipStream_t s, const std::vector<BlasGeo>& geos, uint32_t ntris, Node8* nodes, uint32_t* node_counter, uint32_t node_capacity,
+                    TriRec* tris, uint32_t* tri_counter, uint32_t* item_src, uint32_t* root_out, float root_box[6]) {
+    if (ntris == 0) { *root_out = MAX_UINT; for (int k = 0; k < 6; k++) root_box[k] = 0.0f; return true; }
+    if (!g_scratch.reserve(ntris)) return false;
+    BlasGeo* dgeos = nullptr;
+    HIPCHK(hipMalloc(&dgeos, geos.size() * sizeof(BlasGeo)));
+    HIPCHK(hipMemcpyAsync(dgeos, geos.data(), geos.size() * sizeof(BlasGeo), hipMemcpyHostToDevice, s));
+    hipLaunchKernelGGL(k_prim_boxes_tris, dim3((ntris + 255) / 256), dim3(256), 0, s, dgeos, (uint32_t)geos.size(), ntris, g_scratch.boxes);
+    uint32_t item_begin = 0;
+    HIPCHK(hipMemcpyAsync(&item_begin, tri_counter, 4, hipMemcpyDeviceToHost, s));
+    Box rb;
+    bool ok = build_from_boxes(s, ntris, 4, nodes, node_counter, node_capacity, tri_counter, item_src, root_out, &rb);
+    if (ok) {
+        hipLaunchKernelGGL(k_emit_tris, dim3((ntris + 255) / 256), dim3(256), 0, s, dgeos, (uint32_t)geos.size(), item_src, item_begin, ntris, tris);
+        HIPCHK(hipStreamSynchronize(s));
+        for (int k = 0; k < 3; k++) { root_box[k] = rb.lo[k]; root_box[3 + k] = rb.hi[k]; }
+    }
+    (void)hipFree(dgeos);
+    return ok;
+}
+
+// TLAS over instance world boxes (Accel.zig:484).  host_boxes: n x {lo[3],hi[3]}, ids: instance index per box.
+bool bvh_build_tlas(hipStream_t s, const float* host_boxes, const uint32_t* host_ids, uint32_t n, Node8* nodes, uint32_t* node_counter, uint32_t node_capacity,
+                    uint32_t* tlas_items, uint32_t* item_counter, uint32_t* item_src, uint32_t* root_out) {
+    if (n == 0) { *root_out = MAX_UINT; return true; }
+    if (!g_scratch.reserve(n)) return false;
+    HIPCHK(hipMemcpyAsync(g_scratch.boxes, host_boxes, (size_t)n * sizeof(Box), hipMemcpyHostToDevice, s));
+    uint32_t* dids = nullptr;
+    HIPCHK(hipMalloc(&dids, (size_t)n * 4));
+    HIPCHK(hipMemcpyAsync(dids, host_ids, (size_t)n * 4, hipMemcpyHostToDevice, s));
+    uint32_t item_begin = 0;
+    HIPCHK(hipMemcpyAsync(&item_begin, item_counter, 4, hipMemcpyDeviceToHost, s));
+    Box rb;
+    bool ok = build_from_boxes(s, n, 1, nodes, node_counter, node_capacity, item_counter, item_src, root_out, &rb);
+    if (ok) {
+        hipLaunchKernelGGL(k_emit_items, dim3((n + 255) / 256), dim3(256), 0, s, item_src, item_begin, n, dids, tlas_items);
+        HIPCHK(hipStreamSynchronize(s));
+    }
+    (void)hipFree(dids);
+    return ok;
+}
+
+}  // namespace msne

@@ -1,0 +1,764 @@
+// context.hip — implementation of include/moonshine_amd.h: the host side of the hot path.
+// Mirrors hydra/hydra.zig:107-558 (the reference's C ABI) and the engine/hrtsystem managers behind it:
+// MeshManager.zig (meshes), MaterialManager.zig (materials + TextureManager), Accel.zig (instances, BLAS/TLAS,
+// alias table), BackgroundManager.zig (environment), Camera.zig + core/Sensor.zig (lenses, sensors),
+// pipeline.zig (specialization constants).  Everything the GPU touches lives in HBM for the life of the
+// context; the render loop issues only kernel launches (no per-bounce host synchronisation up to 16 bounces).
+#include "../../include/moonshine_amd.h"
+#include "msne_device.h"
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <map>
+#include <mutex>
+#include <string>
+#include <vector>
+
+namespace msne {
+// kernels' host wrappers (trace.hip, integrator.hip, env.hip, bvh_build.hip)
+void launch_trace_closest(hipStream_t, int, bool, const SceneView&, const PathState&, const HitBuf&, Counters*, uint32_t*, uint32_t*, unsigned long long*);
+void launch_trace_shadow(hipStream_t, int, bool, const SceneView&, const ShadowQueue&, const PathState&, Counters*, uint32_t*, uint32_t*, unsigned long long*);
+void launch_trace_probe(hipStream_t, int, const SceneView&, const float*, uint32_t, int, uint32_t*, float*, uint32_t*, uint32_t*);
+size_t trace_spill_words(int grid);
+void launch_raygen(hipStream_t, int, const ShardView&, const CameraConsts&, const PipelineOpts&, uint32_t, uint32_t, const PathState&, Counters*);
+void launch_shade(hipStream_t, int, const SceneView&, const PipelineOpts&, const PathState&, const HitBuf&, const PathState&, const ShadowQueue&, float4*, Counters*);
+void launch_advance(hipStream_t, Counters*, int);
+void launch_film(hipStream_t, int, const ShardView&, const PipelineOpts&, const float4*, uint32_t, int, int, uint32_t, float4*, float4*);
+void launch_unpack_film(hipStream_t, int, const ShardView&, const float4*, uint32_t, uint32_t, size_t, float4*);
+void launch_env_build(hipStream_t, const float4*, uint32_t, uint32_t, float4*, float*, const uint32_t*, uint32_t, uint32_t);
+struct BlasGeo { const float* positions; const uint32_t* indices; uint32_t tri_offset, tri_count; };
+bool bvh_build_blas(hipStream_t, const std::vector<BlasGeo>&, uint32_t, Node8*, uint32_t*, uint32_t, TriRec*, uint32_t*, uint32_t*, uint32_t*, float[6]);
+bool bvh_build_tlas(hipStream_t, const float*, const uint32_t*, uint32_t, Node8*, uint32_t*, uint32_t, uint32_t*, uint32_t*, uint32_t*, uint32_t*);
+void bvh_release_scratch();
+}  // namespace msne
+
+using namespace msne;
+
+static thread_local std::string g_create_error;
+
+#define CHECK_HIP(ctx, x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { (ctx)->fail(std::string("HIP: ") + hipGetErrorString(e_) + " (" #x ")"); return false; } } while (0)
+
+namespace {
+
+template <typename T> struct DevBuf {
+    T* p = nullptr; size_t n = 0;
+    bool alloc(size_t count) { release(); if (count == 0) count = 1; if (hipMalloc(&p, count * sizeof(T)) != hipSuccess) { p = nullptr; return false; } n = count; return true; }
+    bool ensure(size_t count) { return count <= n && p ? true : alloc(count); }
+    void release() { if (p) (void)hipFree(p); p = nullptr; n = 0; }
+    ~DevBuf() { release(); }
+    DevBuf() = default; DevBuf(const DevBuf&) = delete; DevBuf& operator=(const DevBuf&) = delete;
+};
+
+struct TextureH { uint32_t w, h; std::vector<float> rgba; };
+struct MeshH {
+    DevBuf<float> positions, normals, texcoords; DevBuf<uint32_t> indices;
+    std::vector<float> h_positions; std::vector<uint32_t> h_indices;   // host copies for the alias-table areas (Accel.zig:503-519)
+    uint32_t position_count = 0, attribute_count = 0, index_count = 0; bool has_normals = false, has_texcoords = false;
+};
+struct InstanceH { m34 transform; bool visible; std::vector<GeometryRec> geos; };
+struct BlasInfo { uint32_t root; float box[6]; uint32_t tris; };
+struct MaterialUpdate { bool has[6] = { false, false, false, false, false, false }; uint32_t tex[5] = { 0, 0, 0, 0, 0 }; float ior = 0.0f; };
+
+struct SensorH {
+    Extent2D extent{}; uint32_t sample_count = 0;
+    ShardView shard{};
+    DevBuf<float4> film_packed, film_full, color;
+    float4* host = nullptr;   // pinned, row-major float4[w*h]
+};
+
+struct PathBuffers {
+    DevBuf<float> f;      // 19 float arrays
+    DevBuf<uint32_t> u;   // 3 uint arrays
+    size_t cap = 0;
+    PathState view() const {
+        PathState s; float* b = f.p; size_t c = cap;
+        s.ox = b + 0 * c; s.oy = b + 1 * c; s.oz = b + 2 * c; s.dx = b + 3 * c; s.dy = b + 4 * c; s.dz = b + 5 * c;
+        s.tx = b + 6 * c; s.ty = b + 7 * c; s.tz = b + 8 * c; s.lx = b + 9 * c; s.ly = b + 10 * c; s.lz = b + 11 * c;
+        s.p0x = b + 12 * c; s.p0y = b + 13 * c; s.p0z = b + 14 * c; s.p1x = b + 15 * c; s.p1y = b + 16 * c; s.p1z = b + 17 * c;
+        s.last_pdf = b + 18 * c;
+        s.rng = u.p; s.slot = u.p + c; s.flags = u.p + 2 * c;
+        return s;
+    }
+    bool ensure(size_t c) { if (c <= cap) return true; cap = 0; if (!f.alloc(19 * c) || !u.alloc(3 * c)) return false; cap = c; return true; }
+};
+
+}  // namespace
+
+struct HdMoonshine {
+    std::mutex mutex;                 // hydra.zig:76-78: every call is serialised
+    int device = 0;
+    hipStream_t stream = nullptr;
+    std::string last_error;
+    MsneConfig cfg{};
+    PipelineOpts opts{};
+
+    std::vector<TextureH> textures; bool textures_dirty = true;
+    std::vector<MeshH*> meshes;
+    std::vector<MaterialRec> materials; bool materials_dirty = true;
+    std::map<uint32_t, MaterialUpdate> material_updates;   // deferred edits (hydra.zig:152-223)
+    std::vector<InstanceH> instances; bool accel_dirty = true; bool tlas_only_dirty = false;
+    std::vector<Lens> lenses;
+    std::vector<SensorH*> sensors;
+
+    // device scene tables
+    DevBuf<float4> d_texels; DevBuf<TexDesc> d_texdesc;
+    DevBuf<MaterialRec> d_materials;
+    DevBuf<MeshRec> d_meshes;
+    DevBuf<GeometryRec> d_geometries;
+    DevBuf<InstanceRec> d_instances;
+    DevBuf<AliasEntry> d_alias;
+    DevBuf<Node8> d_nodes; DevBuf<TriRec> d_tris; DevBuf<uint32_t> d_tlas_items, d_item_src;
+    DevBuf<uint32_t> d_build_counters;    // [0] node count, [1] tri count, [2] tlas item count
+    uint32_t blas_nodes_end = 0, blas_tris_end = 0;
+    std::map<std::vector<uint32_t>, BlasInfo> blas_cache;
+    uint32_t tlas_root = MAX_UINT;
+    std::vector<AliasEntry> h_alias;
+    // environment
+    DevBuf<float4> d_env_rgb; DevBuf<float> d_env_lum; EnvView env{};
+    // wavefront
+    PathBuffers paths[2];
+    DevBuf<uint32_t> d_hit_u; DevBuf<float> d_hit_f;
+    DevBuf<float> d_shq_f; DevBuf<uint32_t> d_shq_u;
+    DevBuf<float4> d_lbuf;
+    size_t wf_cap = 0, lbuf_cap = 0;
+    DevBuf<Counters> d_counters;
+    DevBuf<uint32_t> d_spill; DevBuf<uint32_t> d_overflow; DevBuf<unsigned long long> d_trace_stats;
+    int trace_grid = 1024, shade_grid = 2048;
+    size_t max_inflight = 4u << 20;
+    // statistics
+    MsneStats stats{};
+    bool profile = false, trace_stats = false;
+    std::vector<hipEvent_t> events; size_t events_used = 0;
+    struct Span { size_t a, b; int kind; };
+    std::vector<Span> spans;
+
+    void fail(const std::string& m) { last_error = m; if (getenv("MSNE_VERBOSE")) fprintf(stderr, "moonshine_amd: %s\n", m.c_str()); }
+    void clear_all_sensors() { for (auto* s : sensors) s->sample_count = 0; }   // Camera.clearAllSensors Camera.zig:73-77
+    bool bind() { if (hipSetDevice(device) != hipSuccess) { fail("hipSetDevice failed"); return false; } return true; }
+
+    hipEvent_t next_event() {
+        if (events_used == events.size()) { hipEvent_t e; if (hipEventCreate(&e) != hipSuccess) return nullptr; events.push_back(e); }
+        return events[events_used++];
+    }
+
+    bool upload_textures();
+    bool upload_materials();
+    bool rebuild_accel();
+    bool ensure_scene();
+    bool ensure_wavefront(size_t paths, size_t slots);
+    SceneView scene_view() const;
+    bool set_background(const float* rgba, Extent2D e);
+    bool render(uint32_t sensor, uint32_t lens, uint32_t launches, bool readback);
+    bool readback(SensorH* s);
+    ~HdMoonshine();
+};
+
+// ---------------- textures ----------------
+static float half_to_float(uint16_t h) {
+    const uint32_t s = (uint32_t)(h >> 15) << 31, e = (h >> 10) & 0x1f, m = h & 0x3ff;
+    if (e == 0) { if (m == 0) return u2f(s); const float f = (float)m * 0x1p-24f; return (h >> 15) ? -f : f; }
+    if (e == 31) return u2f(s | 0x7f800000u | (m << 13));
+    return u2f(s | ((e + 112) << 23) | (m << 13));
+}
+static const float* srgb_lut() {
+    static float lut[256]; static bool init = false;
+    if (!init) { for (int i = 0; i < 256; i++) { const double v = i / 255.0; lut[i] = (float)(v <= 0.04045 ? v / 12.92 : pow((v + 0.055) / 1.055, 2.4)); } init = true; }
+    return lut;
+}
+static int64_t add_texture(HdMoonshine* c, const void* bytes, uint32_t w, uint32_t h, int fmt) {
+    if (!bytes || w == 0 || h == 0) { c->fail("texture: bad arguments"); return -1; }
+    if (fmt < 0 || fmt > MSNE_FORMAT_R16G16B16A16_SFLOAT) { c->fail("texture: unknown format"); return -1; }
+    TextureH t; t.w = w; t.h = h; t.rgba.resize((size_t)w * h * 4);
+    const size_t n = (size_t)w * h;
+    const uint8_t* b = (const uint8_t*)bytes; const float* f = (const float*)bytes; const uint16_t* hf = (const uint16_t*)bytes;
+    const float* lut = srgb_lut();
+    for (size_t i = 0; i < n; i++) {
+        float* o = &t.rgba[4 * i]; o[0] = o[1] = o[2] = 0.0f; o[3] = 1.0f;
+        switch (fmt) {
+            case MSNE_FORMAT_R8G8B8A8_SRGB: o[0] = lut[b[4 * i]]; o[1] = lut[b[4 * i + 1]]; o[2] = lut[b[4 * i + 2]]; o[3] = (float)b[4 * i + 3] / 255.0f; break;
+            case MSNE_FORMAT_R8G8_UNORM: o[0] = (float)b[2 * i] / 255.0f; o[1] = (float)b[2 * i + 1] / 255.0f; break;
+            case MSNE_FORMAT_R8_UNORM: o[0] = (float)b[i] / 255.0f; break;
+            case MSNE_FORMAT_R32G32B32A32_SFLOAT: o[0] = f[4 * i]; o[1] = f[4 * i + 1]; o[2] = f[4 * i + 2]; o[3] = f[4 * i + 3]; break;
+            case MSNE_FORMAT_R32G32_SFLOAT: o[0] = f[2 * i]; o[1] = f[2 * i + 1]; break;
+            case MSNE_FORMAT_R32_SFLOAT: o[0] = f[i]; break;
+            case MSNE_FORMAT_R16G16B16A16_SFLOAT: o[0] = half_to_float(hf[4 * i]); o[1] = half_to_float(hf[4 * i + 1]); o[2] = half_to_float(hf[4 * i + 2]); o[3] = half_to_float(hf[4 * i + 3]); break;
+        }
+    }
+    c->textures.push_back(std::move(t));
+    c->textures_dirty = true;
+    return (int64_t)c->textures.size() - 1;
+}
+
+bool HdMoonshine::upload_textures() {
+    size_t total = 0;
+    std::vector<TexDesc> desc(textures.size());
+    for (size_t i = 0; i < textures.size(); i++) { desc[i] = TexDesc{ (uint32_t)total, textures[i].w, textures[i].h, 0 }; total += (size_t)textures[i].w * textures[i].h; }
+    if (!d_texels.alloc(total) || !d_texdesc.alloc(desc.size())) { fail("out of device memory (textures)"); return false; }
+    for (size_t i = 0; i < textures.size(); i++)
+        CHECK_HIP(this, hipMemcpyAsync(d_texels.p + desc[i].offset, textures[i].rgba.data(), textures[i].rgba.size() * 4, hipMemcpyHostToDevice, stream));
+    if (!desc.empty()) CHECK_HIP(this, hipMemcpyAsync(d_texdesc.p, desc.data(), desc.size() * sizeof(TexDesc), hipMemcpyHostToDevice, stream));
+    CHECK_HIP(this, hipStreamSynchronize(stream));
+    textures_dirty = false;
+    return true;
+}
+
+bool HdMoonshine::upload_materials() {
+    // flush deferred edits (hydra.zig:152-223)
+    for (auto& kv : material_updates) {
+        if (kv.first >= materials.size()) continue;
+        MaterialRec& m = materials[kv.first]; const MaterialUpdate& u = kv.second;
+        if (u.has[0]) m.normal = u.tex[0];
+        if (u.has[1]) m.emissive = u.tex[1];
+        if (u.has[2]) m.color = u.tex[2];
+        if (u.has[3]) m.metalness = u.tex[3];
+        if (u.has[4]) m.roughness = u.tex[4];
+        if (u.has[5]) m.ior = u.ior;
+    }
+    material_updates.clear();
+    if (!d_materials.alloc(materials.size())) { fail("out of device memory (materials)"); return false; }
+    if (!materials.empty()) CHECK_HIP(this, hipMemcpyAsync(d_materials.p, materials.data(), materials.size() * sizeof(MaterialRec), hipMemcpyHostToDevice, stream));
+    CHECK_HIP(this, hipStreamSynchronize(stream));
+    materials_dirty = false;
+    return true;
+}
+
+// ---------------- acceleration structure + alias table (Accel.zig:312-563) ----------------
+static void vose_alias(const std::vector<float>& w, AliasEntry* entries, float& sum_out) {   // alias_table.zig:25-92
+    const uint32_t n = (uint32_t)w.size();
+    float sum = 0.0f;
+    for (uint32_t i = 0; i < n; i++) sum += w[i];
+    uint32_t less_head = MAX_UINT, more_head = MAX_UINT;
+    for (uint32_t i = 0; i < n; i++) {
+        const float adj = (w[i] * (float)n) / sum;
+        entries[i].select = adj;
+        if (adj < 1.0f) { entries[i].alias = less_head; less_head = i; } else { entries[i].alias = more_head; more_head = i; }
+    }
+    while (less_head != MAX_UINT && more_head != MAX_UINT) {
+        const uint32_t less = less_head; less_head = entries[less].alias;
+        const uint32_t more = more_head; more_head = entries[more].alias;
+        entries[less].alias = more;
+        entries[more].select = (entries[more].select + entries[less].select) - 1.0f;
+        if (entries[more].select < 1.0f) { entries[more].alias = less_head; less_head = more; } else { entries[more].alias = more_head; more_head = more; }
+    }
+    while (less_head != MAX_UINT) { const uint32_t less = less_head; less_head = entries[less].alias; entries[less].select = 1.0f; }
+    sum_out = sum;
+}
+
+static bool is_identity(const m34& m) {
+    for (int r = 0; r < 3; r++) for (int c = 0; c < 4; c++) if (m.m[r][c] != ((r == c) ? 1.0f : 0.0f)) return false;
+    return true;
+}
+
+bool HdMoonshine::rebuild_accel() {
+    // flat geometry table + per-instance offsets (Accel.zig:362-412)
+    std::vector<GeometryRec> geos; std::vector<uint32_t> geo_offset(instances.size());
+    for (size_t i = 0; i < instances.size(); i++) { geo_offset[i] = (uint32_t)geos.size(); for (auto& g : instances[i].geos) geos.push_back(g); }
+    for (auto& g : geos) {
+        if (g.mesh >= meshes.size()) { fail("instance references an unknown mesh"); return false; }
+        if (g.material >= materials.size()) { fail("instance references an unknown material"); return false; }
+    }
+    std::vector<MeshRec> mrec(meshes.size());
+    for (size_t i = 0; i < meshes.size(); i++) mrec[i] = MeshRec{ meshes[i]->positions.p, meshes[i]->has_texcoords ? meshes[i]->texcoords.p : nullptr, meshes[i]->has_normals ? meshes[i]->normals.p : nullptr, meshes[i]->indices.p };
+    if (!d_meshes.alloc(mrec.size()) || !d_geometries.alloc(geos.size())) { fail("out of device memory (tables)"); return false; }
+    if (!mrec.empty()) CHECK_HIP(this, hipMemcpyAsync(d_meshes.p, mrec.data(), mrec.size() * sizeof(MeshRec), hipMemcpyHostToDevice, stream));
+    if (!geos.empty()) CHECK_HIP(this, hipMemcpyAsync(d_geometries.p, geos.data(), geos.size() * sizeof(GeometryRec), hipMemcpyHostToDevice, stream));
+
+    // BLAS per unique mesh list (Accel.zig:315-343); cached across rebuilds
+    std::vector<std::vector<uint32_t>> keys(instances.size());
+    size_t new_tris = 0;
+    {
+        std::map<std::vector<uint32_t>, bool> seen;
+        for (size_t i = 0; i < instances.size(); i++) {
+            for (auto& g : instances[i].geos) keys[i].push_back(g.mesh);
+            if (!blas_cache.count(keys[i]) && !seen.count(keys[i])) { seen[keys[i]] = true; for (uint32_t m : keys[i]) new_tris += meshes[m]->index_count; }
+        }
+    }
+    if (!d_build_counters.p) { if (!d_build_counters.alloc(4)) { fail("out of device memory"); return false; } CHECK_HIP(this, hipMemsetAsync(d_build_counters.p, 0, 16, stream)); }
+    const size_t need_tris = (size_t)blas_tris_end + new_tris;
+    const size_t need_nodes = (size_t)blas_nodes_end + new_tris + 2 * instances.size() + 64;
+    if (need_tris > d_tris.n || !d_tris.p) {
+        DevBuf<TriRec> nt; if (!nt.alloc(need_tris + need_tris / 4 + 16)) { fail("out of device memory (triangles)"); return false; }
+        if (blas_tris_end) CHECK_HIP(this, hipMemcpyAsync(nt.p, d_tris.p, (size_t)blas_tris_end * sizeof(TriRec), hipMemcpyDeviceToDevice, stream));
+        CHECK_HIP(this, hipStreamSynchronize(stream));
+        std::swap(nt.p, d_tris.p); std::swap(nt.n, d_tris.n);
+    }
+    if (need_nodes > d_nodes.n || !d_nodes.p) {
+        DevBuf<Node8> nn; if (!nn.alloc(need_nodes + need_nodes / 4 + 16)) { fail("out of device memory (nodes)"); return false; }
+        if (blas_nodes_end) CHECK_HIP(this, hipMemcpyAsync(nn.p, d_nodes.p, (size_t)blas_nodes_end * sizeof(Node8), hipMemcpyDeviceToDevice, stream));
+        CHECK_HIP(this, hipStreamSynchronize(stream));
+        std::swap(nn.p, d_nodes.p); std::swap(nn.n, d_nodes.n);
+    }
+    if (!d_item_src.ensure(std::max(d_tris.n, instances.size() + 1)) || !d_tlas_items.ensure(instances.size() + 1)) { fail("out of device memory (items)"); return false; }
+    // counters: node count resumes after the BLAS region (the previous TLAS is discarded)
+    { uint32_t c[4] = { blas_nodes_end, blas_tris_end, 0u, 0u }; CHECK_HIP(this, hipMemcpyAsync(d_build_counters.p, c, 16, hipMemcpyHostToDevice, stream)); CHECK_HIP(this, hipStreamSynchronize(stream)); }
+    for (size_t i = 0; i < instances.size(); i++) {
+        if (blas_cache.count(keys[i])) continue;
+        std::vector<BlasGeo> bg; uint32_t off = 0;
+        for (uint32_t m : keys[i]) { bg.push_back(BlasGeo{ meshes[m]->positions.p, meshes[m]->indices.p, off, meshes[m]->index_count }); off += meshes[m]->index_count; }
+        BlasInfo info{}; info.tris = off;
+        if (!bvh_build_blas(stream, bg, off, d_nodes.p, d_build_counters.p, (uint32_t)d_nodes.n, d_tris.p, d_build_counters.p + 1, d_item_src.p, &info.root, info.box)) { fail("BLAS build failed"); return false; }
+        blas_cache[keys[i]] = info;
+    }
+    { uint32_t c[2]; CHECK_HIP(this, hipMemcpy(c, d_build_counters.p, 8, hipMemcpyDeviceToHost)); blas_nodes_end = c[0]; blas_tris_end = c[1]; }
+
+    // instance records + TLAS over visible, non-empty instances (Accel.zig:394-484)
+    std::vector<InstanceRec> irec(instances.size());
+    std::vector<float> boxes; std::vector<uint32_t> ids;
+    for (size_t i = 0; i < instances.size(); i++) {
+        const BlasInfo& bi = blas_cache[keys[i]];
+        InstanceRec& r = irec[i];
+        r.transform = instances[i].transform;
+        r.world_to_instance = m34_inverse_affine(instances[i].transform);   // Accel.zig:430-432
+        r.geo_offset = geo_offset[i]; r.blas_root = bi.root;
+        r.flags = (instances[i].visible ? 1u : 0u) | (is_identity(instances[i].transform) ? 2u : 0u); r.pad = 0;
+        if (!instances[i].visible || bi.root == MAX_UINT) continue;
+        float lo[3] = { 3e38f, 3e38f, 3e38f }, hi[3] = { -3e38f, -3e38f, -3e38f };
+        for (int k = 0; k < 8; k++) {
+            const f3 p = F3((k & 1) ? bi.box[3] : bi.box[0], (k & 2) ? bi.box[4] : bi.box[1], (k & 4) ? bi.box[5] : bi.box[2]);
+            const f3 q = m34_mul_point(instances[i].transform, p);
+            lo[0] = std::min(lo[0], q.x); lo[1] = std::min(lo[1], q.y); lo[2] = std::min(lo[2], q.z);
+            hi[0] = std::max(hi[0], q.x); hi[1] = std::max(hi[1], q.y); hi[2] = std::max(hi[2], q.z);
+        }
+        float pad = 1e-30f;
+        for (int k = 0; k < 3; k++) pad += 1e-6f * (fabsf(hi[k] - lo[k]) + fabsf(hi[k]) + fabsf(lo[k]));
+        for (int k = 0; k < 3; k++) { boxes.push_back(lo[k] - pad); }
+        for (int k = 0; k < 3; k++) { boxes.push_back(hi[k] + pad); }
+        ids.push_back((uint32_t)i);
+    }
+    if (!d_instances.alloc(irec.size())) { fail("out of device memory (instances)"); return false; }
+    if (!irec.empty()) CHECK_HIP(this, hipMemcpyAsync(d_instances.p, irec.data(), irec.size() * sizeof(InstanceRec), hipMemcpyHostToDevice, stream));
+    if (!bvh_build_tlas(stream, boxes.data(), ids.data(), (uint32_t)ids.size(), d_nodes.p, d_build_counters.p, (uint32_t)d_nodes.n, d_tlas_items.p, d_build_counters.p + 2, d_item_src.p, &tlas_root)) { fail("TLAS build failed"); return false; }
+
+    // emissive-triangle alias table (Accel.zig:491-539): entry 0 = {count, sum of areas}
+    std::vector<float> w; h_alias.assign(1, AliasEntry{ 0u, 0.0f, 0u, 0u, 0u });
+    for (size_t i = 0; i < instances.size(); i++) for (size_t g = 0; g < instances[i].geos.size(); g++) {
+        const GeometryRec& ge = instances[i].geos[g];
+        if (!ge.sampled) continue;
+        const MeshH* m = meshes[ge.mesh];
+        for (uint32_t p = 0; p < m->index_count; p++) {
+            const uint32_t* ix = &m->h_indices[3 * (size_t)p];
+            const float* P = m->h_positions.data();
+            const f3 p0 = m34_mul_point(instances[i].transform, F3(P[3 * (size_t)ix[0]], P[3 * (size_t)ix[0] + 1], P[3 * (size_t)ix[0] + 2]));
+            const f3 p1 = m34_mul_point(instances[i].transform, F3(P[3 * (size_t)ix[1]], P[3 * (size_t)ix[1] + 1], P[3 * (size_t)ix[1] + 2]));
+            const f3 p2 = m34_mul_point(instances[i].transform, F3(P[3 * (size_t)ix[2]], P[3 * (size_t)ix[2] + 1], P[3 * (size_t)ix[2] + 2]));
+            w.push_back(length(cross(sub(p1, p0), sub(p2, p0))) / 2.0f);
+            h_alias.push_back(AliasEntry{ 0u, 0.0f, (uint32_t)i, (uint32_t)g, p });
+        }
+    }
+    float sum = 0.0f;
+    if (!w.empty()) vose_alias(w, h_alias.data() + 1, sum);
+    h_alias[0].alias = (uint32_t)w.size(); h_alias[0].select = sum;
+    if (!d_alias.alloc(h_alias.size())) { fail("out of device memory (alias table)"); return false; }
+    CHECK_HIP(this, hipMemcpyAsync(d_alias.p, h_alias.data(), h_alias.size() * sizeof(AliasEntry), hipMemcpyHostToDevice, stream));
+    CHECK_HIP(this, hipStreamSynchronize(stream));
+    accel_dirty = false;
+    return true;
+}
+
+bool HdMoonshine::ensure_scene() {
+    if (textures_dirty && !upload_textures()) return false;
+    if ((materials_dirty || !material_updates.empty()) && !upload_materials()) return false;
+    if (accel_dirty && !rebuild_accel()) return false;
+    return true;
+}
+
+SceneView HdMoonshine::scene_view() const {
+    SceneView v{};
+    v.nodes = d_nodes.p; v.tris = d_tris.p; v.tlas_items = d_tlas_items.p; v.instances = d_instances.p; v.geometries = d_geometries.p;
+    v.meshes = d_meshes.p; v.materials = d_materials.p; v.textures = d_texdesc.p; v.texels = d_texels.p; v.alias = d_alias.p;
+    v.env = env; v.tlas_root = tlas_root;
+    return v;
+}
+
+// ---------------- background (BackgroundManager.zig:142-394) ----------------
+bool HdMoonshine::set_background(const float* rgba, Extent2D e) {
+    if (!rgba || e.width == 0 || e.height == 0) { fail("background: bad arguments"); return false; }
+    uint32_t S = 1; while (S * 2 <= e.height && S * 2 != 0) S *= 2;      // floorPowerOfTwo(height), BackgroundManager.zig:154
+    if (S > 1024) S = 1024;                                               // maximum_equal_area_map_size :132
+    uint32_t mips = 1; while ((S >> (mips - 1)) > 1) mips++;
+    DevBuf<float4> src;
+    if (!src.alloc((size_t)e.width * e.height) || !d_env_rgb.alloc((size_t)S * S)) { fail("out of device memory (background)"); return false; }
+    size_t total = 0; uint32_t off[12] = { 0 };
+    for (uint32_t l = 0; l < mips; l++) { off[l] = (uint32_t)total; total += (size_t)(S >> l) * (S >> l); }
+    if (!d_env_lum.alloc(total)) { fail("out of device memory (background)"); return false; }
+    CHECK_HIP(this, hipMemcpyAsync(src.p, rgba, (size_t)e.width * e.height * 16, hipMemcpyHostToDevice, stream));
+    launch_env_build(stream, src.p, e.width, e.height, d_env_rgb.p, d_env_lum.p, off, S, mips);
+    CHECK_HIP(this, hipStreamSynchronize(stream));
+    env.rgb = d_env_rgb.p; env.lum = d_env_lum.p; env.size = S; env.mip_count = mips;
+    for (int l = 0; l < 12; l++) env.lum_offset[l] = off[l];
+    clear_all_sensors();
+    return true;
+}
+
+// ---------------- wavefront buffers ----------------
+bool HdMoonshine::ensure_wavefront(size_t npaths, size_t slots) {
+    if (npaths > wf_cap) {
+        const size_t c = (npaths + 255) & ~(size_t)255;
+        if (!paths[0].ensure(c) || !paths[1].ensure(c) || !d_hit_u.alloc(3 * c) || !d_hit_f.alloc(2 * c) || !d_shq_f.alloc(7 * 2 * c) || !d_shq_u.alloc(2 * c)) { fail("out of device memory (wavefront state)"); wf_cap = 0; return false; }
+        wf_cap = c;
+    }
+    if (slots > lbuf_cap) { if (!d_lbuf.alloc(slots)) { fail("out of device memory (sample buffer)"); lbuf_cap = 0; return false; } lbuf_cap = slots; }
+    if (!d_counters.p) { if (!d_counters.alloc(1)) return false; if (hipMemsetAsync(d_counters.p, 0, sizeof(Counters), stream) != hipSuccess) return false; }
+    if (!d_spill.p) {
+        if (!d_spill.alloc(trace_spill_words(trace_grid)) || !d_overflow.alloc(1) || !d_trace_stats.alloc(4)) { fail("out of device memory (traversal spill)"); return false; }
+        if (hipMemsetAsync(d_overflow.p, 0, 4, stream) != hipSuccess || hipMemsetAsync(d_trace_stats.p, 0, 32, stream) != hipSuccess) return false;
+    }
+    return true;
+}
+
+static CameraConsts make_camera(const Lens& lens, uint32_t W, uint32_t H) {   // camera.hlsl:14-29, evaluated once per launch instead of per thread
+    CameraConsts c;
+    const f3 origin = F3(lens.origin.x, lens.origin.y, lens.origin.z), forward = F3(lens.forward.x, lens.forward.y, lens.forward.z), up = F3(lens.up.x, lens.up.y, lens.up.z);
+    const float aspect = (float)W / (float)H;
+    const f3 w = scale(forward, -1.0f);
+    const f3 u = normalize(cross(up, w));
+    const f3 v = cross(w, u);
+    const float h = det_tanf(lens.vfov / 2.0f);
+    const float viewport_height = 2.0f * h * lens.focus_distance;
+    const float viewport_width = aspect * viewport_height;
+    c.origin = origin; c.u = u; c.v = v;
+    c.horizontal = scale(u, viewport_width);
+    c.vertical = scale(v, viewport_height);
+    c.llc = sub(sub(sub(origin, divs(c.horizontal, 2.0f)), divs(c.vertical, 2.0f)), scale(w, lens.focus_distance));
+    c.aperture = lens.aperture;
+    return c;
+}
+
+bool HdMoonshine::readback(SensorH* s) {
+    launch_unpack_film(stream, 1024, s->shard, s->film_packed.p, 1, s->shard.shard_index, 0, s->film_full.p);
+    CHECK_HIP(this, hipMemcpyAsync(s->host, s->film_full.p, (size_t)s->extent.width * s->extent.height * 16, hipMemcpyDeviceToHost, stream));
+    CHECK_HIP(this, hipStreamSynchronize(stream));
+    return true;
+}
+
+bool HdMoonshine::render(uint32_t sensor, uint32_t lens, uint32_t launches, bool do_readback) {
+    if (sensor >= sensors.size() || lens >= lenses.size()) { fail("render: bad sensor or lens handle"); return false; }
+    if (!ensure_scene()) return false;
+    SensorH* s = sensors[sensor];
+    const size_t P = s->shard.pixels;
+    const uint32_t spr = opts.samples_per_run;
+    if (P == 0 || spr == 0) { if (do_readback) return readback(s); return true; }
+    const uint32_t chunk = (uint32_t)std::max<size_t>(1, std::min<size_t>(spr, max_inflight / P));
+    if (!ensure_wavefront(P * chunk, P * chunk)) return false;
+    const SceneView sv = scene_view();
+    const CameraConsts cam = make_camera(lenses[lens], s->extent.width, s->extent.height);
+    HitBuf hits{ d_hit_u.p, d_hit_u.p + wf_cap, d_hit_u.p + 2 * wf_cap, d_hit_f.p, d_hit_f.p + wf_cap };
+    const size_t qc = 2 * wf_cap;
+    ShadowQueue shq{ d_shq_f.p, d_shq_f.p + qc, d_shq_f.p + 2 * qc, d_shq_f.p + 3 * qc, d_shq_f.p + 4 * qc, d_shq_f.p + 5 * qc, d_shq_f.p + 6 * qc, d_shq_u.p };
+    const PathState st[2] = { paths[0].view(), paths[1].view() };
+    events_used = 0; spans.clear();
+    hipEvent_t ev_begin = nullptr, ev_end = nullptr;
+    ev_begin = next_event(); ev_end = next_event();
+    if (ev_begin) (void)hipEventRecord(ev_begin, stream);
+    auto timed = [&](int kind, auto&& fn) {
+        if (!profile) { fn(); return; }
+        hipEvent_t a = next_event(), b = next_event();
+        const size_t ia = events_used - 2, ib = events_used - 1;
+        if (a) (void)hipEventRecord(a, stream);
+        fn();
+        if (b) (void)hipEventRecord(b, stream);
+        spans.push_back(Span{ ia, ib, kind });
+    };
+    const uint32_t max_iter = opts.max_bounces + 3;   // hits b = 0..max_bounces+1, + one pass to retire zombies
+    for (uint32_t l = 0; l < launches; l++) {
+        for (uint32_t s0 = 0; s0 < spr; s0 += chunk) {
+            const uint32_t sc = std::min(chunk, spr - s0);
+            CHECK_HIP(this, hipMemsetAsync(d_counters.p, 0, 32, stream));   // queue counts + heads
+            launch_raygen(stream, shade_grid, s->shard, cam, opts, s->sample_count + s0, sc, st[0], d_counters.p);
+            launch_advance(stream, d_counters.p, 1);
+            for (uint32_t b = 0; b < max_iter; b++) {
+                const PathState& cur = st[b & 1]; const PathState& nxt = st[(b + 1) & 1];
+                timed(0, [&] { launch_trace_closest(stream, trace_grid, trace_stats, sv, cur, hits, d_counters.p, d_spill.p, d_overflow.p, d_trace_stats.p); });
+                timed(2, [&] { launch_shade(stream, shade_grid, sv, opts, cur, hits, nxt, shq, d_lbuf.p, d_counters.p); });
+                timed(1, [&] { launch_trace_shadow(stream, trace_grid, trace_stats, sv, shq, nxt, d_counters.p, d_spill.p, d_overflow.p, d_trace_stats.p); });
+                launch_advance(stream, d_counters.p, 0);
+                if (b >= 15 && (b & 3) == 3) {   // long tails (max_bounces = 1024 offline): poll the queue length every 4 bounces
+                    uint32_t n_cur = 0;
+                    CHECK_HIP(this, hipMemcpyAsync(&n_cur, &d_counters.p->n_cur, 4, hipMemcpyDeviceToHost, stream));
+                    CHECK_HIP(this, hipStreamSynchronize(stream));
+                    if (n_cur == 0) break;
+                }
+            }
+            launch_film(stream, shade_grid, s->shard, opts, d_lbuf.p, sc, s0 == 0, s0 + sc == spr, s->sample_count, s->color.p, s->film_packed.p);
+        }
+        s->sample_count += spr;   // hydra.zig:360
+        stats.launches++;
+    }
+    if (ev_end) (void)hipEventRecord(ev_end, stream);
+    if (do_readback) { if (!readback(s)) return false; }
+    else CHECK_HIP(this, hipStreamSynchronize(stream));
+    uint32_t overflow = 0;
+    CHECK_HIP(this, hipMemcpy(&overflow, d_overflow.p, 4, hipMemcpyDeviceToHost));
+    if (overflow) { fail("traversal stack overflow"); return false; }
+    float ms = 0.0f;
+    if (ev_begin && ev_end && hipEventElapsedTime(&ms, ev_begin, ev_end) == hipSuccess) stats.render_ms += ms;
+    for (const Span& sp : spans) {
+        if (hipEventElapsedTime(&ms, events[sp.a], events[sp.b]) != hipSuccess) continue;
+        if (sp.kind == 0) { stats.trace_closest_ms += ms; stats.trace_closest_launches++; } else if (sp.kind == 1) stats.trace_shadow_ms += ms; else stats.shade_ms += ms;
+    }
+    return true;
+}
+
+HdMoonshine::~HdMoonshine() {
+    (void)hipSetDevice(device);
+    if (stream) (void)hipStreamSynchronize(stream);
+    for (auto* m : meshes) delete m;
+    for (auto* s : sensors) { if (s->host) (void)hipHostFree(s->host); delete s; }
+    for (auto e : events) (void)hipEventDestroy(e);
+    if (stream) (void)hipStreamDestroy(stream);
+}
+
+// =====================================================================================
+//                                       C ABI
+// =====================================================================================
+#define LOCK(c) std::lock_guard<std::mutex> lock_((c)->mutex)
+
+extern "C" {
+
+HdMoonshine* MsneCreate(const MsneConfig* cfg_in) {
+    MsneConfig cfg{ -1, 0, 0, 0 };
+    if (cfg_in) cfg = *cfg_in;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) { g_create_error = "no HIP device available: libmoonshine_amd requires an MI355X (gfx950) GPU"; return nullptr; }
+    int dev = cfg.device;
+    if (dev < 0) { const char* e = getenv("MSNE_DEVICE"); dev = e ? atoi(e) : 0; }
+    if (dev >= ndev) { g_create_error = "requested HIP device does not exist"; return nullptr; }
+    if (cfg.tile_size == 0) cfg.tile_size = 64;
+    if (cfg.shard_count == 0) cfg.shard_count = 1;
+    if (cfg.shard_index >= cfg.shard_count) { g_create_error = "shard_index >= shard_count"; return nullptr; }
+    HdMoonshine* c = new (std::nothrow) HdMoonshine();
+    if (!c) { g_create_error = "out of host memory"; return nullptr; }
+    c->device = dev; c->cfg = cfg;
+    if (hipSetDevice(dev) != hipSuccess || hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { g_create_error = "cannot create HIP stream"; delete c; return nullptr; }
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, dev) == hipSuccess) { c->trace_grid = prop.multiProcessorCount * 4; c->shade_grid = prop.multiProcessorCount * 8; }
+    if (const char* e = getenv("MSNE_MAX_INFLIGHT")) c->max_inflight = (size_t)atoll(e);
+    c->opts = PipelineOpts{ 1, 1024, 0, 0, 0, 0, 0 };                 // hydra.zig:97-105
+    const float white[4] = { 1.0f, 1.0f, 1.0f, 1.0f };
+    if (!c->set_background(white, Extent2D{ 1, 1 })) { g_create_error = c->last_error; delete c; return nullptr; }   // addDefaultBackground
+    return c;
+}
+HdMoonshine* HdMoonshineCreate(void) { return MsneCreate(nullptr); }
+void HdMoonshineDestroy(HdMoonshine* c) { if (!c) return; { LOCK(c); (void)c->bind(); } delete c; }
+
+const char* MsneGetLastError(const HdMoonshine* c) { return c ? c->last_error.c_str() : g_create_error.c_str(); }
+
+int64_t MsneCreateMesh(HdMoonshine* c, const F32x3* positions, const F32x3* normals, const F32x2* texcoords, size_t position_count, size_t attribute_count, const U32x3* indices, size_t index_count) {
+    LOCK(c);
+    if (!c->bind()) return -1;
+    if (!positions || !indices || position_count == 0 || index_count == 0) { c->fail("mesh: positions and indices are required"); return -1; }
+    if ((normals || texcoords) && attribute_count == 0) { c->fail("mesh: attribute_count is zero"); return -1; }
+    for (size_t i = 0; i < index_count; i++) if (indices[i].x >= position_count || indices[i].y >= position_count || indices[i].z >= position_count) { c->fail("mesh: index out of range"); return -1; }
+    MeshH* m = new MeshH();
+    m->position_count = (uint32_t)position_count; m->attribute_count = (uint32_t)attribute_count; m->index_count = (uint32_t)index_count;
+    m->has_normals = normals != nullptr; m->has_texcoords = texcoords != nullptr;
+    bool ok = m->positions.alloc(3 * position_count) && m->indices.alloc(3 * index_count);
+    if (ok && normals) ok = m->normals.alloc(3 * attribute_count);
+    if (ok && texcoords) ok = m->texcoords.alloc(2 * attribute_count);
+    if (!ok) { delete m; c->fail("out of device memory (mesh)"); return -1; }
+    m->h_positions.assign((const float*)positions, (const float*)positions + 3 * position_count);
+    m->h_indices.assign((const uint32_t*)indices, (const uint32_t*)indices + 3 * index_count);
+    bool up = hipMemcpyAsync(m->positions.p, positions, 12 * position_count, hipMemcpyHostToDevice, c->stream) == hipSuccess
+           && hipMemcpyAsync(m->indices.p, indices, 12 * index_count, hipMemcpyHostToDevice, c->stream) == hipSuccess;
+    if (up && normals) up = hipMemcpyAsync(m->normals.p, normals, 12 * attribute_count, hipMemcpyHostToDevice, c->stream) == hipSuccess;
+    if (up && texcoords) up = hipMemcpyAsync(m->texcoords.p, texcoords, 8 * attribute_count, hipMemcpyHostToDevice, c->stream) == hipSuccess;
+    if (up) up = hipStreamSynchronize(c->stream) == hipSuccess;   // MeshManager.upload copies: the caller keeps ownership
+    if (!up) { delete m; c->fail("mesh upload failed"); return -1; }
+    c->meshes.push_back(m);
+    return (int64_t)c->meshes.size() - 1;
+}
+MeshHandle HdMoonshineCreateMesh(HdMoonshine* c, const F32x3* positions, const F32x3* normals, const F32x2* texcoords, size_t position_count, const U32x3* indices, size_t index_count) {
+    const int64_t h = MsneCreateMesh(c, positions, normals, texcoords, position_count, index_count * 3, indices, index_count);   // hydra.zig:379-380
+    return h < 0 ? 0xFFFFFFFFu : (MeshHandle)h;
+}
+
+int64_t MsneCreateTexture(HdMoonshine* c, const void* bytes, Extent2D e, MsneTextureFormat f) { LOCK(c); return add_texture(c, bytes, e.width, e.height, (int)f); }
+ImageHandle HdMoonshineCreateSolidTexture1(HdMoonshine* c, float v, const char*) { LOCK(c); return (ImageHandle)add_texture(c, &v, 1, 1, MSNE_FORMAT_R32_SFLOAT); }
+ImageHandle HdMoonshineCreateSolidTexture2(HdMoonshine* c, F32x2 v, const char*) { LOCK(c); return (ImageHandle)add_texture(c, &v, 1, 1, MSNE_FORMAT_R32G32_SFLOAT); }
+ImageHandle HdMoonshineCreateSolidTexture3(HdMoonshine* c, F32x3 v, const char*) { LOCK(c); const float f[4] = { v.x, v.y, v.z, 0.0f }; return (ImageHandle)add_texture(c, f, 1, 1, MSNE_FORMAT_R32G32B32A32_SFLOAT); }   // stored as f32x4, MaterialManager.zig:380-388
+ImageHandle HdMoonshineCreateRawTexture(HdMoonshine* c, uint8_t* data, Extent2D e, TextureFormat f, const char*) {
+    LOCK(c); return (ImageHandle)add_texture(c, data, e.width, e.height, f == f16x4 ? MSNE_FORMAT_R16G16B16A16_SFLOAT : MSNE_FORMAT_R8G8B8A8_SRGB);   // hydra.zig:47-52
+}
+
+int64_t MsneCreateMaterial(HdMoonshine* c, const MsneMaterialDesc* d) {
+    LOCK(c);
+    if (!d || d->type > MSNE_MATERIAL_STANDARD_PBR) { c->fail("material: bad descriptor"); return -1; }
+    const size_t nt = c->textures.size();
+    if (d->normal >= nt || d->emissive >= nt) { c->fail("material: unknown texture handle"); return -1; }
+    if ((d->type == MSNE_MATERIAL_LAMBERT || d->type == MSNE_MATERIAL_STANDARD_PBR) && d->color >= nt) { c->fail("material: unknown color texture"); return -1; }
+    if (d->type == MSNE_MATERIAL_STANDARD_PBR && (d->metalness >= nt || d->roughness >= nt)) { c->fail("material: unknown texture handle"); return -1; }
+    c->materials.push_back(MaterialRec{ d->normal, d->emissive, d->type, d->color, d->metalness, d->roughness, d->ior, 0u });
+    c->materials_dirty = true;
+    return (int64_t)c->materials.size() - 1;
+}
+MaterialHandle HdMoonshineCreateMaterial(HdMoonshine* c, Material m) {
+    MsneMaterialDesc d{ m.normal, m.emissive, MSNE_MATERIAL_STANDARD_PBR, m.color, m.metalness, m.roughness, m.ior };
+    const int64_t h = MsneCreateMaterial(c, &d);
+    return h < 0 ? 0xFFFFFFFFu : (MaterialHandle)h;
+}
+static void defer_material(HdMoonshine* c, MaterialHandle m, int field, ImageHandle t, float ior) {
+    LOCK(c); MaterialUpdate& u = c->material_updates[m]; u.has[field] = true; if (field < 5) u.tex[field] = t; else u.ior = ior;
+}
+void HdMoonshineSetMaterialNormal(HdMoonshine* c, MaterialHandle m, ImageHandle t) { defer_material(c, m, 0, t, 0.0f); }
+void HdMoonshineSetMaterialEmissive(HdMoonshine* c, MaterialHandle m, ImageHandle t) { defer_material(c, m, 1, t, 0.0f); }
+void HdMoonshineSetMaterialColor(HdMoonshine* c, MaterialHandle m, ImageHandle t) { defer_material(c, m, 2, t, 0.0f); }
+void HdMoonshineSetMaterialMetalness(HdMoonshine* c, MaterialHandle m, ImageHandle t) { defer_material(c, m, 3, t, 0.0f); }
+void HdMoonshineSetMaterialRoughness(HdMoonshine* c, MaterialHandle m, ImageHandle t) { defer_material(c, m, 4, t, 0.0f); }
+void HdMoonshineSetMaterialIOR(HdMoonshine* c, MaterialHandle m, float ior) { defer_material(c, m, 5, 0, ior); }
+
+InstanceHandle HdMoonshineCreateInstance(HdMoonshine* c, Mat3x4 t, const Geometry* geos, size_t n, bool visible) {
+    LOCK(c);
+    InstanceH in; memcpy(&in.transform, &t, sizeof(m34)); in.visible = visible;
+    for (size_t i = 0; i < n; i++) in.geos.push_back(GeometryRec{ geos[i].mesh, geos[i].material, geos[i].sampled ? 1u : 0u });
+    c->instances.push_back(std::move(in));
+    c->accel_dirty = true; c->clear_all_sensors();           // hydra.zig:483-493
+    return (InstanceHandle)c->instances.size() - 1;
+}
+void HdMoonshineSetInstanceVisibility(HdMoonshine* c, InstanceHandle h, bool v) { LOCK(c); if (h >= c->instances.size()) return; c->instances[h].visible = v; c->accel_dirty = true; c->clear_all_sensors(); }
+void HdMoonshineDestroyInstance(HdMoonshine* c, InstanceHandle h) { HdMoonshineSetInstanceVisibility(c, h, false); }   // hydra.zig:495-497
+void HdMoonshineSetInstanceTransform(HdMoonshine* c, InstanceHandle h, Mat3x4 t) { LOCK(c); if (h >= c->instances.size()) return; memcpy(&c->instances[h].transform, &t, sizeof(m34)); c->accel_dirty = true; c->clear_all_sensors(); }
+
+int MsneSetPipeline(HdMoonshine* c, const MsnePipelineOpts* o) {
+    LOCK(c);
+    if (!o || o->samples_per_run == 0) { c->fail("pipeline: samples_per_run must be >= 1"); return -1; }
+    if (o->env_samples_per_bounce > 1 || o->mesh_samples_per_bounce > 1) { c->fail("pipeline: more than one env/mesh light sample per bounce is not supported by the wavefront integrator yet"); return -2; }
+    if (o->max_bounces > 65000) { c->fail("pipeline: max_bounces too large"); return -1; }
+    c->opts = PipelineOpts{ o->samples_per_run, o->max_bounces, o->env_samples_per_bounce, o->mesh_samples_per_bounce, o->flip_image, o->indexed_attributes, o->two_component_normal_texture };
+    c->clear_all_sensors();                                   // hydra.zig:365-372
+    return 0;
+}
+int MsneGetPipeline(const HdMoonshine* c, MsnePipelineOpts* o) {
+    if (!c || !o) return -1;
+    *o = MsnePipelineOpts{ c->opts.samples_per_run, c->opts.max_bounces, c->opts.env_samples, c->opts.mesh_samples, c->opts.flip_image, c->opts.indexed_attributes, c->opts.two_component_normal_texture };
+    return 0;
+}
+bool HdMoonshineRebuildPipeline(HdMoonshine* c) { LOCK(c); c->clear_all_sensors(); return true; }   // nothing to recompile: constants are kernel arguments
+
+int MsneSetBackground(HdMoonshine* c, const float* rgba, Extent2D e) { LOCK(c); if (!c->bind()) return -1; return c->set_background(rgba, e) ? 0 : -1; }
+
+SensorHandle HdMoonshineCreateSensor(HdMoonshine* c, Extent2D e) {
+    LOCK(c);
+    if (!c->bind() || e.width == 0 || e.height == 0) { c->fail("sensor: bad extent"); return 0xFFFFFFFFu; }
+    SensorH* s = new SensorH(); s->extent = e;
+    ShardView& sh = s->shard;
+    sh.width = e.width; sh.height = e.height; sh.tile_size = c->cfg.tile_size;
+    sh.tiles_x = (e.width + sh.tile_size - 1) / sh.tile_size; sh.tiles_y = (e.height + sh.tile_size - 1) / sh.tile_size;
+    sh.shard_index = c->cfg.shard_index; sh.shard_count = c->cfg.shard_count;
+    const uint32_t total = sh.tiles_x * sh.tiles_y;
+    sh.local_tiles = total > sh.shard_index ? (total - sh.shard_index + sh.shard_count - 1) / sh.shard_count : 0;
+    sh.pixels = sh.local_tiles * sh.tile_size * sh.tile_size;
+    const size_t npix = (size_t)e.width * e.height;
+    // the packed film is padded to the largest shard so that gathers move equal-sized buffers
+    const size_t padded = (size_t)((total + sh.shard_count - 1) / sh.shard_count) * sh.tile_size * sh.tile_size;
+    bool ok = s->film_packed.alloc(padded) && s->color.alloc(padded) && s->film_full.alloc(npix)
+           && hipHostMalloc((void**)&s->host, npix * 16, hipHostMallocDefault) == hipSuccess;
+    if (ok) ok = hipMemsetAsync(s->film_packed.p, 0, std::max<size_t>(padded, 1) * 16, c->stream) == hipSuccess && hipMemsetAsync(s->film_full.p, 0, npix * 16, c->stream) == hipSuccess && hipStreamSynchronize(c->stream) == hipSuccess;
+    if (!ok) { if (s->host) (void)hipHostFree(s->host); delete s; c->fail("out of memory (sensor)"); return 0xFFFFFFFFu; }
+    memset(s->host, 0, npix * 16);
+    c->sensors.push_back(s);
+    return (SensorHandle)c->sensors.size() - 1;
+}
+float* HdMoonshineGetSensorData(const HdMoonshine* c, SensorHandle s) { return s < c->sensors.size() ? (float*)c->sensors[s]->host : nullptr; }
+LensHandle HdMoonshineCreateLens(HdMoonshine* c, Lens l) { LOCK(c); c->lenses.push_back(l); return (LensHandle)c->lenses.size() - 1; }
+void HdMoonshineSetLens(HdMoonshine* c, LensHandle h, Lens l) { LOCK(c); if (h >= c->lenses.size()) return; c->lenses[h] = l; c->clear_all_sensors(); }
+void MsneClearSensor(HdMoonshine* c, SensorHandle s) { LOCK(c); if (s < c->sensors.size()) c->sensors[s]->sample_count = 0; }
+uint32_t MsneGetSampleCount(const HdMoonshine* c, SensorHandle s) { return s < c->sensors.size() ? c->sensors[s]->sample_count : 0; }
+
+int MsneRender(HdMoonshine* c, SensorHandle s, LensHandle l, uint32_t launches, int readback) {
+    LOCK(c);
+    if (!c->bind()) return -1;
+    return c->render(s, l, launches, readback != 0) ? 0 : -1;
+}
+bool HdMoonshineRender(HdMoonshine* c, SensorHandle s, LensHandle l) { return MsneRender(c, s, l, 1, 1) == 0; }
+
+uint64_t MsneGetShardTileCount(const HdMoonshine* c, SensorHandle s) { return s < c->sensors.size() ? c->sensors[s]->shard.local_tiles : 0; }
+void* MsneGetPackedFilmDevicePtr(const HdMoonshine* c, SensorHandle s) { return s < c->sensors.size() ? (void*)c->sensors[s]->film_packed.p : nullptr; }
+int MsneUnpackGatheredFilm(HdMoonshine* c, SensorHandle sh, const void* gathered, uint32_t shard_count) {
+    LOCK(c);
+    if (!c->bind() || sh >= c->sensors.size() || !gathered) return -1;
+    SensorH* s = c->sensors[sh];
+    if (shard_count != s->shard.shard_count) { c->fail("unpack: shard_count mismatch"); return -1; }
+    const uint32_t total = s->shard.tiles_x * s->shard.tiles_y;
+    const size_t stride = (size_t)((total + shard_count - 1) / shard_count) * s->shard.tile_size * s->shard.tile_size;   // max tiles per shard, padded
+    launch_unpack_film(c->stream, 1024, s->shard, (const float4*)gathered, shard_count, 0, stride, s->film_full.p);
+    if (hipMemcpyAsync(s->host, s->film_full.p, (size_t)s->extent.width * s->extent.height * 16, hipMemcpyDeviceToHost, c->stream) != hipSuccess || hipStreamSynchronize(c->stream) != hipSuccess) { c->fail("unpack failed"); return -1; }
+    return 0;
+}
+
+int MsneGetStats(const HdMoonshine* cc, MsneStats* out) {
+    HdMoonshine* c = const_cast<HdMoonshine*>(cc);
+    LOCK(c);
+    if (!out || !c->bind()) return -1;
+    *out = c->stats;
+    if (c->d_counters.p) {
+        Counters h{};
+        if (hipMemcpy(&h, c->d_counters.p, sizeof h, hipMemcpyDeviceToHost) != hipSuccess) return -1;
+        out->closest_rays = h.closest_rays; out->shadow_rays = h.shadow_rays; out->samples = h.samples;
+    }
+    return 0;
+}
+void MsneResetStats(HdMoonshine* c) {
+    LOCK(c);
+    if (!c->bind()) return;
+    c->stats = MsneStats{};
+    if (c->d_counters.p) (void)hipMemset(c->d_counters.p, 0, sizeof(Counters));
+    if (c->d_trace_stats.p) (void)hipMemset(c->d_trace_stats.p, 0, 32);
+}
+
+// ---- diagnostics used by the parity tests (no reference equivalent) ----
+void MsneSetProfiling(HdMoonshine* c, int kernel_events, int traversal_counters) { LOCK(c); c->profile = kernel_events != 0; c->trace_stats = traversal_counters != 0; }
+int MsneGetTraversalCounters(HdMoonshine* c, uint64_t out[4]) {   // closest {node visits, tri tests}, shadow {node visits, tri tests}
+    LOCK(c);
+    if (!c->bind() || !c->d_trace_stats.p) { for (int i = 0; i < 4; i++) out[i] = 0; return 0; }
+    unsigned long long h[4];
+    if (hipMemcpy(h, c->d_trace_stats.p, 32, hipMemcpyDeviceToHost) != hipSuccess) return -1;
+    for (int i = 0; i < 4; i++) out[i] = h[i];
+    return 0;
+}
+// rays: 7 floats each (origin, direction, tmax); out_ids 4 per ray {hit, instance, geometry, primitive}; out_tuv 3 per ray
+int MsneTraceRays(HdMoonshine* c, const float* rays, uint32_t n, int any_hit, uint32_t* out_ids, float* out_tuv) {
+    LOCK(c);
+    if (!c->bind() || !c->ensure_scene() || !c->ensure_wavefront(1, 1)) return -1;
+    if (n == 0) return 0;
+    DevBuf<float> dr; DevBuf<uint32_t> di; DevBuf<float> dt;
+    if (!dr.alloc(7 * (size_t)n) || !di.alloc(4 * (size_t)n) || !dt.alloc(3 * (size_t)n)) { c->fail("out of device memory (probe)"); return -1; }
+    if (hipMemcpyAsync(dr.p, rays, 28 * (size_t)n, hipMemcpyHostToDevice, c->stream) != hipSuccess) return -1;
+    launch_trace_probe(c->stream, c->trace_grid, c->scene_view(), dr.p, n, any_hit, di.p, dt.p, c->d_spill.p, c->d_overflow.p);
+    if (hipMemcpyAsync(out_ids, di.p, 16 * (size_t)n, hipMemcpyDeviceToHost, c->stream) != hipSuccess) return -1;
+    if (hipMemcpyAsync(out_tuv, dt.p, 12 * (size_t)n, hipMemcpyDeviceToHost, c->stream) != hipSuccess) return -1;
+    if (hipStreamSynchronize(c->stream) != hipSuccess) { c->fail("probe failed"); return -1; }
+    return 0;
+}
+uint32_t MsneGetEnvSize(const HdMoonshine* c) { return c->env.size; }
+int MsneReadEnv(HdMoonshine* c, float* rgb_out /*S*S*4*/, float* lum_out /*whole pyramid*/) {
+    LOCK(c);
+    if (!c->bind()) return -1;
+    const uint32_t S = c->env.size; size_t total = 0;
+    for (uint32_t l = 0; l < c->env.mip_count; l++) total += (size_t)(S >> l) * (S >> l);
+    if (rgb_out && hipMemcpy(rgb_out, c->d_env_rgb.p, (size_t)S * S * 16, hipMemcpyDeviceToHost) != hipSuccess) return -1;
+    if (lum_out && hipMemcpy(lum_out, c->d_env_lum.p, total * 4, hipMemcpyDeviceToHost) != hipSuccess) return -1;
+    return 0;
+}
+uint32_t MsneGetAliasTable(HdMoonshine* c, void* out, uint32_t max_entries) {   // entries of 20 B, entry 0 = header
+    LOCK(c);
+    if (!c->bind() || !c->ensure_scene()) return 0;
+    const uint32_t n = (uint32_t)c->h_alias.size();
+    if (out) memcpy(out, c->h_alias.data(), (size_t)std::min(n, max_entries) * sizeof(AliasEntry));
+    return n;
+}
+// BVH dump for structural validation: copies nodes / triangles / tlas items to the host
+int MsneReadBvh(HdMoonshine* c, void* nodes_out, uint32_t* node_count, void* tris_out, uint32_t* tri_count, uint32_t* tlas_root, uint32_t* tlas_items_out, uint32_t* tlas_item_count) {
+    LOCK(c);
+    if (!c->bind() || !c->ensure_scene()) return -1;
+    uint32_t cnt[3];
+    if (hipMemcpy(cnt, c->d_build_counters.p, 12, hipMemcpyDeviceToHost) != hipSuccess) return -1;
+    if (node_count) { if (nodes_out && *node_count >= cnt[0] && hipMemcpy(nodes_out, c->d_nodes.p, (size_t)cnt[0] * sizeof(Node8), hipMemcpyDeviceToHost) != hipSuccess) return -1; *node_count = cnt[0]; }
+    if (tri_count) { if (tris_out && *tri_count >= cnt[1] && hipMemcpy(tris_out, c->d_tris.p, (size_t)cnt[1] * sizeof(TriRec), hipMemcpyDeviceToHost) != hipSuccess) return -1; *tri_count = cnt[1]; }
+    if (tlas_item_count) { if (tlas_items_out && *tlas_item_count >= cnt[2] && cnt[2] && hipMemcpy(tlas_items_out, c->d_tlas_items.p, (size_t)cnt[2] * 4, hipMemcpyDeviceToHost) != hipSuccess) return -1; *tlas_item_count = cnt[2]; }
+    if (tlas_root) *tlas_root = c->tlas_root;
+    return 0;
+}
+
+}  // extern "C"

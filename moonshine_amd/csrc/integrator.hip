@@ -1,0 +1,290 @@
+// integrator.hip — wavefront form of the reference's raygen megakernel:
+//   k_raygen  = raygen prologue: Rng::fromSeed, dispatchUV, Camera::generateRay       (main.hlsl:54-59,83-89; camera.hlsl:14-42)
+//   k_shade   = one iteration of PathTracingIntegrator::incomingRadiance              (integrator.hlsl:79-166) + the miss epilogue (:168-181)
+//   k_film    = storeColor                                                            (main.hlsl:43-51,94)
+//   k_advance = queue bookkeeping between bounces (no reference equivalent: the reference loops inside one thread)
+// Light samples are generated in k_shade; their shadow rays are traced by k_trace_shadow, which zeroes the
+// pending contribution when occluded; the contribution is added to the path's radiance by the next k_shade
+// in the reference's order (env sample, then mesh sample — integrator.hlsl:139-151).
+#include "shade.h"
+
+namespace msne {
+
+constexpr int SHADE_BLOCK = 256;
+
+__device__ __forceinline__ uint32_t wave_append(uint32_t* counter, bool pred) {
+    const unsigned long long m = __ballot(pred);
+    if (!pred) return 0;
+    const uint32_t lane = __lane_id();
+    const int leader = __ffsll((long long)m) - 1;
+    uint32_t base = 0;
+    if ((int)lane == leader) base = atomicAdd(counter, (uint32_t)__popcll(m));
+    base = __shfl(base, leader);
+    return base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+}
+
+// pixel owned by local pixel index p (tile-major order inside the shard); false if outside the image
+__device__ __forceinline__ bool shard_pixel(const ShardView& sh, uint32_t p, uint32_t& x, uint32_t& y) {
+    const uint32_t tpix = sh.tile_size * sh.tile_size;
+    const uint32_t k = p / tpix, w = p % tpix;
+    const uint32_t t = sh.shard_index + k * sh.shard_count;
+    const uint32_t tx = t % sh.tiles_x, ty = t / sh.tiles_x;
+    x = tx * sh.tile_size + w % sh.tile_size;
+    y = ty * sh.tile_size + w / sh.tile_size;
+    return x < sh.width && y < sh.height;
+}
+
+__global__ __launch_bounds__(SHADE_BLOCK) void k_raygen(ShardView sh, CameraConsts cam, PipelineOpts opts, uint32_t sample_base, uint32_t s_count,
+                                                          PathState st, Counters* cnt) {
+    const uint32_t total = s_count * sh.pixels;
+    for (uint32_t slot = blockIdx.x * SHADE_BLOCK + threadIdx.x; slot < ((total + 63u) & ~63u); slot += gridDim.x * SHADE_BLOCK) {
+        uint32_t x = 0, y = 0;
+        const bool active = slot < total && shard_pixel(sh, slot % sh.pixels, x, y);
+        const uint32_t i = wave_append(&cnt->n_cur, active);
+        if (!active) continue;
+        const uint32_t s_local = slot / sh.pixels;
+        uint32_t rng = rng_seed(sample_base + s_local, x, y);                       // main.hlsl:85
+        f2 r1; r1.x = rng_float(rng); r1.y = rng_float(rng);
+        const f2 g = square_to_gaussian(r1);                                        // dispatchUV main.hlsl:54-59
+        const f2 center = F2(0.5f + 0.5f * g.x, 0.5f + 0.5f * g.y);
+        f2 uv = F2(((float)x + center.x) / (float)sh.width, ((float)y + center.y) / (float)sh.height);
+        if (opts.flip_image) uv.y = 1.0f - uv.y;
+        f2 r2; r2.x = rng_float(rng); r2.y = rng_float(rng);
+        const f2 sr = square_to_uniform_disk_concentric(r2);                        // camera.hlsl:31-40
+        const f2 rd = F2(cam.aperture * sr.x / 2.0f, cam.aperture * sr.y / 2.0f);
+        const f3 defocus = add(scale(cam.u, rd.x), scale(cam.v, rd.y));
+        const f3 O = add(cam.origin, defocus);
+        const f3 D = normalize(sub(sub(add(add(cam.llc, scale(cam.horizontal, uv.x)), scale(cam.vertical, uv.y)), defocus), cam.origin));
+        st.ox[i] = O.x; st.oy[i] = O.y; st.oz[i] = O.z; st.dx[i] = D.x; st.dy[i] = D.y; st.dz[i] = D.z;
+        st.tx[i] = 1.0f; st.ty[i] = 1.0f; st.tz[i] = 1.0f;
+        st.lx[i] = 0.0f; st.ly[i] = 0.0f; st.lz[i] = 0.0f;
+        st.p0x[i] = 0.0f; st.p0y[i] = 0.0f; st.p0z[i] = 0.0f; st.p1x[i] = 0.0f; st.p1y[i] = 0.0f; st.p1z[i] = 0.0f;
+        st.last_pdf[i] = 0.0f; st.rng[i] = rng; st.slot[i] = slot; st.flags[i] = 0u;
+    }
+}
+
+__device__ __forceinline__ float power_heuristic(uint32_t numf, float fPdf, uint32_t numg, float gPdf) {   // integrator.hlsl:10-16
+    const float f = (float)numf * fPdf, g = (float)numg * gPdf;
+    const float f2_ = f * f;
+    return f2_ / (f2_ + g * g);
+}
+// estimateDirectMISLight integrator.hlsl:20-35, light already sampled and assumed unoccluded
+__device__ __forceinline__ f3 estimate_direct_mis(const Frame& frame, const LSample& ls, const Mat& mat, f3 woFs, uint32_t samplesTaken) {
+    if (ls.pdf > 0.0f) {
+        const f3 wiFs = frame_world_to_frame(frame, ls.dirWs);
+        const float scatteringPdf = material_pdf(mat, wiFs, woFs);
+        if (scatteringPdf > 0.0f) {
+            const f3 brdf = material_eval(mat, wiFs, woFs);
+            const float weight = power_heuristic(samplesTaken, ls.pdf, 1, scatteringPdf);
+            const float ac = absf(wiFs.z);
+            return F3(ls.radiance.x * brdf.x * ac * weight / ls.pdf, ls.radiance.y * brdf.y * ac * weight / ls.pdf, ls.radiance.z * brdf.z * ac * weight / ls.pdf);
+        }
+    }
+    return F3(0.0f, 0.0f, 0.0f);
+}
+
+__global__ __launch_bounds__(SHADE_BLOCK) void k_shade(SceneView sc, PipelineOpts opts, PathState cur, HitBuf hits, PathState nxt, ShadowQueue shq,
+                                                         float4* lbuf, Counters* cnt) {
+    const uint32_t n = cnt->n_cur;
+    const uint32_t max_bounces = opts.max_bounces, env_n = opts.env_samples, mesh_n = opts.mesh_samples;
+    const uint32_t n_pad = (n + 63u) & ~63u;
+    for (uint32_t i = blockIdx.x * SHADE_BLOCK + threadIdx.x; i < n_pad; i += gridDim.x * SHADE_BLOCK) {
+        const bool live = i < n;
+        bool cont = false, sh0 = false, sh1 = false;
+        // state carried to the next bounce
+        f3 rayO = F3(0, 0, 0), rayD = F3(0, 0, 1), throughput = F3(0, 0, 0), L = F3(0, 0, 0), c0 = F3(0, 0, 0), c1 = F3(0, 0, 0);
+        f3 s0o = F3(0, 0, 0), s0d = F3(0, 0, 0), s1o = F3(0, 0, 0), s1d = F3(0, 0, 0);
+        float s0t = 0.0f, s1t = 0.0f, lastPdf = 0.0f;
+        uint32_t rng = 0, slot = 0, flags = 0;
+        if (live) {
+            rayO = F3(cur.ox[i], cur.oy[i], cur.oz[i]); rayD = F3(cur.dx[i], cur.dy[i], cur.dz[i]);
+            throughput = F3(cur.tx[i], cur.ty[i], cur.tz[i]);
+            L = F3(cur.lx[i], cur.ly[i], cur.lz[i]);
+            lastPdf = cur.last_pdf[i]; rng = cur.rng[i]; slot = cur.slot[i]; flags = cur.flags[i];
+            // light samples of the previous bounce, in the reference's order (env, then mesh)
+            L = add(L, F3(cur.p0x[i], cur.p0y[i], cur.p0z[i]));
+            L = add(L, F3(cur.p1x[i], cur.p1y[i], cur.p1z[i]));
+            const uint32_t bounceCount = flags & 0xFFFFu;
+            const bool isLastMaterialDelta = (flags & PATH_FLAG_DELTA) != 0;
+            bool done = (flags & PATH_FLAG_ZOMBIE) != 0;
+            const uint32_t hinst = hits.inst[i];
+            if (!done && hinst == MAX_UINT) {
+                // miss epilogue, integrator.hlsl:168-181
+                if (env_n == 0 || bounceCount == 0 || isLastMaterialDelta) L = add(L, mul(throughput, env_incoming_radiance(sc.env, rayD)));
+                else {
+                    f3 rad; float pdf;
+                    env_eval(sc.env, rayD, rad, pdf);
+                    if (pdf > 0.0f) { const float weight = power_heuristic(1, lastPdf, env_n, pdf); L = add(L, scale(mul(throughput, rad), weight)); }
+                }
+                done = true;
+            }
+            if (!done) {
+                const uint32_t hgeo = hits.geo[i], hprim = hits.prim[i];
+                GeometryRec geometry;
+                const Attrs attrs = mesh_attributes_world(sc, opts.indexed_attributes != 0, hinst, hgeo, hprim, F2(hits.u[i], hits.v[i]), geometry);
+                const MaterialRec mrec = sc.materials[geometry.material];
+                const Frame textureFrame = get_texture_frame(sc, mrec, opts.two_component_normal_texture != 0, attrs.texcoord, attrs.frame);
+                const f3 emissiveLight = tex_sample_rgb(sc, mrec.emissive, attrs.texcoord);
+                const Mat material = material_load(sc, mrec, attrs.texcoord);
+
+                const f3 woWs = neg(rayD);
+                const bool frontfacing = dot(attrs.triangleFrame.n, woWs) > 0.0f;
+                Frame shadingFrame;
+                if ((frontfacing && dot(woWs, textureFrame.n) > 0.0f) || (!frontfacing && -dot(woWs, textureFrame.n) > 0.0f)) shadingFrame = textureFrame;
+                else if ((frontfacing && dot(woWs, attrs.frame.n) > 0.0f) || (!frontfacing && -dot(woWs, attrs.frame.n) > 0.0f)) shadingFrame = attrs.frame;
+                else shadingFrame = attrs.triangleFrame;
+                const f3 woSs = frame_world_to_frame(shadingFrame, woWs);
+
+                // emission, integrator.hlsl:108-124
+                if (mesh_n == 0 || bounceCount == 0 || !geometry.sampled || isLastMaterialDelta) {
+                    if (dot(woWs, attrs.triangleFrame.n) > 0.0f) L = add(L, mul(throughput, emissiveLight));
+                } else if (geometry.sampled) {
+                    const float sum = sc.alias[0].select;
+                    const float lightPdf = area_to_solid_angle(attrs.position, rayO, rayD, attrs.triangleFrame.n) / sum;
+                    if (lightPdf > 0.0f) { const float weight = power_heuristic(1, lastPdf, mesh_n, lightPdf); L = add(L, scale(mul(throughput, emissiveLight), weight)); }
+                }
+                // termination, integrator.hlsl:126-135
+                if (bounceCount >= max_bounces + 1) done = true;
+                else if (bounceCount > 3) {
+                    const float pSurvive = minf(0.95f, luminance(throughput));
+                    if (rng_float(rng) > pSurvive) done = true;
+                    else throughput = divs(throughput, pSurvive);
+                }
+                if (!done) {
+                    const bool isCurrentMaterialDelta = material_is_delta(material);
+                    if (!isCurrentMaterialDelta) {
+                        if (env_n) {   // integrator.hlsl:141-144 (one sample; MsneSetPipeline rejects > 1)
+                            f2 rand; rand.x = rng_float(rng); rand.y = rng_float(rng);
+                            const LSample ls = env_sample_unoccluded(sc.env, rand);
+                            if (ls.pdf > 0.0f) {
+                                sh0 = true;
+                                s0o = offset_along_normal(attrs.position, face_forward(attrs.triangleFrame.n, ls.dirWs)); s0d = ls.dirWs; s0t = INFINITY_F;
+                                const f3 e = estimate_direct_mis(shadingFrame, ls, material, woSs, env_n);
+                                c0 = divs(mul(throughput, e), (float)env_n);
+                            }
+                        }
+                        if (mesh_n) {  // integrator.hlsl:147-150 + MeshLights::sample light.hlsl:130-158
+                            f2 rand; rand.x = rng_float(rng); rand.y = rng_float(rng);
+                            const uint32_t entryCount = sc.alias[0].alias;
+                            const float sum = sc.alias[0].select;
+                            if (!(entryCount == 0 || sum == 0.0f)) {
+                                const float scaled = rand.x * (float)entryCount;
+                                uint32_t idx = (uint32_t)scaled;
+                                rand.x = scaled - floor_(scaled);
+                                AliasEntry en = alias_load(sc, entryCount, 1 + idx);
+                                if (!coin_flip_remap(en.select, rand.x)) { idx = en.alias; en = alias_load(sc, entryCount, 1 + idx); }
+                                const f2 bary = square_to_triangle(rand);
+                                GeometryRec lgeo;
+                                const Attrs at = mesh_attributes_world(sc, opts.indexed_attributes != 0, en.instance, en.geometry, en.primitive, bary, lgeo);
+                                LSample ls;
+                                ls.radiance = tex_sample_rgb(sc, sc.materials[lgeo.material].emissive, at.texcoord);
+                                ls.dirWs = normalize(sub(at.position, attrs.position));
+                                ls.pdf = area_to_solid_angle(at.position, attrs.position, ls.dirWs, at.triangleFrame.n) / sum;
+                                if (ls.pdf > 0.0f) {
+                                    const f3 offL = offset_along_normal(at.position, at.triangleFrame.n);
+                                    const f3 offS = offset_along_normal(attrs.position, face_forward(attrs.triangleFrame.n, ls.dirWs));
+                                    sh1 = true;
+                                    s1t = length(sub(offL, offS)); s1o = offS; s1d = normalize(sub(offL, offS));
+                                    const f3 e = estimate_direct_mis(shadingFrame, ls, material, woSs, mesh_n);
+                                    c1 = divs(mul(throughput, e), (float)mesh_n);
+                                }
+                            }
+                        }
+                    }
+                    // next direction, integrator.hlsl:153-165
+                    f2 sq; sq.x = rng_float(rng); sq.y = rng_float(rng);
+                    const MSample sample = material_sample(material, woSs, sq);
+                    if (sample.pdf == 0.0f) {
+                        done = true;
+                        if (sh0 || sh1) { cont = true; flags |= PATH_FLAG_ZOMBIE; done = false; }   // finalize after its shadow rays resolve
+                    } else {
+                        lastPdf = sample.pdf;
+                        rayD = frame_frame_to_world(shadingFrame, sample.dirFs);
+                        rayO = offset_along_normal(attrs.position, face_forward(attrs.triangleFrame.n, rayD));
+                        const f3 f = material_eval(material, sample.dirFs, woSs);
+                        const float ac = absf(sample.dirFs.z);
+                        throughput = mul(throughput, F3(f.x * ac / sample.pdf, f.y * ac / sample.pdf, f.z * ac / sample.pdf));
+                        flags = ((bounceCount + 1u) & 0xFFFFu) | (isCurrentMaterialDelta ? PATH_FLAG_DELTA : 0u);
+                        cont = true;
+                    }
+                }
+            }
+            if (done) lbuf[slot] = make_float4(L.x, L.y, L.z, 0.0f);
+        }
+        // ---- compaction: surviving paths and their shadow rays ----
+        const uint32_t j = wave_append(&cnt->n_next, cont);
+        if (cont) {
+            nxt.ox[j] = rayO.x; nxt.oy[j] = rayO.y; nxt.oz[j] = rayO.z; nxt.dx[j] = rayD.x; nxt.dy[j] = rayD.y; nxt.dz[j] = rayD.z;
+            nxt.tx[j] = throughput.x; nxt.ty[j] = throughput.y; nxt.tz[j] = throughput.z;
+            nxt.lx[j] = L.x; nxt.ly[j] = L.y; nxt.lz[j] = L.z;
+            nxt.p0x[j] = c0.x; nxt.p0y[j] = c0.y; nxt.p0z[j] = c0.z; nxt.p1x[j] = c1.x; nxt.p1y[j] = c1.y; nxt.p1z[j] = c1.z;
+            nxt.last_pdf[j] = lastPdf; nxt.rng[j] = rng; nxt.slot[j] = slot; nxt.flags[j] = flags;
+        }
+        const uint32_t q0 = wave_append(&cnt->n_shadow, sh0);
+        if (sh0) { shq.ox[q0] = s0o.x; shq.oy[q0] = s0o.y; shq.oz[q0] = s0o.z; shq.dx[q0] = s0d.x; shq.dy[q0] = s0d.y; shq.dz[q0] = s0d.z; shq.tmax[q0] = s0t; shq.target[q0] = (j << 1); }
+        const uint32_t q1 = wave_append(&cnt->n_shadow, sh1);
+        if (sh1) { shq.ox[q1] = s1o.x; shq.oy[q1] = s1o.y; shq.oz[q1] = s1o.z; shq.dx[q1] = s1d.x; shq.dy[q1] = s1d.y; shq.dz[q1] = s1d.z; shq.tmax[q1] = s1t; shq.target[q1] = (j << 1) | 1u; }
+    }
+}
+
+// between bounces: account the rays just traced, rotate the queues, reset the dequeue heads
+__global__ void k_advance(Counters* cnt, int after_raygen) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    if (after_raygen) { cnt->samples += cnt->n_cur; cnt->n_next = 0; cnt->n_shadow = 0; cnt->head_closest = 0; cnt->head_shadow = 0; return; }
+    cnt->closest_rays += cnt->n_cur;
+    cnt->shadow_rays += cnt->n_shadow;
+    cnt->n_cur = cnt->n_next; cnt->n_next = 0; cnt->n_shadow = 0;
+    cnt->head_closest = 0; cnt->head_shadow = 0;
+}
+
+// storeColor main.hlsl:43-51 over the `s_count` samples of this chunk (summed in sample order, main.hlsl:83-92)
+__global__ __launch_bounds__(SHADE_BLOCK) void k_film(ShardView sh, PipelineOpts opts, const float4* lbuf, uint32_t s_count, int first_chunk, int last_chunk,
+                                                        uint32_t sample_count, float4* color, float4* film) {
+    for (uint32_t p = blockIdx.x * SHADE_BLOCK + threadIdx.x; p < sh.pixels; p += gridDim.x * SHADE_BLOCK) {
+        uint32_t x, y;
+        if (!shard_pixel(sh, p, x, y)) continue;
+        f3 c = F3(0.0f, 0.0f, 0.0f);
+        if (!first_chunk) { const float4 q = color[p]; c = F3(q.x, q.y, q.z); }
+        for (uint32_t s = 0; s < s_count; s++) { const float4 l = lbuf[(size_t)s * sh.pixels + p]; c = add(c, F3(l.x, l.y, l.z)); }
+        if (!last_chunk) { color[p] = make_float4(c.x, c.y, c.z, 0.0f); continue; }
+        const float spr = (float)opts.samples_per_run;
+        if (sample_count == 0) film[p] = make_float4(c.x / spr, c.y / spr, c.z / spr, 1.0f);
+        else {
+            const float4 f = film[p];
+            const float den = (float)(sample_count + opts.samples_per_run);
+            film[p] = make_float4(f.x + (c.x - f.x) / den, f.y + (c.y - f.y) / den, f.z + (c.z - f.z) / den, f.w + 1.0f);
+        }
+    }
+}
+
+// packed (tile-major, per shard) film → row-major full film.  `packed` holds `nshards` shard films back to back,
+// each `stride` float4 long (MsneUnpackGatheredFilm); nshards == 1 for the local readback.
+__global__ __launch_bounds__(SHADE_BLOCK) void k_unpack_film(ShardView sh, const float4* packed, uint32_t nshards, uint32_t first_shard, size_t stride, float4* full) {
+    const uint32_t tpix = sh.tile_size * sh.tile_size;
+    const uint32_t total_tiles = sh.tiles_x * sh.tiles_y;
+    for (size_t g = (size_t)blockIdx.x * SHADE_BLOCK + threadIdx.x; g < (size_t)total_tiles * tpix; g += (size_t)gridDim.x * SHADE_BLOCK) {
+        const uint32_t t = (uint32_t)(g / tpix), w = (uint32_t)(g % tpix);
+        const uint32_t shard = t % sh.shard_count, k = t / sh.shard_count;
+        if (shard < first_shard || shard >= first_shard + nshards) continue;
+        const uint32_t x = (t % sh.tiles_x) * sh.tile_size + w % sh.tile_size, y = (t / sh.tiles_x) * sh.tile_size + w / sh.tile_size;
+        if (x >= sh.width || y >= sh.height) continue;
+        full[(size_t)y * sh.width + x] = packed[(size_t)(shard - first_shard) * stride + (size_t)k * tpix + w];
+    }
+}
+
+// ---------------- host launch wrappers ----------------
+void launch_raygen(hipStream_t s, int grid, const ShardView& sh, const CameraConsts& cam, const PipelineOpts& o, uint32_t sample_base, uint32_t s_count, const PathState& st, Counters* cnt) {
+    hipLaunchKernelGGL(k_raygen, dim3(grid), dim3(SHADE_BLOCK), 0, s, sh, cam, o, sample_base, s_count, st, cnt);
+}
+void launch_shade(hipStream_t s, int grid, const SceneView& sc, const PipelineOpts& o, const PathState& cur, const HitBuf& hits, const PathState& nxt, const ShadowQueue& q, float4* lbuf, Counters* cnt) {
+    hipLaunchKernelGGL(k_shade, dim3(grid), dim3(SHADE_BLOCK), 0, s, sc, o, cur, hits, nxt, q, lbuf, cnt);
+}
+void launch_advance(hipStream_t s, Counters* cnt, int after_raygen) { hipLaunchKernelGGL(k_advance, dim3(1), dim3(1), 0, s, cnt, after_raygen); }
+void launch_film(hipStream_t s, int grid, const ShardView& sh, const PipelineOpts& o, const float4* lbuf, uint32_t s_count, int first_chunk, int last_chunk, uint32_t sample_count, float4* color, float4* film) {
+    hipLaunchKernelGGL(k_film, dim3(grid), dim3(SHADE_BLOCK), 0, s, sh, o, lbuf, s_count, first_chunk, last_chunk, sample_count, color, film);
+}
+void launch_unpack_film(hipStream_t s, int grid, const ShardView& sh, const float4* packed, uint32_t nshards, uint32_t first_shard, size_t stride, float4* full) {
+    hipLaunchKernelGGL(k_unpack_film, dim3(grid), dim3(SHADE_BLOCK), 0, s, sh, packed, nshards, first_shard, stride, full);
+}
+
+}  // namespace msne

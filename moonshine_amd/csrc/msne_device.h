@@ -1,0 +1,119 @@
+// msne_device.h — HBM data layout of the hot path.
+#pragma once
+#include "msne_math.h"
+
+namespace msne {
+
+// ---- acceleration structure ----
+// 8-wide quantized node, 80 B = 5 x 16 B.  Child boxes: lo = origin + qlo * 2^(e-127) per axis.
+// imask bit i: child i is an internal node at nodes[child_base + popcount(imask & ((1<<i)-1))].
+// otherwise meta[i] == 0xFF: empty; else leaf with ((meta>>5)+1) items starting at item_base + (meta & 31).
+struct alignas(16) Node8 {
+    float ox, oy, oz;
+    uint8_t ex, ey, ez, imask;
+    uint32_t child_base;
+    uint32_t item_base;
+    uint8_t meta[8];
+    uint8_t qlo[3][8];
+    uint8_t qhi[3][8];
+};
+static_assert(sizeof(Node8) == 80, "Node8 must be 80 bytes");
+
+// triangle record in BVH order, object space (48 B = 3 x 16 B)
+struct alignas(16) TriRec {
+    float v0x, v0y, v0z, v1x;
+    float v1y, v1z, v2x, v2y;
+    float v2z; uint32_t geo, prim, pad;
+};
+static_assert(sizeof(TriRec) == 48, "TriRec must be 48 bytes");
+
+// per instance (Accel.zig:394-432): object->world, world->object, first geometry, BLAS root
+struct alignas(16) InstanceRec {
+    m34 transform;
+    m34 world_to_instance;
+    uint32_t geo_offset;   // instanceID() (world.hlsl:12-14)
+    uint32_t blas_root;    // node index of the BLAS root, MAX_UINT if the BLAS is empty
+    uint32_t flags;        // bit0 visible, bit1 identity transform
+    uint32_t pad;
+};
+static_assert(sizeof(InstanceRec) == 112, "InstanceRec size");
+
+struct GeometryRec { uint32_t mesh, material, sampled; };                    // world.hlsl:19-23 (12 B)
+struct MeshRec { const float* positions; const float* texcoords; const float* normals; const uint32_t* indices; }; // world.hlsl:25-31 (32 B)
+// reference: Material{normal,emissive,type,addr}+variant buffer (MaterialManager.zig:35-77); flattened here to one 32-B record
+struct alignas(16) MaterialRec { uint32_t normal, emissive, type, color, metalness, roughness; float ior; uint32_t pad; };
+struct TexDesc { uint32_t offset, w, h, pad; };                              // texel offset into SceneView::texels (float4)
+struct AliasEntry { uint32_t alias; float select; uint32_t instance, geometry, primitive; };  // light.hlsl:17-22,112-116 (20 B)
+
+struct EnvView {
+    const float4* rgb;        // S*S equal-area map
+    const float* lum;         // luminance pyramid, level l at lum + lum_offset[l], (S>>l)^2 texels
+    uint32_t lum_offset[12];
+    uint32_t size, mip_count;
+};
+
+struct SceneView {
+    const Node8* nodes;
+    const TriRec* tris;
+    const uint32_t* tlas_items;       // instance index per TLAS leaf item
+    const InstanceRec* instances;
+    const GeometryRec* geometries;
+    const MeshRec* meshes;
+    const MaterialRec* materials;
+    const TexDesc* textures;
+    const float4* texels;
+    const AliasEntry* alias;          // entry 0 = header {count, sum}
+    EnvView env;
+    uint32_t tlas_root;               // MAX_UINT when the scene is empty
+};
+
+// ---- wavefront state (SoA, one slot per in-flight path; two sets ping-pong between bounces) ----
+struct PathState {
+    float* ox; float* oy; float* oz;
+    float* dx; float* dy; float* dz;
+    float* tx; float* ty; float* tz;     // throughput
+    float* lx; float* ly; float* lz;     // accumulated radiance
+    float* p0x; float* p0y; float* p0z;  // pending env-NEE contribution (zeroed by k_trace_shadow if occluded)
+    float* p1x; float* p1y; float* p1z;  // pending mesh-NEE contribution
+    float* last_pdf;
+    uint32_t* rng;
+    uint32_t* slot;                      // sample slot: s_local * pixels + pixel_local
+    uint32_t* flags;                     // bits 0..15 bounce count, bit 16 last material delta, bit 17 zombie (finalize only)
+};
+constexpr uint32_t PATH_FLAG_DELTA = 1u << 16;
+constexpr uint32_t PATH_FLAG_ZOMBIE = 1u << 17;
+constexpr int PATH_STATE_WORDS = 22;
+
+struct HitBuf { uint32_t* inst; uint32_t* geo; uint32_t* prim; float* u; float* v; };
+
+struct ShadowQueue {
+    float* ox; float* oy; float* oz; float* dx; float* dy; float* dz; float* tmax;
+    uint32_t* target;   // (next-state index << 1) | which (0 env, 1 mesh)
+};
+
+// device-side counters; one instance per context
+struct Counters {
+    uint32_t n_cur, n_next, n_shadow, pad0;
+    uint32_t head_closest, head_shadow, pad1, pad2;
+    unsigned long long closest_rays, shadow_rays, samples, pad3;
+};
+
+struct PipelineOpts {   // pipeline.zig:319-327
+    uint32_t samples_per_run, max_bounces, env_samples, mesh_samples;
+    uint32_t flip_image, indexed_attributes, two_component_normal_texture;
+};
+
+// camera constants precomputed on the host with the oracle's expression order (camera.hlsl:14-42)
+struct CameraConsts {
+    f3 origin, u, v, horizontal, vertical, llc;
+    float aperture;
+};
+
+// which pixels this context owns: tile t of the image -> shard t mod shard_count
+struct ShardView {
+    uint32_t width, height, tile_size, tiles_x, tiles_y;
+    uint32_t shard_index, shard_count, local_tiles;   // local tile k = global tile shard_index + k*shard_count
+    uint32_t pixels;                                  // local_tiles * tile_size^2 (padded: edge tiles keep masked pixels)
+};
+
+}  // namespace msne

@@ -240,9 +240,9 @@ class Context:
         return np.ctypeslib.as_array(p, shape=(h, w, 4)).copy()
 
     def counters(self):
-        out = (C.c_uint64 * 6)()
+        out = (C.c_uint64 * 8)()
         self.L.OrcGetCounters(self.h, out)
-        k = ("closest_rays", "shadow_rays", "samples", "surface_hits", "node_visits", "tri_tests")
+        k = ("closest_rays", "shadow_rays", "samples", "surface_hits", "node_visits", "tri_tests", "shadow_node_visits", "shadow_tri_tests")
         return dict(zip(k, [int(x) for x in out]))
 
     def reset_counters(self):

@@ -257,7 +257,7 @@ static int blas_traverse(const orc_bvh *b, v3 o, v3 d, uint32_t inst, orc_hit *b
     stack[sp++] = 0;
     while (sp > 0) {
         const orc_wnode *n = &b->nodes[stack[--sp]];
-        cnt->node_visits++;
+        cnt->node_visits++; if (any_hit) cnt->shadow_node_visits++;
         float tn[8]; int idx[8]; int nh = 0;
         for (int i = 0; i < n->nchild; i++) {
             float t;
@@ -277,7 +277,7 @@ static int blas_traverse(const orc_bvh *b, v3 o, v3 d, uint32_t inst, orc_hit *b
             for (uint32_t q = 0; q < n->count[i]; q++) {
                 const orc_tri *tr = &b->tris[n->child[i] + q];
                 float t, u, v;
-                cnt->tri_tests++;
+                cnt->tri_tests++; if (any_hit) cnt->shadow_tri_tests++;
                 if (!tri_intersect(o, &rk, tr, &t, &u, &v)) continue;
                 if (any_hit) { if (t < best->t) return 1; continue; }
                 int closer = t < best->t;
@@ -300,7 +300,7 @@ static int scene_traverse(const OrcContext *c, v3 o, v3 d, float tmax, orc_hit *
     stack[sp++] = 0;
     while (sp > 0) {
         const orc_wnode *n = &tl->nodes[stack[--sp]];
-        cnt->node_visits++;
+        cnt->node_visits++; if (any_hit) cnt->shadow_node_visits++;
         float tn[8]; int idx[8]; int nh = 0;
         for (int i = 0; i < n->nchild; i++) {
             float t;

@@ -472,6 +472,7 @@ int OrcRender(OrcContext *c, uint32_t sensor, uint32_t lens, uint32_t launches) 
             c->counters.closest_rays += args[i].cnt.closest_rays; c->counters.shadow_rays += args[i].cnt.shadow_rays;
             c->counters.samples += args[i].cnt.samples; c->counters.surface_hits += args[i].cnt.surface_hits;
             c->counters.node_visits += args[i].cnt.node_visits; c->counters.tri_tests += args[i].cnt.tri_tests;
+            c->counters.shadow_node_visits += args[i].cnt.shadow_node_visits; c->counters.shadow_tri_tests += args[i].cnt.shadow_tri_tests;
         }
         s->sample_count += c->opts.samples_per_run;
     }
@@ -495,7 +496,8 @@ uint32_t OrcDebugPath(OrcContext *c, uint32_t sensor, uint32_t lens, uint32_t k,
     rgb[0] = L.x; rgb[1] = L.y; rgb[2] = L.z;
     return g_dbg_n;
 }
-void OrcGetCounters(OrcContext *c, uint64_t out[6]) {
+void OrcGetCounters(OrcContext *c, uint64_t out[8]) {
+    out[6] = c->counters.shadow_node_visits; out[7] = c->counters.shadow_tri_tests;
     out[0] = c->counters.closest_rays; out[1] = c->counters.shadow_rays; out[2] = c->counters.samples;
     out[3] = c->counters.surface_hits; out[4] = c->counters.node_visits; out[5] = c->counters.tri_tests;
 }

@@ -56,7 +56,8 @@ typedef struct { float *film; uint32_t w, h, sample_count; } orc_sensor;
 
 typedef struct {
     uint64_t closest_rays, shadow_rays, samples, surface_hits;
-    uint64_t node_visits, tri_tests;
+    uint64_t node_visits, tri_tests;                 /* all rays */
+    uint64_t shadow_node_visits, shadow_tri_tests;   /* any-hit rays only */
 } orc_counters;
 
 typedef struct OrcContext {

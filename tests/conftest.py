@@ -1,0 +1,33 @@
+import os
+import sys
+
+import pytest
+
+try:  # torch bundles its own libamdhip64.so.7: load it first so the process ends up with ONE HIP runtime
+    import torch  # noqa: F401
+except Exception:  # pragma: no cover
+    torch = None
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def orc():
+    """The CPU oracle (test infrastructure): builds oracle/liborc.so on first use."""
+    from oracle import orc as _orc
+    _orc.build()
+    return _orc
+
+
+@pytest.fixture(scope="session")
+def gpu_api():
+    """The product: HIP library through its C ABI.  Fails (not skips) if the library is missing."""
+    from moonshine_amd import api
+    api.load_library()
+    return api

@@ -1,0 +1,279 @@
+"""GPU parity tests proper: HIP path (through the C ABI) vs the CPU oracle on the same inputs.
+
+Bar: bit-exact.  The hot path computes in f32 with single IEEE operations in a fixed order and
+from-scratch transcendentals (csrc/msne_math.h), and hits are decided by a watertight triangle test
+with deterministic tie-breaks, so the GPU film equals the oracle's film bit for bit; the north-star
+tolerance (relative per-pixel L2 < 1e-4) is asserted as well and must hold a fortiori.
+"""
+import math
+
+import numpy as np
+import pytest
+
+from moonshine_amd import scenes
+
+pytestmark = pytest.mark.gpu
+
+
+def rel_l2(a, b):
+    return float(np.linalg.norm(a.astype(np.float64) - b.astype(np.float64)) / max(np.linalg.norm(b.astype(np.float64)), 1e-30))
+
+
+def assert_film_equal(gpu_img, orc_img, what):
+    g, o = gpu_img[..., :3], orc_img[..., :3]
+    l2 = rel_l2(g, o)
+    nbad = int((g.view(np.uint32) != o.view(np.uint32)).any(axis=-1).sum())
+    assert l2 < 1e-4, "%s: relative L2 %g" % (what, l2)
+    assert nbad == 0, "%s: %d pixels differ bitwise (rel L2 %g, max abs %g)" % (what, nbad, l2, float(np.abs(g - o).max()))
+    assert np.array_equal(gpu_img[..., 3], orc_img[..., 3]), "%s: alpha (launch count) differs" % what
+
+
+def both(orc, gpu_api, builder, **kw):
+    oc = orc.Context(threads=8)
+    gc = gpu_api.Context()
+    so, lo = builder(oc, **kw)
+    sg, lg = builder(gc, **kw)
+    return oc, so, lo, gc, sg, lg
+
+
+# ---- the reference's own furnace tests (engine/tests.zig:257-455), at the reference's parameters and tolerances ----
+def test_furnace_white_sphere(orc, gpu_api):
+    oc, so, lo, gc, sg, lg = both(orc, gpu_api, scenes.furnace_white_sphere)
+    for c in (oc, gc):
+        c.set_pipeline(samples_per_run=512, max_bounces=1024, env_samples_per_bounce=0, mesh_samples_per_bounce=0)
+    gc.render(sg, lg); oc.render(so, lo)
+    g = gc.sensor_data(sg)
+    assert np.all(np.abs(g[..., :3] - 1.0) <= 1e-5), "tests.zig:339-343"
+    assert_film_equal(g, oc.sensor_data(so), "white furnace")
+    # tests.zig:346-363: same scene with env sampling (MIS)
+    for c in (oc, gc):
+        c.set_pipeline(samples_per_run=512, max_bounces=1024, env_samples_per_bounce=1, mesh_samples_per_bounce=0)
+    gc.render(sg, lg); oc.render(so, lo)
+    g = gc.sensor_data(sg)
+    assert np.all(np.abs(g[..., :3] - 1.0) <= 0.1), "tests.zig:358-362"
+    assert_film_equal(g, oc.sensor_data(so), "white furnace + env MIS")
+    assert gc.counters() == {k: v for k, v in oc.counters().items() if k in ("closest_rays", "shadow_rays", "samples")}
+
+
+def test_furnace_inside_sphere(orc, gpu_api):
+    oc, so, lo, gc, sg, lg = both(orc, gpu_api, scenes.furnace_inside_sphere)
+    for c in (oc, gc):
+        c.set_pipeline(samples_per_run=1024, max_bounces=1024, env_samples_per_bounce=0, mesh_samples_per_bounce=0)
+    gc.render(sg, lg); oc.render(so, lo)
+    g = gc.sensor_data(sg)
+    assert np.all(np.abs(g[..., :3] - 1.0) <= 0.02), "tests.zig:449-454"
+    assert_film_equal(g, oc.sensor_data(so), "inside furnace")
+
+
+# ---- traversal: hit records ----
+def _random_rays(n, seed, radius=4.0):
+    rng = np.random.default_rng(seed)
+    o = rng.normal(size=(n, 3)); o = o / np.linalg.norm(o, axis=1, keepdims=True) * radius
+    tgt = rng.normal(size=(n, 3)) * 0.7
+    d = tgt - o; d /= np.linalg.norm(d, axis=1, keepdims=True)
+    rays = np.zeros((n, 7), np.float32)
+    rays[:, :3] = o; rays[:, 3:6] = d; rays[:, 6] = 1e12
+    return rays
+
+
+def _check_rays(oc, gc, rays):
+    ids, tuv = gc.trace_rays(rays, any_hit=False)
+    occ, _ = gc.trace_rays(rays, any_hit=True)
+    for k in range(len(rays)):
+        hit, oid, otuv = oc.trace_closest(rays[k, :3], rays[k, 3:6], float(rays[k, 6]))
+        assert bool(ids[k, 0]) == hit, "ray %d hit flag" % k
+        if hit:
+            assert tuple(ids[k, 1:4]) == tuple(oid), "ray %d ids %s vs %s" % (k, ids[k, 1:4], oid)
+            assert np.array_equal(tuv[k].view(np.uint32), otuv.view(np.uint32)), "ray %d tuv %s vs %s" % (k, tuv[k], otuv)
+        assert bool(occ[k, 0]) == oc.trace_shadow(rays[k, :3], rays[k, 3:6], float(rays[k, 6])), "ray %d occlusion" % k
+
+
+def test_trace_rays_icosphere(orc, gpu_api):
+    oc, so, lo, gc, sg, lg = both(orc, gpu_api, scenes.furnace_white_sphere, order=4)
+    _check_rays(oc, gc, _random_rays(3000, 1))
+
+
+def test_trace_rays_instanced(orc, gpu_api):
+    oc, so, lo, gc, sg, lg = both(orc, gpu_api, scenes.s2, extent=(64, 36), dims=(3, 3, 2), order=2)
+    rays = _random_rays(3000, 2, radius=12.0)
+    rays[:, 2] = np.abs(rays[:, 2]) + 0.5
+    _check_rays(oc, gc, rays)
+    # hidden instance is skipped; moved instance is found at its new place (Accel.zig:226,402; hydra.zig:499-513)
+    for c in (oc, gc):
+        c.set_instance_visibility(0, False)
+        T = np.eye(3, 4, dtype=np.float32); T[:, 3] = [0.3, -0.2, 6.0]
+        c.set_instance_transform(1, T)
+    _check_rays(oc, gc, rays[:1500])
+
+
+def test_empty_scene(orc, gpu_api):
+    gc = gpu_api.Context(); oc = orc.Context()
+    for c in (gc, oc):
+        c.set_background(np.array([0.25, 0.5, 1.0, 1.0], np.float32), 1, 1)
+        c.set_pipeline(samples_per_run=2, max_bounces=4)
+    sg = gc.create_sensor(40, 24); lg = gc.create_lens(gc.make_lens((0, 0, 0), (1, 0, 0), (0, 0, 1), 0.8))
+    so = oc.create_sensor(40, 24); lo = oc.create_lens(oc.make_lens((0, 0, 0), (1, 0, 0), (0, 0, 1), 0.8))
+    gc.render(sg, lg); oc.render(so, lo)
+    assert_film_equal(gc.sensor_data(sg), oc.sensor_data(so), "empty scene")
+    assert np.allclose(gc.sensor_data(sg)[..., :3], [0.25, 0.5, 1.0])
+
+
+# ---- environment preprocessing + alias table ----
+def test_env_map_build(orc, gpu_api):
+    img = scenes.sky_sun_equirect(96, 48)
+    gc = gpu_api.Context(); oc = orc.Context()
+    for c in (gc, oc):
+        c.set_background(img, 96, 48)
+    grgb, glum = gc.env(); orgb, olum = oc.env()
+    assert grgb.shape == (32, 32, 4) and len(glum) == 6   # S = min(floorPow2(48), 1024), BackgroundManager.zig:154
+    assert np.array_equal(grgb.view(np.uint32), orgb.view(np.uint32))
+    for a, b in zip(glum, olum):
+        assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
+
+
+def test_alias_table(orc, gpu_api):
+    oc, so, lo, gc, sg, lg = both(orc, gpu_api, scenes.cornell, extent=(32, 32))
+    a, b = gc.alias_table(), oc.alias_table()
+    assert len(a) == 3 and a[0]["alias"] == 2   # header + the two emitter triangles
+    assert a.tobytes() == b.tobytes()
+
+
+# ---- full integrator on every material / light type ----
+@pytest.mark.parametrize("env", ["constant", "sky"])
+def test_s1_small(orc, gpu_api, env):
+    kw = dict(extent=(160, 90), grid=3, order=3, env=env)
+    oc, so, lo, gc, sg, lg = both(orc, gpu_api, scenes.s1, **kw)
+    for c in (oc, gc):
+        c.set_pipeline(samples_per_run=1, max_bounces=8, env_samples_per_bounce=1, mesh_samples_per_bounce=1)
+    gc.render(sg, lg, launches=6); oc.render(so, lo, launches=6)
+    assert gc.sample_count(sg) == 6
+    assert_film_equal(gc.sensor_data(sg), oc.sensor_data(so), "S1 small (%s env)" % env)
+    assert gc.counters() == {k: v for k, v in oc.counters().items() if k in ("closest_rays", "shadow_rays", "samples")}
+
+
+def test_cornell(orc, gpu_api):
+    oc, so, lo, gc, sg, lg = both(orc, gpu_api, scenes.cornell, extent=(96, 96))
+    for c in (oc, gc):
+        c.set_pipeline(samples_per_run=4, max_bounces=8, env_samples_per_bounce=0, mesh_samples_per_bounce=1)
+    gc.render(sg, lg, launches=2); oc.render(so, lo, launches=2)
+    assert_film_equal(gc.sensor_data(sg), oc.sensor_data(so), "cornell")
+
+
+def test_instanced_s2_small(orc, gpu_api):
+    oc, so, lo, gc, sg, lg = both(orc, gpu_api, scenes.s2, extent=(128, 72), dims=(3, 3, 2), order=3)
+    for c in (oc, gc):
+        c.set_pipeline(samples_per_run=2, max_bounces=8, env_samples_per_bounce=1, mesh_samples_per_bounce=1)
+    gc.render(sg, lg, launches=2); oc.render(so, lo, launches=2)
+    assert_film_equal(gc.sensor_data(sg), oc.sensor_data(so), "S2 small")
+
+
+def test_textured_and_normal_mapped(orc, gpu_api):
+    """bilinear/repeat texture sampling, sRGB decode, two-component normal maps, vertex normals, texcoords, thin lens."""
+    rng = np.random.default_rng(7)
+    def build(c):
+        P, I = scenes.icosphere(3)
+        N = P.copy()
+        T = np.stack([np.arctan2(P[:, 1], P[:, 0]) / (2 * math.pi) + 0.5, np.arccos(np.clip(P[:, 2], -1, 1)) / math.pi], -1).astype(np.float32)
+        mesh = c.create_mesh(P, I, normals=N, texcoords=T)
+        col = rng2.integers(0, 256, size=(16, 32, 4), dtype=np.uint8)
+        nrm = (128 + rng2.integers(-40, 40, size=(8, 8, 2))).astype(np.uint8)
+        rough = rng2.integers(30, 200, size=(4, 4), dtype=np.uint8)
+        tcol = c.create_texture(col, 32, 16, "r8g8b8a8_srgb")
+        tn = c.create_texture(nrm, 8, 8, "r8g8_unorm")
+        tr = c.create_texture(rough, 4, 4, "r8_unorm")
+        m = c.create_material(scenes.STANDARD_PBR, tn, c.solid_texture(0.0, 0.0, 0.0), color=tcol, metalness=c.solid_texture(0.3), roughness=tr, ior=1.45)
+        c.create_instance([(mesh, m, False)])
+        gp, gi = scenes.quad((-4, -4, -1), (4, -4, -1), (4, 4, -1), (-4, 4, -1))
+        gm = c.create_material(scenes.LAMBERT, c.solid_texture(0.5, 0.5), c.solid_texture(0.0, 0.0, 0.0), color=c.solid_texture(0.6, 0.6, 0.6))
+        c.create_instance([(c.create_mesh(gp, gi), gm, False)])
+        img = scenes.sky_sun_equirect(64, 32)
+        c.set_background(img, 64, 32)
+        lens = c.create_lens(c.make_lens((-3, -1, 1.5), (0.8, 0.3, -0.4), (0, 0, 1), 0.7, aperture=0.05, focus_distance=3.0))
+        return c.create_sensor(96, 64), lens
+    gc = gpu_api.Context(); oc = orc.Context(threads=8)
+    rng2 = np.random.default_rng(7); sg, lg = build(gc)
+    rng2 = np.random.default_rng(7); so, lo = build(oc)
+    for c in (oc, gc):
+        c.set_pipeline(samples_per_run=2, max_bounces=6, env_samples_per_bounce=1, mesh_samples_per_bounce=0)
+    gc.render(sg, lg, launches=2); oc.render(so, lo, launches=2)
+    assert_film_equal(gc.sensor_data(sg), oc.sensor_data(so), "textured sphere")
+
+
+def test_progressive_equals_batched(gpu_api):
+    """running mean over launches (main.hlsl:43-51): N x Render(1) == Render(N); Sensor.clear restarts it (Sensor.zig:81-83)."""
+    gc = gpu_api.Context()
+    s, l = scenes.cornell(gc, extent=(48, 48))
+    gc.set_pipeline(samples_per_run=1, max_bounces=4, env_samples_per_bounce=0, mesh_samples_per_bounce=1)
+    gc.render(s, l, launches=5)
+    a = gc.sensor_data(s)
+    gc.clear_sensor(s)
+    for _ in range(5):
+        gc.render(s, l, launches=1)
+    b = gc.sensor_data(s)
+    assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
+    assert np.all(a[..., 3] == 5.0)
+
+
+def test_sharded_film_equals_unsharded(gpu_api):
+    """image tiles shard across contexts; gather + unpack reproduces the unsharded film bit for bit."""
+    import ctypes as C
+    full = gpu_api.Context()
+    s, l = scenes.cornell(full, extent=(200, 136))     # not a multiple of the tile size
+    full.set_pipeline(samples_per_run=1, max_bounces=4, env_samples_per_bounce=0, mesh_samples_per_bounce=1)
+    full.render(s, l, launches=3)
+    ref = full.sensor_data(s)
+    G = 3
+    shards = [gpu_api.Context(shard_index=i, shard_count=G) for i in range(G)]
+    hs = []
+    for c in shards:
+        ss, ll = scenes.cornell(c, extent=(200, 136))
+        c.set_pipeline(samples_per_run=1, max_bounces=4, env_samples_per_bounce=0, mesh_samples_per_bounce=1)
+        c.render(ss, ll, launches=3, readback=False)
+        hs.append(ss)
+    hip = C.CDLL("libamdhip64.so.7")     # the runtime libmoonshine_amd.so is already using
+    hip.hipMalloc.argtypes = [C.POINTER(C.c_void_p), C.c_size_t]
+    hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+    n4 = shards[0].packed_film(hs[0])[1]
+    gathered = C.c_void_p()
+    assert hip.hipMalloc(C.byref(gathered), G * n4 * 16) == 0
+    for i, (c, ss) in enumerate(zip(shards, hs)):     # stands in for the RCCL gather of bench.py
+        ptr, n = c.packed_film(ss)
+        assert n == n4
+        assert hip.hipMemcpy(C.c_void_p(gathered.value + i * n4 * 16), C.c_void_p(ptr), n4 * 16, 3) == 0
+    shards[0].unpack_gathered(hs[0], gathered.value, G)
+    got = shards[0].sensor_data(hs[0])
+    assert np.array_equal(got.view(np.uint32), ref.view(np.uint32))
+
+
+def test_hydra_abi_smoke(gpu_api):
+    """the 24 reference entry points (hydra/moonshine.h:72-95) drive a render exactly as hydra/*.cpp would."""
+    import ctypes as C
+    L = gpu_api.load_library()
+    h = L.HdMoonshineCreate()
+    assert h
+    P, I = scenes.icosphere(2)
+    fvn = P[I.reshape(-1)]   # face-varying normals (hydra.zig:379-380)
+    mesh = L.HdMoonshineCreateMesh(h, P.ctypes.data_as(C.c_void_p), fvn.ctypes.data_as(C.c_void_p), None, len(P), I.ctypes.data_as(C.c_void_p), len(I))
+    up = L.HdMoonshineCreateSolidTexture3(h, gpu_api.F32x3(0, 0, 1), b"up")      # renderParam.hpp:15: raw three-component normal
+    black = L.HdMoonshineCreateSolidTexture3(h, gpu_api.F32x3(0, 0, 0), b"black")
+    grey = L.HdMoonshineCreateSolidTexture3(h, gpu_api.F32x3(0.5, 0.5, 0.5), b"grey")
+    zero = L.HdMoonshineCreateSolidTexture1(h, 0.0, b"zero"); one = L.HdMoonshineCreateSolidTexture1(h, 1.0, b"one")
+    mat = L.HdMoonshineCreateMaterial(h, gpu_api.Material(up, black, grey, zero, one, 1.5))
+    geo = (gpu_api.Geometry * 1)(gpu_api.Geometry(mesh, mat, False))
+    inst = L.HdMoonshineCreateInstance(h, gpu_api.mat3x4(), geo, 1, True)
+    sensor = L.HdMoonshineCreateSensor(h, gpu_api.Extent2D(32, 32))
+    lens = L.HdMoonshineCreateLens(h, gpu_api.make_lens((-3, 0, 0), (1, 0, 0), (0, 0, 1), 0.8))
+    assert L.HdMoonshineRender(h, sensor, lens) and L.HdMoonshineRender(h, sensor, lens)
+    img = np.ctypeslib.as_array(L.HdMoonshineGetSensorData(h, sensor), shape=(32, 32, 4)).copy()
+    assert np.all(img[..., 3] == 2.0) and np.isfinite(img).all()
+    assert img[0, 0, 0] == 1.0 and 0.0 < img[16, 16, 0] < 1.0      # white default background; grey sphere in the middle
+    L.HdMoonshineSetMaterialColor(h, mat, black)                    # deferred until the next Render (hydra.zig:435-481)
+    L.HdMoonshineSetInstanceTransform(h, inst, gpu_api.mat3x4())    # clears the sensors (hydra.zig:499-513)
+    assert L.HdMoonshineRender(h, sensor, lens)
+    img2 = np.ctypeslib.as_array(L.HdMoonshineGetSensorData(h, sensor), shape=(32, 32, 4)).copy()
+    assert np.all(img2[..., 3] == 1.0) and img2[16, 16, 0] < img[16, 16, 0]
+    L.HdMoonshineDestroyInstance(h, inst)
+    assert L.HdMoonshineRebuildPipeline(h) and L.HdMoonshineRender(h, sensor, lens)
+    img3 = np.ctypeslib.as_array(L.HdMoonshineGetSensorData(h, sensor), shape=(32, 32, 4)).copy()
+    assert np.all(img3[..., :3] == 1.0)
+    L.HdMoonshineDestroy(h)
