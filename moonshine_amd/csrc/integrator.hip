@@ -196,7 +196,7 @@ __global__ __launch_bounds__(SHADE_BLOCK) void k_shade(SceneView sc, PipelineOpt
                     const MSample sample = material_sample(material, woSs, sq);
                     if (sample.pdf == 0.0f) {
                         done = true;
-                        if (sh0 || sh1) { cont = true; flags |= PATH_FLAG_ZOMBIE; done = false; }   // finalize after its shadow rays resolve
+                        if (sh0 || sh1) { cont = true; flags |= PATH_FLAG_ZOMBIE; done = false; atomicAdd(&cnt->zombies_next, 1u); }   // finalize after its shadow rays resolve
                     } else {
                         lastPdf = sample.pdf;
                         rayD = frame_frame_to_world(shadingFrame, sample.dirFs);
@@ -230,8 +230,9 @@ __global__ __launch_bounds__(SHADE_BLOCK) void k_shade(SceneView sc, PipelineOpt
 // between bounces: account the rays just traced, rotate the queues, reset the dequeue heads
 __global__ void k_advance(Counters* cnt, int after_raygen) {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
-    if (after_raygen) { cnt->samples += cnt->n_cur; cnt->n_next = 0; cnt->n_shadow = 0; cnt->head_closest = 0; cnt->head_shadow = 0; return; }
-    cnt->closest_rays += cnt->n_cur;
+    if (after_raygen) { cnt->samples += cnt->n_cur; cnt->zombies_cur = 0; cnt->zombies_next = 0; cnt->n_next = 0; cnt->n_shadow = 0; cnt->head_closest = 0; cnt->head_shadow = 0; return; }
+    cnt->closest_rays += cnt->n_cur - cnt->zombies_cur;
+    cnt->zombies_cur = cnt->zombies_next; cnt->zombies_next = 0;
     cnt->shadow_rays += cnt->n_shadow;
     cnt->n_cur = cnt->n_next; cnt->n_next = 0; cnt->n_shadow = 0;
     cnt->head_closest = 0; cnt->head_shadow = 0;

@@ -93,8 +93,8 @@ struct ShadowQueue {
 
 // device-side counters; one instance per context
 struct Counters {
-    uint32_t n_cur, n_next, n_shadow, pad0;
-    uint32_t head_closest, head_shadow, pad1, pad2;
+    uint32_t n_cur, n_next, n_shadow, zombies_cur;      // zombies: queue entries that only wait to be finalized (no ray)
+    uint32_t head_closest, head_shadow, zombies_next, pad2;
     unsigned long long closest_rays, shadow_rays, samples, pad3;
 };
 
