@@ -20,7 +20,7 @@ namespace msne {
 // kernels' host wrappers (trace.hip, integrator.hip, env.hip, bvh_build.hip)
 void launch_trace_closest(hipStream_t, int, bool, const SceneView&, const PathState&, const HitBuf&, Counters*, uint32_t*, uint32_t*, unsigned long long*);
 void launch_trace_shadow(hipStream_t, int, bool, const SceneView&, const ShadowQueue&, const PathState&, Counters*, uint32_t*, uint32_t*, unsigned long long*);
-void launch_trace_probe(hipStream_t, int, const SceneView&, const float*, uint32_t, int, uint32_t*, float*, uint32_t*, uint32_t*);
+void launch_trace_probe(hipStream_t, int, const SceneView&, const float*, uint32_t, int, uint32_t*, uint32_t*, float*, uint32_t*, uint32_t*);
 size_t trace_spill_words(int grid);
 void launch_raygen(hipStream_t, int, const ShardView&, const CameraConsts&, const PipelineOpts&, uint32_t, uint32_t, const PathState&, Counters*);
 void launch_shade(hipStream_t, int, const SceneView&, const PipelineOpts&, const PathState&, const HitBuf&, const PathState&, const ShadowQueue&, float4*, Counters*);
@@ -725,7 +725,8 @@ int MsneTraceRays(HdMoonshine* c, const float* rays, uint32_t n, int any_hit, ui
     DevBuf<float> dr; DevBuf<uint32_t> di; DevBuf<float> dt;
     if (!dr.alloc(7 * (size_t)n) || !di.alloc(4 * (size_t)n) || !dt.alloc(3 * (size_t)n)) { c->fail("out of device memory (probe)"); return -1; }
     if (hipMemcpyAsync(dr.p, rays, 28 * (size_t)n, hipMemcpyHostToDevice, c->stream) != hipSuccess) return -1;
-    launch_trace_probe(c->stream, c->trace_grid, c->scene_view(), dr.p, n, any_hit, di.p, dt.p, c->d_spill.p, c->d_overflow.p);
+    if (hipMemsetAsync(&c->d_counters.p->head_closest, 0, 4, c->stream) != hipSuccess) return -1;
+    launch_trace_probe(c->stream, c->trace_grid, c->scene_view(), dr.p, n, any_hit, &c->d_counters.p->head_closest, di.p, dt.p, c->d_spill.p, c->d_overflow.p);
     if (hipMemcpyAsync(out_ids, di.p, 16 * (size_t)n, hipMemcpyDeviceToHost, c->stream) != hipSuccess) return -1;
     if (hipMemcpyAsync(out_tuv, dt.p, 12 * (size_t)n, hipMemcpyDeviceToHost, c->stream) != hipSuccess) return -1;
     if (hipStreamSynchronize(c->stream) != hipSuccess) { c->fail("probe failed"); return -1; }

@@ -1,5 +1,5 @@
 // shade.h — device-side restatement of shaders/hrtsystem/{world,material,light}.hlsl (cites per function).
-// Expression order is identical to the test oracle's (oracle/orc_shade.h) so radiance is bit-exact.
+// Expression order is identical to the test oracle's restatement so radiance is bit-exact.
 #pragma once
 #include "msne_device.h"
 

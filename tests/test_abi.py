@@ -1,0 +1,54 @@
+"""CPU tests: the C-ABI library loads and exports every symbol include/moonshine_amd.h declares; struct layouts match
+hydra/moonshine.h.  No compute call is made (there is no GPU here, and there is no CPU fallback)."""
+import ctypes as C
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol(gpu_api):
+    L = gpu_api.load_library()
+    hdr = open(os.path.join(ROOT, "include", "moonshine_amd.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    declared = set(re.findall(r"\b((?:HdMoonshine|Msne)[A-Za-z0-9]+)\s*\(", hdr))
+    assert len([d for d in declared if d.startswith("HdMoonshine")]) == 24        # hydra/moonshine.h:72-95
+    bound = {s[0] for s in gpu_api.SYMBOLS}
+    assert declared == bound, (declared ^ bound)
+    for name in declared:
+        assert hasattr(L, name), name
+
+
+def test_struct_layouts_match_reference_header(gpu_api):
+    a = gpu_api
+    assert C.sizeof(a.F32x2) == 8 and C.sizeof(a.F32x3) == 12 and C.sizeof(a.F32x4) == 16
+    assert C.sizeof(a.Mat3x4) == 48                      # moonshine.h:33-35
+    assert C.sizeof(a.Geometry) == 12                    # moonshine.h:37-41 (u32, u32, bool + pad)
+    assert C.sizeof(a.Lens) == 48                        # moonshine.h:48-55 / Camera.zig:18-25
+    assert C.sizeof(a.Material) == 24                    # moonshine.h:57-64
+    assert C.sizeof(a.MsnePipelineOpts) == 28            # pipeline.zig:319-327: 7 x 4 B spec constants
+    assert C.sizeof(a.Extent2D) == 8
+
+
+def test_no_cpu_fallback_without_gpu(gpu_api):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    with pytest.raises(gpu_api.MoonshineError):
+        gpu_api.Context()          # must fail loudly, not fall back to a CPU path
+    L = gpu_api.load_library()
+    assert L.HdMoonshineCreate() in (None, 0)            # hydra.zig:107-143: NULL on init failure
+    assert b"HIP device" in L.MsneGetLastError(None)
+
+
+def test_product_never_imports_the_oracle():
+    """the oracle is test infrastructure: nothing under moonshine_amd/ or include/ may import, include, link or load it"""
+    pat = re.compile(r"(^\s*(from|import)\s+oracle\b)|(#include\s*[\"<][^\">]*orc_)|(liborc)|(\boracle[./]orc)", re.M)
+    for top in ("moonshine_amd", "include"):
+        for dirpath, _, files in os.walk(os.path.join(ROOT, top)):
+            for f in files:
+                if f.endswith((".py", ".hip", ".h", ".cpp", ".c")):
+                    src = open(os.path.join(dirpath, f), errors="ignore").read()
+                    assert not pat.search(src), (f, pat.search(src).group(0))

@@ -1,0 +1,229 @@
+"""CPU tests (-m "not gpu"): the oracle against the reference's own pins and the committed golden vectors.
+
+Pins available for this path: the reference's furnace tests (engine/tests.zig:257-455), run here
+at the reference's exact parameters and tolerances, and the integer-exact PCG answers.  Everything else the
+reference leaves untested; for those the golden files freeze the oracle's restatement of Appendix A.
+"""
+import json
+import math
+import os
+
+import numpy as np
+import pytest
+
+from moonshine_amd import scenes
+
+G = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def bits(a):
+    return np.ascontiguousarray(a, np.float32).view(np.uint32)
+
+
+def test_pcg_known_answers(orc):
+    d = json.load(open(os.path.join(G, "rng.json")))
+    # SURVEY.md Appendix A.1 (random.hlsl:8-46, integer-exact)
+    assert orc.pcg(0) == 0x07bb2fe2 and orc.pcg(1) == 0xa8beea3c and orc.pcg(0xFFFFFFFF) == 0xe62a4902
+    st, f = orc.rng_floats(0, 0, 0, 4)
+    assert st == 0x7fddb461 and [int(x * 2 ** 24) for x in f] == [9253448, 10386727, 5161806, 1356166]
+    st, f = orc.rng_floats(5, 1919, 1079, 4)
+    assert st == 0xa704cf68 and [int(x * 2 ** 24) for x in f] == [9975394, 12244545, 12969628, 11018050]
+    for s in d["streams"]:
+        st, f = orc.rng_floats(*s["seed"], 16)
+        assert st == s["state0"] and [int(x * 2 ** 24) for x in f] == s["h_shr8"]
+        assert np.all((f >= 0) & (f < 1))
+
+
+def test_math_golden_and_accuracy(orc):
+    m = np.load(os.path.join(G, "math.npz"))
+    assert np.array_equal(bits(orc.math_probe("sin", m["xs"])), bits(m["sin"]))
+    assert np.array_equal(bits(orc.math_probe("cos", m["xs"])), bits(m["cos"]))
+    assert np.array_equal(bits(orc.math_probe("log", m["x01"])), bits(m["log"]))
+    assert np.array_equal(bits(orc.math_probe("atan2", m["atan2_in"])), bits(m["atan2"]))
+    # the from-scratch transcendentals are as accurate as a libm: <= 2 ulp-ish absolute error on the ranges the path uses
+    x = np.linspace(-1, 7, 20001).astype(np.float32)
+    assert np.abs(orc.math_probe("sin", x) - np.sin(x.astype(np.float64))).max() < 2.5e-7
+    assert np.abs(orc.math_probe("cos", x) - np.cos(x.astype(np.float64))).max() < 2.5e-7
+    u = np.linspace(1e-7, 0.99, 20001).astype(np.float32)
+    assert np.abs(orc.math_probe("log", u) / np.log(u.astype(np.float64)) - 1).max() < 3e-7
+    a = np.linspace(-1, 1, 20001).astype(np.float32)
+    assert np.abs(orc.math_probe("acos", a) - np.arccos(a.astype(np.float64))).max() < 6e-7
+    assert orc.math_probe("log", np.float32([1.0]))[0] == 0.0
+
+
+def test_equal_area_sphere_roundtrip(orc):
+    m = np.load(os.path.join(G, "math.npz"))
+    sph = orc.square_to_equal_area_sphere(m["grid"])
+    assert np.array_equal(bits(sph), bits(m["sphere"]))
+    assert np.array_equal(bits(orc.square_to_equal_area_sphere_inverse(sph)), bits(m["sphere_inv"]))
+    rs = np.random.default_rng(3)
+    uv = rs.random((4000, 2)).astype(np.float32)
+    d = orc.square_to_equal_area_sphere(uv)
+    assert np.abs(np.linalg.norm(d, axis=1) - 1).max() < 1e-6            # on the unit sphere (mappings.hlsl:67-83)
+    assert np.abs(orc.square_to_equal_area_sphere_inverse(d) - uv).max() < 2e-6   # inverse (mappings.hlsl:85-99)
+    assert abs(d[:, 2].mean()) < 0.03                                     # equal-area: z uniform in [-1,1]
+
+
+def test_offset_along_normal(orc):
+    m = np.load(os.path.join(G, "math.npz"))
+    out = orc.offset_along_normal(m["off_p"], m["off_n"])
+    assert np.array_equal(bits(out), bits(m["off_out"]))
+    # math.hlsl:32-42: near the origin the offset is n/65536, elsewhere an integer ulp step away from the surface
+    assert np.allclose(orc.offset_along_normal([(0, 0, 0)], [(1, 0, 0)]), [[1 / 65536, 0, 0]])
+    p = orc.offset_along_normal([(1, 1, 1)], [(0, 0, 1)])[0]
+    assert bits(p)[2] - bits(np.float32(1.0)) == 256 and p[0] == 1 and p[1] == 1
+    q = orc.offset_along_normal([(-1, -1, -1)], [(0, 0, 1)])[0]
+    assert bits(np.float32(-1.0)) - bits(q)[2] == 256      # moves towards +z also for negative coordinates
+
+
+def test_alias_table_golden_and_invariants(orc):
+    d = json.load(open(os.path.join(G, "alias.json")))
+    for name, g in d.items():
+        a, s, tot = orc.build_alias_table(g["weights"])
+        assert a.tolist() == g["alias"], name
+        assert [bytes(b).hex() for b in s.astype(">f4").view(np.uint8).reshape(-1, 4)] == g["select_hex"], name
+        w = np.array(g["weights"], np.float64); n = len(w)
+        # Vose invariant (alias_table.zig:25-92): the table reproduces the input distribution
+        p = np.zeros(n)
+        for i in range(n):
+            sel = min(float(s[i]), 1.0)
+            p[i] += sel / n
+            if sel < 1.0:
+                p[a[i]] += (1.0 - sel) / n
+        assert np.abs(p - w / w.sum()).max() < 1e-5, name
+    a, s, tot = orc.build_alias_table([1, 2, 3, 4])
+    assert tot == 10.0
+
+
+def test_camera_rays(orc):
+    c = np.load(os.path.join(G, "camera.npz"))
+    for key, lens in (("lens0", orc.make_lens((-3, 0, 0), (1, 0, 0), (0, 0, 1), math.pi / 4)), ("lens1", orc.make_lens((0, 0, 0), (1, 0, 0), (0, 0, 1), math.pi / 3))):
+        rows = np.array([orc.generate_ray(lens, 32, 32, u, v) for u in (0.0, 0.5, 1.0) for v in (0.0, 0.5, 1.0)], np.float32)
+        assert np.array_equal(bits(rows), bits(c[key]))
+    centre = orc.generate_ray(orc.make_lens((-3, 0, 0), (1, 0, 0), (0, 0, 1), math.pi / 4), 32, 32, 0.5, 0.5)
+    assert np.allclose(centre, [-3, 0, 0, 1, 0, 0], atol=1e-7)           # camera.hlsl:14-42
+    corner = orc.generate_ray(orc.make_lens((-3, 0, 0), (1, 0, 0), (0, 0, 1), math.pi / 4), 32, 32, 1.0, 1.0)
+    assert abs(math.atan2(corner[5], corner[3]) - math.pi / 8) < 1e-6    # top edge at vfov/2
+
+
+def test_bsdf_golden_and_properties(orc):
+    rows = np.load(os.path.join(G, "bsdf.npy"))
+    for r in rows:
+        t, met, rough = int(r[0]), float(r[1]), float(r[2])
+        out = orc.bsdf_probe(t, (0.9, 0.6, 0.2), met, rough, 1.5, r[3:6], r[6:9], r[9:11])
+        got = np.concatenate([[out["pdf"]], out["eval"], out["dir"], [out["sample_pdf"]]]).astype(np.float32)
+        assert np.array_equal(bits(got), bits(r[11:19]))
+    # Lambert: pdf integrates to 1 over the hemisphere; eval*cos/pdf == albedo (material.hlsl:137-175)
+    wo = np.float32([0.3, -0.2, math.sqrt(1 - 0.13)])
+    n, acc = 200, 0.0
+    for i in range(n):
+        for j in range(4 * n):
+            th, ph = (i + 0.5) / n * math.pi / 2, (j + 0.5) / (4 * n) * 2 * math.pi
+            wi = (math.sin(th) * math.cos(ph), math.sin(th) * math.sin(ph), math.cos(th))
+            acc += orc.bsdf_probe(orc.LAMBERT, (1, 1, 1), 0, 0, 1.5, wi, wo, (0.5, 0.5))["pdf"] * math.sin(th)
+    assert abs(acc * (math.pi / 2 / n) * (2 * math.pi / (4 * n)) - 1.0) < 1e-3
+    rs = np.random.default_rng(5)
+    for _ in range(200):
+        sq = rs.random(2)
+        s = orc.bsdf_probe(orc.LAMBERT, (0.5, 0.25, 1.0), 0, 0, 1.5, (0, 0, 1), wo, sq)
+        e = orc.bsdf_probe(orc.LAMBERT, (0.5, 0.25, 1.0), 0, 0, 1.5, s["dir"], wo, sq)["eval"]
+        assert np.allclose(e * abs(s["dir"][2]) / s["sample_pdf"], [0.5, 0.25, 1.0], rtol=2e-6)
+        # mirror / glass: f*|cos|/pdf == 1 (material.hlsl:313-393)
+        m = orc.bsdf_probe(orc.PERFECT_MIRROR, (1, 1, 1), 0, 0, 1.5, (0, 0, 1), wo, sq)
+        assert np.allclose(m["dir"], [-wo[0], -wo[1], wo[2]]) and m["sample_pdf"] == 1.0
+        g = orc.bsdf_probe(orc.GLASS, (1, 1, 1), 0, 0, 1.5, (0, 0, 1), wo, sq)
+        ge = orc.bsdf_probe(orc.GLASS, (1, 1, 1), 0, 0, 1.5, g["dir"], wo, sq)["eval"]
+        assert np.allclose(ge * abs(g["dir"][2]) / g["sample_pdf"], 1.0, rtol=3e-6)
+        # GGX/StandardPBR: sampled direction has positive pdf equal to pdf(); energy bounded
+        p = orc.bsdf_probe(orc.STANDARD_PBR, (0.9, 0.6, 0.2), 0.7, 0.4, 1.5, (0, 0, 1), wo, sq)
+        pp = orc.bsdf_probe(orc.STANDARD_PBR, (0.9, 0.6, 0.2), 0.7, 0.4, 1.5, p["dir"], wo, sq)
+        if p["dir"][2] > 0:
+            assert abs(pp["pdf"] - p["sample_pdf"]) <= 2e-5 * max(1.0, p["sample_pdf"])   # h is re-derived from wi+wo in pdf()
+            assert np.all(pp["eval"] * abs(p["dir"][2]) / p["sample_pdf"] < 2.5)
+
+
+# ---- the reference's furnace tests on the oracle, at the reference's parameters and tolerances ----
+def test_reference_furnace_white_sphere(orc):
+    c = orc.Context(threads=os.cpu_count())
+    s, l = scenes.furnace_white_sphere(c)
+    c.set_pipeline(samples_per_run=512, max_bounces=1024, env_samples_per_bounce=0, mesh_samples_per_bounce=0)   # tests.zig:330-335
+    c.render(s, l)
+    img = c.sensor_data(s)
+    assert np.all(np.abs(img[..., :3] - 1.0) <= 0.00001)        # tests.zig:339-343
+    c.set_pipeline(samples_per_run=512, max_bounces=1024, env_samples_per_bounce=1, mesh_samples_per_bounce=0)   # tests.zig:347-352
+    c.render(s, l)
+    assert np.all(np.abs(c.sensor_data(s)[..., :3] - 1.0) <= 0.1)   # tests.zig:358-362
+
+
+def test_reference_furnace_inside_sphere(orc):
+    c = orc.Context(threads=os.cpu_count())
+    s, l = scenes.furnace_inside_sphere(c)
+    c.set_pipeline(samples_per_run=1024, max_bounces=1024, env_samples_per_bounce=0, mesh_samples_per_bounce=0)  # tests.zig:440-445
+    c.render(s, l)
+    assert np.all(np.abs(c.sensor_data(s)[..., :3] - 1.0) <= 0.02)  # tests.zig:449-454
+
+
+def test_icosphere_fixture():
+    P, I = scenes.icosphere(5)
+    assert P.shape == (10242, 3) and I.shape == (20480, 3)       # tests.zig:115-247 at order 5
+    assert np.abs(np.linalg.norm(P, axis=1) - 1).max() < 1e-6
+    n = np.cross(P[I[:, 1]] - P[I[:, 0]], P[I[:, 2]] - P[I[:, 0]])
+    assert np.all((n * P[I].mean(1)).sum(1) > 0)                 # outward winding
+    _, Ir = scenes.icosphere(2, True)
+    assert np.array_equal(Ir, scenes.icosphere(2)[1][:, ::-1])
+
+
+def test_golden_films(orc):
+    for name, builder, kw, pipe, launches in (
+            ("furnace_white_16spp", scenes.furnace_white_sphere, {}, dict(samples_per_run=16, max_bounces=1024, env_samples_per_bounce=0, mesh_samples_per_bounce=0), 1),
+            ("furnace_inside_16spp", scenes.furnace_inside_sphere, {}, dict(samples_per_run=16, max_bounces=1024, env_samples_per_bounce=0, mesh_samples_per_bounce=0), 1),
+            ("s1_mini_64x36_4spp", scenes.s1, dict(extent=(64, 36), grid=2, order=2), dict(samples_per_run=1, max_bounces=8, env_samples_per_bounce=1, mesh_samples_per_bounce=1), 4),
+            ("cornell_48_4spp", scenes.cornell, dict(extent=(48, 48)), dict(samples_per_run=2, max_bounces=8, env_samples_per_bounce=0, mesh_samples_per_bounce=1), 2)):
+        c = orc.Context(threads=os.cpu_count())
+        s, l = builder(c, **kw)
+        c.set_pipeline(**pipe)
+        c.render(s, l, launches=launches)
+        assert np.array_equal(bits(c.sensor_data(s)), bits(np.load(os.path.join(G, name + ".npy")))), name
+
+
+def test_env_preprocessing(orc):
+    e = np.load(os.path.join(G, "env_32x16.npz"))
+    c = orc.Context()
+    c.set_background(e["src"], 32, 16)
+    rgb, lum = c.env()
+    assert rgb.shape == (16, 16, 4)                               # S = min(floorPow2(height), 1024), BackgroundManager.zig:154
+    assert np.array_equal(bits(rgb), bits(e["rgb"]))
+    for i, l in enumerate(lum):
+        assert np.array_equal(bits(l), bits(e["lum%d" % i]))
+    # fold.hlsl:6-17 is a 2x2 SUM: the top level is the integral of level 0
+    assert abs(float(lum[-1][0, 0]) - float(lum[0].astype(np.float64).sum())) < 1e-3 * float(lum[-1][0, 0])
+    # luminance.hlsl:7-15
+    assert np.allclose(lum[0], 0.2126 * rgb[..., 0] + 0.7152 * rgb[..., 1] + 0.0722 * rgb[..., 2], rtol=1e-6)
+    # 1x1 constant environment stays exact (tests.zig:313-321)
+    c.set_background(np.float32([0.25, 0.5, 1.0, 1.0]), 1, 1)
+    rgb, lum = c.env()
+    assert rgb.shape == (1, 1, 4) and np.array_equal(rgb[0, 0, :3], np.float32([0.25, 0.5, 1.0]))
+
+
+def test_nee_and_plain_estimators_agree(orc):
+    """light sampling must not change the expectation (integrator.hlsl:108-181): Cornell with and without mesh NEE."""
+    means = []
+    for mesh in (0, 1):
+        c = orc.Context(threads=os.cpu_count())
+        s, l = scenes.cornell(c, extent=(24, 24))
+        c.set_pipeline(samples_per_run=1, max_bounces=6, env_samples_per_bounce=0, mesh_samples_per_bounce=mesh)
+        c.render(s, l, launches=600 if mesh == 0 else 150)
+        means.append(c.sensor_data(s)[..., :3].astype(np.float64).mean())
+    assert abs(means[0] - means[1]) / means[1] < 0.06
+
+
+def test_sample_count_and_clear_rules(orc):
+    c = orc.Context()
+    s, l = scenes.single_triangle(c, extent=(8, 8))
+    c.set_pipeline(samples_per_run=3, max_bounces=1, env_samples_per_bounce=1, mesh_samples_per_bounce=0)
+    c.render(s, l, launches=2)
+    assert c.sample_count(s) == 6 and np.all(c.sensor_data(s)[..., 3] == 2.0)     # alpha counts launches (main.hlsl:46,49)
+    c.set_lens(l, c.make_lens((0, -3, 0), (0, 1, 0), (0, 0, 1), 0.7))             # SetLens clears sensors (hydra.zig:530-540)
+    assert c.sample_count(s) == 0
+    c.render(s, l)
+    assert np.all(c.sensor_data(s)[..., 3] == 1.0)
