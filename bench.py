@@ -69,6 +69,7 @@ def main():
     sensor, lens = scenes.s1(ctx, extent=(a.width, a.height), env=a.env)
     ctx.set_pipeline(samples_per_run=1, max_bounces=8, env_samples_per_bounce=1, mesh_samples_per_bounce=1)
     ctx.set_profiling(kernel_events=True, traversal_counters=False)
+    ctx.reserve(sensor, max(a.steps, a.warmup))   # wavefront state for the whole batch, allocated outside the timed region
     ptr, n4 = ctx.packed_film(sensor)
     gathered = torch.empty(world * n4 * 4, dtype=torch.float32, device="cuda") if rank == 0 else None
 

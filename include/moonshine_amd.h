@@ -190,6 +190,9 @@ int MsneSetBackground(HdMoonshine*, const float* rgba, Extent2D);
 /* `launches` back-to-back HdMoonshineRender-equivalents without host round trips (offline/main.zig:131-165 spp loop);
  * one film readback at the end when `readback` is nonzero.  0 on success. */
 int MsneRender(HdMoonshine*, SensorHandle, LensHandle, uint32_t launches, int readback);
+/* Pre-allocates the wavefront state for MsneRender calls of up to `launches` launches on this sensor (otherwise it is
+ * allocated on first use, inside that call).  Up to $MSNE_MAX_INFLIGHT (default 160 Mi) paths are traced concurrently. */
+int MsneReserve(HdMoonshine*, SensorHandle, uint32_t launches);
 void MsneClearSensor(HdMoonshine*, SensorHandle);                 /* Sensor.clear (core/Sensor.zig:81-83) */
 uint32_t MsneGetSampleCount(const HdMoonshine*, SensorHandle);    /* Sensor.sample_count (core/Sensor.zig:12) */
 
@@ -212,7 +215,7 @@ const char* MsneGetLastError(const HdMoonshine*);   /* NULL ctx → last creatio
 /* kernel_events: bracket every trace/shade launch with HIP events on the render stream (MsneStats *_ms fields);
  * traversal_counters: count BVH node visits / triangle tests inside the trace kernels. */
 void MsneSetProfiling(HdMoonshine*, int kernel_events, int traversal_counters);
-int MsneGetTraversalCounters(HdMoonshine*, uint64_t out[4]); /* closest {nodes,tris}, shadow {nodes,tris} */
+int MsneGetTraversalCounters(HdMoonshine*, uint64_t out[20]); /* [0..3] closest {nodes,tris}, shadow {nodes,tris}; [4..19] wave-cycle profiles */
 /* rays: 7 floats each (origin, direction, tmax); out_ids: 4 per ray {hit, instance, geometry, primitive}; out_tuv: 3 per ray */
 int MsneTraceRays(HdMoonshine*, const float* rays, uint32_t n, int any_hit, uint32_t* out_ids, float* out_tuv);
 uint32_t MsneGetEnvSize(const HdMoonshine*);

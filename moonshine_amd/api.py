@@ -109,6 +109,7 @@ SYMBOLS = [
     ("MsneGetPipeline", C.c_int, [_vp, C.POINTER(MsnePipelineOpts)]),
     ("MsneSetBackground", C.c_int, [_vp, _vp, Extent2D]),
     ("MsneRender", C.c_int, [_vp, _u32, _u32, _u32, C.c_int]),
+    ("MsneReserve", C.c_int, [_vp, _u32, _u32]),
     ("MsneClearSensor", None, [_vp, _u32]),
     ("MsneGetSampleCount", _u32, [_vp, _u32]),
     ("MsneGetShardTileCount", C.c_uint64, [_vp, _u32]),
@@ -270,6 +271,10 @@ class Context:
         if self.L.MsneRender(self.h, sensor, lens, launches, int(readback)) != 0:
             self._err("MsneRender")
 
+    def reserve(self, sensor, launches):
+        if self.L.MsneReserve(self.h, sensor, launches) != 0:
+            self._err("MsneReserve")
+
     def clear_sensor(self, sensor):
         self.L.MsneClearSensor(self.h, sensor)
 
@@ -315,10 +320,13 @@ class Context:
         self.reset_stats()
 
     def traversal_counters(self):
-        out = (C.c_uint64 * 4)()
+        out = (C.c_uint64 * 20)()
         self.L.MsneGetTraversalCounters(self.h, out)
+        names = ("pop", "refill", "vote", "node", "tri", "inst", "node_lane_steps", "iterations")
         return {"closest_node_visits": int(out[0]), "closest_tri_tests": int(out[1]),
-                "shadow_node_visits": int(out[2]), "shadow_tri_tests": int(out[3])}
+                "shadow_node_visits": int(out[2]), "shadow_tri_tests": int(out[3]),
+                "closest_profile": {n: int(out[4 + i]) for i, n in enumerate(names)},
+                "shadow_profile": {n: int(out[12 + i]) for i, n in enumerate(names)}}
 
     def trace_rays(self, rays, any_hit=False):
         r = _f32(rays, (-1, 7))

@@ -11,7 +11,8 @@ CSRC = os.path.join(HERE, "csrc")
 SOURCES = ["context.hip", "bvh_build.hip", "trace.hip", "integrator.hip", "env.hip"]
 LIB = os.path.join(HERE, "libmoonshine_amd.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math", "-Wall", "-Wno-unused-function"]
+EXTRA = os.environ.get("MSNE_CXXFLAGS", "").split()
+FLAGS = EXTRA + ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math", "-Wall", "-Wno-unused-function"]
 
 
 def _stale(out, deps):

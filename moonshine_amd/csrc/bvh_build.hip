@@ -30,7 +30,8 @@ __device__ __forceinline__ uint32_t expand_bits10(uint32_t v) {
 
 // ---------------- primitive boxes ----------------
 // triangles of one BLAS: geometry g -> mesh; prim boxes + source records
-struct BlasGeo { const float* positions; const uint32_t* indices; uint32_t tri_offset, tri_count; };
+// `geo` = geometry index inside its instance; `inst` = owning instance for triangles of the merged world BLAS (else unused)
+struct BlasGeo { const float* positions; const uint32_t* indices; uint32_t tri_offset, tri_count, geo, inst; };
 
 __global__ void k_prim_boxes_tris(const BlasGeo* geos, uint32_t ngeo, uint32_t n, Box* boxes) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -301,7 +302,7 @@ __global__ void k_emit_tris(const BlasGeo* geos, uint32_t ngeo, const uint32_t* 
     r.v0x = P[3 * (size_t)i0]; r.v0y = P[3 * (size_t)i0 + 1]; r.v0z = P[3 * (size_t)i0 + 2];
     r.v1x = P[3 * (size_t)i1]; r.v1y = P[3 * (size_t)i1 + 1]; r.v1z = P[3 * (size_t)i1 + 2];
     r.v2x = P[3 * (size_t)i2]; r.v2y = P[3 * (size_t)i2 + 1]; r.v2z = P[3 * (size_t)i2 + 2];
-    r.geo = g; r.prim = p; r.pad = 0;
+    r.geo = ge.geo; r.prim = p; r.pad = ge.inst;
     tris[item_begin + i] = r;
 }
 __global__ void k_emit_items(const uint32_t* item_src, uint32_t item_begin, uint32_t n, const uint32_t* ids, uint32_t* out) {

@@ -18,17 +18,18 @@
 
 namespace msne {
 // kernels' host wrappers (trace.hip, integrator.hip, env.hip, bvh_build.hip)
-void launch_trace_closest(hipStream_t, int, bool, const SceneView&, const PathState&, const HitBuf&, Counters*, uint32_t*, uint32_t*, unsigned long long*);
-void launch_trace_shadow(hipStream_t, int, bool, const SceneView&, const ShadowQueue&, const PathState&, Counters*, uint32_t*, uint32_t*, unsigned long long*);
-void launch_trace_probe(hipStream_t, int, const SceneView&, const float*, uint32_t, int, uint32_t*, uint32_t*, float*, uint32_t*, uint32_t*);
+void launch_trace_closest(hipStream_t, int, bool, const SceneView&, const PathState&, const HitBuf&, Counters*, uint32_t*, uint32_t*, unsigned long long*, const uint32_t[4]);
+void launch_trace_shadow(hipStream_t, int, bool, const SceneView&, const ShadowQueue&, const PathState&, Counters*, uint32_t*, uint32_t*, unsigned long long*, const uint32_t[4]);
+void launch_trace_probe(hipStream_t, int, const SceneView&, const float*, uint32_t, int, uint32_t*, uint32_t*, float*, uint32_t*, uint32_t*, const uint32_t[4]);
 size_t trace_spill_words(int grid);
+int trace_blocks_per_cu();
 void launch_raygen(hipStream_t, int, const ShardView&, const CameraConsts&, const PipelineOpts&, uint32_t, uint32_t, const PathState&, Counters*);
 void launch_shade(hipStream_t, int, const SceneView&, const PipelineOpts&, const PathState&, const HitBuf&, const PathState&, const ShadowQueue&, float4*, Counters*);
-void launch_advance(hipStream_t, Counters*, int);
-void launch_film(hipStream_t, int, const ShardView&, const PipelineOpts&, const float4*, uint32_t, int, int, uint32_t, float4*, float4*);
+void launch_advance(hipStream_t, Counters*, int, uint32_t, uint32_t);
+void launch_film(hipStream_t, int, const ShardView&, const PipelineOpts&, const float4*, uint32_t, uint32_t, int, int, uint32_t, float4*, float4*);
 void launch_unpack_film(hipStream_t, int, const ShardView&, const float4*, uint32_t, uint32_t, size_t, float4*);
 void launch_env_build(hipStream_t, const float4*, uint32_t, uint32_t, float4*, float*, const uint32_t*, uint32_t, uint32_t);
-struct BlasGeo { const float* positions; const uint32_t* indices; uint32_t tri_offset, tri_count; };
+struct BlasGeo { const float* positions; const uint32_t* indices; uint32_t tri_offset, tri_count, geo, inst; };
 bool bvh_build_blas(hipStream_t, const std::vector<BlasGeo>&, uint32_t, Node8*, uint32_t*, uint32_t, TriRec*, uint32_t*, uint32_t*, uint32_t*, float[6]);
 bool bvh_build_tlas(hipStream_t, const float*, const uint32_t*, uint32_t, Node8*, uint32_t*, uint32_t, uint32_t*, uint32_t*, uint32_t*, uint32_t*);
 void bvh_release_scratch();
@@ -113,7 +114,7 @@ struct HdMoonshine {
     DevBuf<uint32_t> d_build_counters;    // [0] node count, [1] tri count, [2] tlas item count
     uint32_t blas_nodes_end = 0, blas_tris_end = 0;
     std::map<std::vector<uint32_t>, BlasInfo> blas_cache;
-    uint32_t tlas_root = MAX_UINT;
+    uint32_t tlas_root = MAX_UINT, root_in_blas = 0;
     std::vector<AliasEntry> h_alias;
     // environment
     DevBuf<float4> d_env_rgb; DevBuf<float> d_env_lum; EnvView env{};
@@ -126,7 +127,8 @@ struct HdMoonshine {
     DevBuf<Counters> d_counters;
     DevBuf<uint32_t> d_spill; DevBuf<uint32_t> d_overflow; DevBuf<unsigned long long> d_trace_stats;
     int trace_grid = 1024, shade_grid = 2048;
-    size_t max_inflight = 4u << 20;
+    uint32_t tune[4] = { 16, 24, 24, 8 };   // traversal: lane-refill threshold, phase-vote thresholds (node, triangle, instance); $MSNE_TUNE=a,b,c,d
+    size_t max_inflight = 160u << 20;  // most paths traced concurrently (276 B of wavefront state each, allocated on demand); $MSNE_MAX_INFLIGHT
     // statistics
     MsneStats stats{};
     bool profile = false, trace_stats = false;
@@ -265,19 +267,35 @@ bool HdMoonshine::rebuild_accel() {
     if (!mrec.empty()) CHECK_HIP(this, hipMemcpyAsync(d_meshes.p, mrec.data(), mrec.size() * sizeof(MeshRec), hipMemcpyHostToDevice, stream));
     if (!geos.empty()) CHECK_HIP(this, hipMemcpyAsync(d_geometries.p, geos.data(), geos.size() * sizeof(GeometryRec), hipMemcpyHostToDevice, stream));
 
-    // BLAS per unique mesh list (Accel.zig:315-343); cached across rebuilds
-    std::vector<std::vector<uint32_t>> keys(instances.size());
+    // BLAS per unique mesh list (Accel.zig:315-343), cached across rebuilds — except that all visible
+    // identity-transform instances are merged into ONE world-space BLAS (msne_device.h WORLD_INSTANCE): static
+    // geometry then needs no TLAS hop, no ray transform and no per-instance root visits.
+    const size_t N = instances.size();
+    std::vector<std::vector<uint32_t>> keys(N);
+    std::vector<char> in_world(N, 0);
+    std::vector<uint32_t> world_key;
+    for (size_t i = 0; i < N; i++) {
+        uint32_t ntri = 0;
+        for (auto& g : instances[i].geos) { keys[i].push_back(g.mesh); ntri += meshes[g.mesh]->index_count; }
+        if (instances[i].visible && ntri && is_identity(instances[i].transform)) {
+            in_world[i] = 1;
+            world_key.push_back(0xFFFFFFFFu); world_key.push_back((uint32_t)i);
+            world_key.insert(world_key.end(), keys[i].begin(), keys[i].end());
+        }
+    }
     size_t new_tris = 0;
     {
         std::map<std::vector<uint32_t>, bool> seen;
-        for (size_t i = 0; i < instances.size(); i++) {
-            for (auto& g : instances[i].geos) keys[i].push_back(g.mesh);
+        for (size_t i = 0; i < N; i++) {
+            if (in_world[i]) continue;
             if (!blas_cache.count(keys[i]) && !seen.count(keys[i])) { seen[keys[i]] = true; for (uint32_t m : keys[i]) new_tris += meshes[m]->index_count; }
         }
+        if (!world_key.empty() && !blas_cache.count(world_key))
+            for (size_t i = 0; i < N; i++) if (in_world[i]) for (uint32_t m : keys[i]) new_tris += meshes[m]->index_count;
     }
     if (!d_build_counters.p) { if (!d_build_counters.alloc(4)) { fail("out of device memory"); return false; } CHECK_HIP(this, hipMemsetAsync(d_build_counters.p, 0, 16, stream)); }
     const size_t need_tris = (size_t)blas_tris_end + new_tris;
-    const size_t need_nodes = (size_t)blas_nodes_end + new_tris + 2 * instances.size() + 64;
+    const size_t need_nodes = (size_t)blas_nodes_end + new_tris + 2 * N + 64;
     if (need_tris > d_tris.n || !d_tris.p) {
         DevBuf<TriRec> nt; if (!nt.alloc(need_tris + need_tris / 4 + 16)) { fail("out of device memory (triangles)"); return false; }
         if (blas_tris_end) CHECK_HIP(this, hipMemcpyAsync(nt.p, d_tris.p, (size_t)blas_tris_end * sizeof(TriRec), hipMemcpyDeviceToDevice, stream));
@@ -290,46 +308,77 @@ bool HdMoonshine::rebuild_accel() {
         CHECK_HIP(this, hipStreamSynchronize(stream));
         std::swap(nn.p, d_nodes.p); std::swap(nn.n, d_nodes.n);
     }
-    if (!d_item_src.ensure(std::max(d_tris.n, instances.size() + 1)) || !d_tlas_items.ensure(instances.size() + 1)) { fail("out of device memory (items)"); return false; }
+    if (!d_item_src.ensure(std::max(d_tris.n, N + 2)) || !d_tlas_items.ensure(N + 2)) { fail("out of device memory (items)"); return false; }
     // counters: node count resumes after the BLAS region (the previous TLAS is discarded)
     { uint32_t c[4] = { blas_nodes_end, blas_tris_end, 0u, 0u }; CHECK_HIP(this, hipMemcpyAsync(d_build_counters.p, c, 16, hipMemcpyHostToDevice, stream)); CHECK_HIP(this, hipStreamSynchronize(stream)); }
-    for (size_t i = 0; i < instances.size(); i++) {
-        if (blas_cache.count(keys[i])) continue;
-        std::vector<BlasGeo> bg; uint32_t off = 0;
-        for (uint32_t m : keys[i]) { bg.push_back(BlasGeo{ meshes[m]->positions.p, meshes[m]->indices.p, off, meshes[m]->index_count }); off += meshes[m]->index_count; }
+    for (size_t i = 0; i < N; i++) {
+        if (in_world[i] || blas_cache.count(keys[i])) continue;
+        std::vector<BlasGeo> bg; uint32_t off = 0, g = 0;
+        for (uint32_t m : keys[i]) { bg.push_back(BlasGeo{ meshes[m]->positions.p, meshes[m]->indices.p, off, meshes[m]->index_count, g++, 0u }); off += meshes[m]->index_count; }
         BlasInfo info{}; info.tris = off;
         if (!bvh_build_blas(stream, bg, off, d_nodes.p, d_build_counters.p, (uint32_t)d_nodes.n, d_tris.p, d_build_counters.p + 1, d_item_src.p, &info.root, info.box)) { fail("BLAS build failed"); return false; }
         blas_cache[keys[i]] = info;
     }
+    if (!world_key.empty() && !blas_cache.count(world_key)) {
+        std::vector<BlasGeo> bg; uint32_t off = 0;
+        for (size_t i = 0; i < N; i++) {
+            if (!in_world[i]) continue;
+            uint32_t g = 0;
+            for (uint32_t m : keys[i]) { bg.push_back(BlasGeo{ meshes[m]->positions.p, meshes[m]->indices.p, off, meshes[m]->index_count, g++, (uint32_t)i }); off += meshes[m]->index_count; }
+        }
+        BlasInfo info{}; info.tris = off;
+        if (!bvh_build_blas(stream, bg, off, d_nodes.p, d_build_counters.p, (uint32_t)d_nodes.n, d_tris.p, d_build_counters.p + 1, d_item_src.p, &info.root, info.box)) { fail("world BLAS build failed"); return false; }
+        blas_cache[world_key] = info;
+    }
     { uint32_t c[2]; CHECK_HIP(this, hipMemcpy(c, d_build_counters.p, 8, hipMemcpyDeviceToHost)); blas_nodes_end = c[0]; blas_tris_end = c[1]; }
 
-    // instance records + TLAS over visible, non-empty instances (Accel.zig:394-484)
-    std::vector<InstanceRec> irec(instances.size());
+    // instance records + TLAS over the transformed visible instances and the world pseudo-instance (Accel.zig:394-484)
+    std::vector<InstanceRec> irec(N + 1);
     std::vector<float> boxes; std::vector<uint32_t> ids;
-    for (size_t i = 0; i < instances.size(); i++) {
-        const BlasInfo& bi = blas_cache[keys[i]];
-        InstanceRec& r = irec[i];
-        r.transform = instances[i].transform;
-        r.world_to_instance = m34_inverse_affine(instances[i].transform);   // Accel.zig:430-432
-        r.geo_offset = geo_offset[i]; r.blas_root = bi.root;
-        r.flags = (instances[i].visible ? 1u : 0u) | (is_identity(instances[i].transform) ? 2u : 0u); r.pad = 0;
-        if (!instances[i].visible || bi.root == MAX_UINT) continue;
+    auto add_box = [&](const m34& T, const float box[6], uint32_t id) {
         float lo[3] = { 3e38f, 3e38f, 3e38f }, hi[3] = { -3e38f, -3e38f, -3e38f };
         for (int k = 0; k < 8; k++) {
-            const f3 p = F3((k & 1) ? bi.box[3] : bi.box[0], (k & 2) ? bi.box[4] : bi.box[1], (k & 4) ? bi.box[5] : bi.box[2]);
-            const f3 q = m34_mul_point(instances[i].transform, p);
+            const f3 p = F3((k & 1) ? box[3] : box[0], (k & 2) ? box[4] : box[1], (k & 4) ? box[5] : box[2]);
+            const f3 q = m34_mul_point(T, p);
             lo[0] = std::min(lo[0], q.x); lo[1] = std::min(lo[1], q.y); lo[2] = std::min(lo[2], q.z);
             hi[0] = std::max(hi[0], q.x); hi[1] = std::max(hi[1], q.y); hi[2] = std::max(hi[2], q.z);
         }
         float pad = 1e-30f;
         for (int k = 0; k < 3; k++) pad += 1e-6f * (fabsf(hi[k] - lo[k]) + fabsf(hi[k]) + fabsf(lo[k]));
-        for (int k = 0; k < 3; k++) { boxes.push_back(lo[k] - pad); }
-        for (int k = 0; k < 3; k++) { boxes.push_back(hi[k] + pad); }
-        ids.push_back((uint32_t)i);
+        for (int k = 0; k < 3; k++) boxes.push_back(lo[k] - pad);
+        for (int k = 0; k < 3; k++) boxes.push_back(hi[k] + pad);
+        ids.push_back(id);
+    };
+    for (size_t i = 0; i < N; i++) {
+        InstanceRec& r = irec[i];
+        r.transform = instances[i].transform;
+        r.world_to_instance = m34_inverse_affine(instances[i].transform);   // Accel.zig:430-432
+        r.geo_offset = geo_offset[i]; r.pad = 0;
+        r.flags = (instances[i].visible ? INST_FLAG_VISIBLE : 0u) | (is_identity(instances[i].transform) ? INST_FLAG_IDENTITY : 0u);
+        r.blas_root = MAX_UINT;
+        if (in_world[i]) continue;
+        const BlasInfo& bi = blas_cache[keys[i]];
+        r.blas_root = bi.root;
+        if (!instances[i].visible || bi.root == MAX_UINT) continue;
+        add_box(instances[i].transform, bi.box, (uint32_t)i);
+    }
+    m34 ident; for (int r = 0; r < 3; r++) for (int c = 0; c < 4; c++) ident.m[r][c] = r == c ? 1.0f : 0.0f;
+    {
+        InstanceRec& w = irec[N];
+        w.transform = ident; w.world_to_instance = ident; w.geo_offset = 0; w.pad = 0; w.blas_root = MAX_UINT; w.flags = 0;
+        if (!world_key.empty()) {
+            const BlasInfo& bi = blas_cache[world_key];
+            w.blas_root = bi.root; w.flags = INST_FLAG_VISIBLE | INST_FLAG_IDENTITY | INST_FLAG_WORLD;
+            add_box(ident, bi.box, (uint32_t)N);
+        }
     }
     if (!d_instances.alloc(irec.size())) { fail("out of device memory (instances)"); return false; }
-    if (!irec.empty()) CHECK_HIP(this, hipMemcpyAsync(d_instances.p, irec.data(), irec.size() * sizeof(InstanceRec), hipMemcpyHostToDevice, stream));
-    if (!bvh_build_tlas(stream, boxes.data(), ids.data(), (uint32_t)ids.size(), d_nodes.p, d_build_counters.p, (uint32_t)d_nodes.n, d_tlas_items.p, d_build_counters.p + 2, d_item_src.p, &tlas_root)) { fail("TLAS build failed"); return false; }
+    CHECK_HIP(this, hipMemcpyAsync(d_instances.p, irec.data(), irec.size() * sizeof(InstanceRec), hipMemcpyHostToDevice, stream));
+    root_in_blas = 0;
+    if (ids.size() == 1 && ids[0] == (uint32_t)N) {
+        tlas_root = irec[N].blas_root; root_in_blas = 1;     // nothing but static geometry: traversal starts inside the world BLAS
+        const uint32_t zero = 0; CHECK_HIP(this, hipMemcpyAsync(d_build_counters.p + 2, &zero, 4, hipMemcpyHostToDevice, stream));
+    } else if (!bvh_build_tlas(stream, boxes.data(), ids.data(), (uint32_t)ids.size(), d_nodes.p, d_build_counters.p, (uint32_t)d_nodes.n, d_tlas_items.p, d_build_counters.p + 2, d_item_src.p, &tlas_root)) { fail("TLAS build failed"); return false; }
 
     // emissive-triangle alias table (Accel.zig:491-539): entry 0 = {count, sum of areas}
     std::vector<float> w; h_alias.assign(1, AliasEntry{ 0u, 0.0f, 0u, 0u, 0u });
@@ -368,7 +417,7 @@ SceneView HdMoonshine::scene_view() const {
     SceneView v{};
     v.nodes = d_nodes.p; v.tris = d_tris.p; v.tlas_items = d_tlas_items.p; v.instances = d_instances.p; v.geometries = d_geometries.p;
     v.meshes = d_meshes.p; v.materials = d_materials.p; v.textures = d_texdesc.p; v.texels = d_texels.p; v.alias = d_alias.p;
-    v.env = env; v.tlas_root = tlas_root;
+    v.env = env; v.tlas_root = tlas_root; v.root_in_blas = root_in_blas;
     return v;
 }
 
@@ -402,8 +451,8 @@ bool HdMoonshine::ensure_wavefront(size_t npaths, size_t slots) {
     if (slots > lbuf_cap) { if (!d_lbuf.alloc(slots)) { fail("out of device memory (sample buffer)"); lbuf_cap = 0; return false; } lbuf_cap = slots; }
     if (!d_counters.p) { if (!d_counters.alloc(1)) return false; if (hipMemsetAsync(d_counters.p, 0, sizeof(Counters), stream) != hipSuccess) return false; }
     if (!d_spill.p) {
-        if (!d_spill.alloc(trace_spill_words(trace_grid)) || !d_overflow.alloc(1) || !d_trace_stats.alloc(4)) { fail("out of device memory (traversal spill)"); return false; }
-        if (hipMemsetAsync(d_overflow.p, 0, 4, stream) != hipSuccess || hipMemsetAsync(d_trace_stats.p, 0, 32, stream) != hipSuccess) return false;
+        if (!d_spill.alloc(trace_spill_words(trace_grid)) || !d_overflow.alloc(1) || !d_trace_stats.alloc(20)) { fail("out of device memory (traversal spill)"); return false; }
+        if (hipMemsetAsync(d_overflow.p, 0, 4, stream) != hipSuccess || hipMemsetAsync(d_trace_stats.p, 0, 160, stream) != hipSuccess) return false;
     }
     return true;
 }
@@ -440,8 +489,13 @@ bool HdMoonshine::render(uint32_t sensor, uint32_t lens, uint32_t launches, bool
     const size_t P = s->shard.pixels;
     const uint32_t spr = opts.samples_per_run;
     if (P == 0 || spr == 0) { if (do_readback) return readback(s); return true; }
-    const uint32_t chunk = (uint32_t)std::max<size_t>(1, std::min<size_t>(spr, max_inflight / P));
-    if (!ensure_wavefront(P * chunk, P * chunk)) return false;
+    // how many samples are traced concurrently: whole launches are batched (nb launches in flight, folded into the
+    // film in launch order by k_film — bit-identical to nb sequential dispatches, because the RNG is keyed by the sample
+    // index, main.hlsl:85); a launch too large for the in-flight budget is split into chunks of its samples instead.
+    const size_t per_launch = P * (size_t)spr;
+    const uint32_t max_batch = per_launch <= max_inflight ? (uint32_t)std::max<size_t>(1, max_inflight / per_launch) : 1u;
+    const uint32_t chunk = per_launch <= max_inflight ? spr : (uint32_t)std::max<size_t>(1, max_inflight / P);
+    if (!ensure_wavefront(P * (size_t)chunk * std::min<uint32_t>(max_batch, launches), P * (size_t)chunk * std::min<uint32_t>(max_batch, launches))) return false;
     const SceneView sv = scene_view();
     const CameraConsts cam = make_camera(lenses[lens], s->extent.width, s->extent.height);
     HitBuf hits{ d_hit_u.p, d_hit_u.p + wf_cap, d_hit_u.p + 2 * wf_cap, d_hit_f.p, d_hit_f.p + wf_cap };
@@ -462,29 +516,42 @@ bool HdMoonshine::render(uint32_t sensor, uint32_t lens, uint32_t launches, bool
         spans.push_back(Span{ ia, ib, kind });
     };
     const uint32_t max_iter = opts.max_bounces + 3;   // hits b = 0..max_bounces+1, + one pass to retire zombies
-    for (uint32_t l = 0; l < launches; l++) {
-        for (uint32_t s0 = 0; s0 < spr; s0 += chunk) {
-            const uint32_t sc = std::min(chunk, spr - s0);
-            CHECK_HIP(this, hipMemsetAsync(d_counters.p, 0, 32, stream));   // queue counts + heads
-            launch_raygen(stream, shade_grid, s->shard, cam, opts, s->sample_count + s0, sc, st[0], d_counters.p);
-            launch_advance(stream, d_counters.p, 1);
-            for (uint32_t b = 0; b < max_iter; b++) {
-                const PathState& cur = st[b & 1]; const PathState& nxt = st[(b + 1) & 1];
-                timed(0, [&] { launch_trace_closest(stream, trace_grid, trace_stats, sv, cur, hits, d_counters.p, d_spill.p, d_overflow.p, d_trace_stats.p); });
-                timed(2, [&] { launch_shade(stream, shade_grid, sv, opts, cur, hits, nxt, shq, d_lbuf.p, d_counters.p); });
-                timed(1, [&] { launch_trace_shadow(stream, trace_grid, trace_stats, sv, shq, nxt, d_counters.p, d_spill.p, d_overflow.p, d_trace_stats.p); });
-                launch_advance(stream, d_counters.p, 0);
-                if (b >= 15 && (b & 3) == 3) {   // long tails (max_bounces = 1024 offline): poll the queue length every 4 bounces
-                    uint32_t n_cur = 0;
-                    CHECK_HIP(this, hipMemcpyAsync(&n_cur, &d_counters.p->n_cur, 4, hipMemcpyDeviceToHost, stream));
-                    CHECK_HIP(this, hipStreamSynchronize(stream));
-                    if (n_cur == 0) break;
-                }
+    // one wavefront pass over `ns` samples per pixel starting at sample index `first_sample`
+    auto trace_pass = [&](uint32_t first_sample, uint32_t ns) -> bool {
+        CHECK_HIP(this, hipMemsetAsync(d_counters.p, 0, 32, stream));   // queue counts + heads
+        launch_raygen(stream, shade_grid, s->shard, cam, opts, first_sample, ns, st[0], d_counters.p);
+        launch_advance(stream, d_counters.p, 1, ns * s->shard.pixels, ns * (s->shard.pixels - s->shard.valid_pixels));
+        for (uint32_t b = 0; b < max_iter; b++) {
+            const PathState& cur = st[b & 1]; const PathState& nxt = st[(b + 1) & 1];
+            timed(0, [&] { launch_trace_closest(stream, trace_grid, trace_stats, sv, cur, hits, d_counters.p, d_spill.p, d_overflow.p, d_trace_stats.p, tune); });
+            timed(2, [&] { launch_shade(stream, shade_grid, sv, opts, cur, hits, nxt, shq, d_lbuf.p, d_counters.p); });
+            timed(1, [&] { launch_trace_shadow(stream, trace_grid, trace_stats, sv, shq, nxt, d_counters.p, d_spill.p, d_overflow.p, d_trace_stats.p, tune); });
+            launch_advance(stream, d_counters.p, 0, 0, 0);
+            if (b >= 15 && (b & 3) == 3) {   // long tails (max_bounces = 1024 offline): poll the queue length every 4 bounces
+                uint32_t n_cur = 0;
+                CHECK_HIP(this, hipMemcpyAsync(&n_cur, &d_counters.p->n_cur, 4, hipMemcpyDeviceToHost, stream));
+                CHECK_HIP(this, hipStreamSynchronize(stream));
+                if (n_cur == 0) break;
             }
-            launch_film(stream, shade_grid, s->shard, opts, d_lbuf.p, sc, s0 == 0, s0 + sc == spr, s->sample_count, s->color.p, s->film_packed.p);
         }
-        s->sample_count += spr;   // hydra.zig:360
-        stats.launches++;
+        return true;
+    };
+    for (uint32_t l = 0; l < launches;) {
+        if (chunk == spr) {
+            const uint32_t nb = std::min(max_batch, launches - l);
+            if (!trace_pass(s->sample_count, nb * spr)) return false;
+            launch_film(stream, shade_grid, s->shard, opts, d_lbuf.p, spr, nb, 1, 1, s->sample_count, s->color.p, s->film_packed.p);
+            s->sample_count += nb * spr;   // hydra.zig:360, nb times
+            stats.launches += nb; l += nb;
+        } else {
+            for (uint32_t s0 = 0; s0 < spr; s0 += chunk) {
+                const uint32_t sc = std::min(chunk, spr - s0);
+                if (!trace_pass(s->sample_count + s0, sc)) return false;
+                launch_film(stream, shade_grid, s->shard, opts, d_lbuf.p, sc, 1, s0 == 0, s0 + sc == spr, s->sample_count, s->color.p, s->film_packed.p);
+            }
+            s->sample_count += spr;
+            stats.launches++; l++;
+        }
     }
     if (ev_end) (void)hipEventRecord(ev_end, stream);
     if (do_readback) { if (!readback(s)) return false; }
@@ -533,8 +600,10 @@ HdMoonshine* MsneCreate(const MsneConfig* cfg_in) {
     c->device = dev; c->cfg = cfg;
     if (hipSetDevice(dev) != hipSuccess || hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { g_create_error = "cannot create HIP stream"; delete c; return nullptr; }
     hipDeviceProp_t prop;
-    if (hipGetDeviceProperties(&prop, dev) == hipSuccess) { c->trace_grid = prop.multiProcessorCount * 4; c->shade_grid = prop.multiProcessorCount * 8; }
+    if (hipGetDeviceProperties(&prop, dev) == hipSuccess) { c->trace_grid = prop.multiProcessorCount * trace_blocks_per_cu(); c->shade_grid = prop.multiProcessorCount * 8; }
     if (const char* e = getenv("MSNE_MAX_INFLIGHT")) c->max_inflight = (size_t)atoll(e);
+    if (const char* e = getenv("MSNE_TUNE")) { unsigned a, b, d, f; if (sscanf(e, "%u,%u,%u,%u", &a, &b, &d, &f) == 4) { c->tune[0] = a; c->tune[1] = b; c->tune[2] = d; c->tune[3] = f; } }
+    if (const char* e = getenv("MSNE_TRACE_BLOCKS_PER_CU")) c->trace_grid = prop.multiProcessorCount * atoi(e);
     c->opts = PipelineOpts{ 1, 1024, 0, 0, 0, 0, 0 };                 // hydra.zig:97-105
     const float white[4] = { 1.0f, 1.0f, 1.0f, 1.0f };
     if (!c->set_background(white, Extent2D{ 1, 1 })) { g_create_error = c->last_error; delete c; return nullptr; }   // addDefaultBackground
@@ -649,6 +718,11 @@ SensorHandle HdMoonshineCreateSensor(HdMoonshine* c, Extent2D e) {
     const uint32_t total = sh.tiles_x * sh.tiles_y;
     sh.local_tiles = total > sh.shard_index ? (total - sh.shard_index + sh.shard_count - 1) / sh.shard_count : 0;
     sh.pixels = sh.local_tiles * sh.tile_size * sh.tile_size;
+    sh.valid_pixels = 0;
+    for (uint32_t k = 0; k < sh.local_tiles; k++) {
+        const uint32_t t = sh.shard_index + k * sh.shard_count, x0 = (t % sh.tiles_x) * sh.tile_size, y0 = (t / sh.tiles_x) * sh.tile_size;
+        sh.valid_pixels += std::min(sh.tile_size, e.width - x0) * std::min(sh.tile_size, e.height - y0);
+    }
     const size_t npix = (size_t)e.width * e.height;
     // the packed film is padded to the largest shard so that gathers move equal-sized buffers
     const size_t padded = (size_t)((total + sh.shard_count - 1) / sh.shard_count) * sh.tile_size * sh.tile_size;
@@ -666,6 +740,15 @@ void HdMoonshineSetLens(HdMoonshine* c, LensHandle h, Lens l) { LOCK(c); if (h >
 void MsneClearSensor(HdMoonshine* c, SensorHandle s) { LOCK(c); if (s < c->sensors.size()) c->sensors[s]->sample_count = 0; }
 uint32_t MsneGetSampleCount(const HdMoonshine* c, SensorHandle s) { return s < c->sensors.size() ? c->sensors[s]->sample_count : 0; }
 
+int MsneReserve(HdMoonshine* c, SensorHandle sh, uint32_t launches) {
+    LOCK(c);
+    if (!c->bind() || sh >= c->sensors.size()) return -1;
+    const size_t P = c->sensors[sh]->shard.pixels, per_launch = P * (size_t)c->opts.samples_per_run;
+    if (per_launch == 0) return 0;
+    const size_t nb = per_launch <= c->max_inflight ? std::min<size_t>(std::max<size_t>(1, c->max_inflight / per_launch), std::max<uint32_t>(launches, 1)) : 1;
+    const size_t n = per_launch <= c->max_inflight ? per_launch * nb : P * std::max<size_t>(1, c->max_inflight / P);
+    return c->ensure_wavefront(n, n) ? 0 : -1;
+}
 int MsneRender(HdMoonshine* c, SensorHandle s, LensHandle l, uint32_t launches, int readback) {
     LOCK(c);
     if (!c->bind()) return -1;
@@ -704,17 +787,17 @@ void MsneResetStats(HdMoonshine* c) {
     if (!c->bind()) return;
     c->stats = MsneStats{};
     if (c->d_counters.p) (void)hipMemset(c->d_counters.p, 0, sizeof(Counters));
-    if (c->d_trace_stats.p) (void)hipMemset(c->d_trace_stats.p, 0, 32);
+    if (c->d_trace_stats.p) (void)hipMemset(c->d_trace_stats.p, 0, 160);
 }
 
 // ---- diagnostics used by the parity tests (no reference equivalent) ----
 void MsneSetProfiling(HdMoonshine* c, int kernel_events, int traversal_counters) { LOCK(c); c->profile = kernel_events != 0; c->trace_stats = traversal_counters != 0; }
-int MsneGetTraversalCounters(HdMoonshine* c, uint64_t out[4]) {   // closest {node visits, tri tests}, shadow {node visits, tri tests}
+int MsneGetTraversalCounters(HdMoonshine* c, uint64_t out[20]) {   // [0..3] closest {node visits, tri tests}, shadow {..}; [4..11] closest wave-cycle profile, [12..19] shadow
     LOCK(c);
-    if (!c->bind() || !c->d_trace_stats.p) { for (int i = 0; i < 4; i++) out[i] = 0; return 0; }
-    unsigned long long h[4];
-    if (hipMemcpy(h, c->d_trace_stats.p, 32, hipMemcpyDeviceToHost) != hipSuccess) return -1;
-    for (int i = 0; i < 4; i++) out[i] = h[i];
+    if (!c->bind() || !c->d_trace_stats.p) { for (int i = 0; i < 20; i++) out[i] = 0; return 0; }
+    unsigned long long h[20];
+    if (hipMemcpy(h, c->d_trace_stats.p, 160, hipMemcpyDeviceToHost) != hipSuccess) return -1;
+    for (int i = 0; i < 20; i++) out[i] = h[i];
     return 0;
 }
 // rays: 7 floats each (origin, direction, tmax); out_ids 4 per ray {hit, instance, geometry, primitive}; out_tuv 3 per ray
@@ -726,7 +809,7 @@ int MsneTraceRays(HdMoonshine* c, const float* rays, uint32_t n, int any_hit, ui
     if (!dr.alloc(7 * (size_t)n) || !di.alloc(4 * (size_t)n) || !dt.alloc(3 * (size_t)n)) { c->fail("out of device memory (probe)"); return -1; }
     if (hipMemcpyAsync(dr.p, rays, 28 * (size_t)n, hipMemcpyHostToDevice, c->stream) != hipSuccess) return -1;
     if (hipMemsetAsync(&c->d_counters.p->head_closest, 0, 4, c->stream) != hipSuccess) return -1;
-    launch_trace_probe(c->stream, c->trace_grid, c->scene_view(), dr.p, n, any_hit, &c->d_counters.p->head_closest, di.p, dt.p, c->d_spill.p, c->d_overflow.p);
+    launch_trace_probe(c->stream, c->trace_grid, c->scene_view(), dr.p, n, any_hit, &c->d_counters.p->head_closest, di.p, dt.p, c->d_spill.p, c->d_overflow.p, c->tune);
     if (hipMemcpyAsync(out_ids, di.p, 16 * (size_t)n, hipMemcpyDeviceToHost, c->stream) != hipSuccess) return -1;
     if (hipMemcpyAsync(out_tuv, dt.p, 12 * (size_t)n, hipMemcpyDeviceToHost, c->stream) != hipSuccess) return -1;
     if (hipStreamSynchronize(c->stream) != hipSuccess) { c->fail("probe failed"); return -1; }

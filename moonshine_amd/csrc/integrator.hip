@@ -36,12 +36,13 @@ __device__ __forceinline__ bool shard_pixel(const ShardView& sh, uint32_t p, uin
 
 __global__ __launch_bounds__(SHADE_BLOCK) void k_raygen(ShardView sh, CameraConsts cam, PipelineOpts opts, uint32_t sample_base, uint32_t s_count,
                                                           PathState st, Counters* cnt) {
+    // queue index = slot (no compaction, no atomics: one device-scope counter would cap this kernel at ~88 waves/us);
+    // the few slots of edge tiles that fall outside the image are flagged and dropped by the first k_shade
     const uint32_t total = s_count * sh.pixels;
-    for (uint32_t slot = blockIdx.x * SHADE_BLOCK + threadIdx.x; slot < ((total + 63u) & ~63u); slot += gridDim.x * SHADE_BLOCK) {
+    for (uint32_t slot = blockIdx.x * SHADE_BLOCK + threadIdx.x; slot < total; slot += gridDim.x * SHADE_BLOCK) {
         uint32_t x = 0, y = 0;
-        const bool active = slot < total && shard_pixel(sh, slot % sh.pixels, x, y);
-        const uint32_t i = wave_append(&cnt->n_cur, active);
-        if (!active) continue;
+        const uint32_t i = slot;
+        if (!shard_pixel(sh, slot % sh.pixels, x, y)) { st.flags[i] = PATH_FLAG_ZOMBIE | PATH_FLAG_MASKED; st.slot[i] = slot; continue; }
         const uint32_t s_local = slot / sh.pixels;
         uint32_t rng = rng_seed(sample_base + s_local, x, y);                       // main.hlsl:85
         f2 r1; r1.x = rng_float(rng); r1.y = rng_float(rng);
@@ -87,9 +88,13 @@ __global__ __launch_bounds__(SHADE_BLOCK) void k_shade(SceneView sc, PipelineOpt
                                                          float4* lbuf, Counters* cnt) {
     const uint32_t n = cnt->n_cur;
     const uint32_t max_bounces = opts.max_bounces, env_n = opts.env_samples, mesh_n = opts.mesh_samples;
-    const uint32_t n_pad = (n + 63u) & ~63u;
+    __shared__ unsigned long long s_cnt[SHADE_BLOCK / 64];
+    __shared__ unsigned long long s_base;
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    const unsigned long long lt = lane == 0 ? 0ull : (~0ull >> (64 - lane));
+    const uint32_t n_pad = (n + (SHADE_BLOCK - 1u)) & ~(SHADE_BLOCK - 1u);   // trip count uniform per workgroup (it synchronises below)
     for (uint32_t i = blockIdx.x * SHADE_BLOCK + threadIdx.x; i < n_pad; i += gridDim.x * SHADE_BLOCK) {
-        const bool live = i < n;
+        const bool live = i < n && !(cur.flags[i] & PATH_FLAG_MASKED);
         bool cont = false, sh0 = false, sh1 = false;
         // state carried to the next bounce
         f3 rayO = F3(0, 0, 0), rayD = F3(0, 0, 1), throughput = F3(0, 0, 0), L = F3(0, 0, 0), c0 = F3(0, 0, 0), c1 = F3(0, 0, 0);
@@ -211,8 +216,24 @@ __global__ __launch_bounds__(SHADE_BLOCK) void k_shade(SceneView sc, PipelineOpt
             }
             if (done) lbuf[slot] = make_float4(L.x, L.y, L.z, 0.0f);
         }
-        // ---- compaction: surviving paths and their shadow rays ----
-        const uint32_t j = wave_append(&cnt->n_next, cont);
+        // ---- compaction: surviving paths and their shadow rays.  One 64-bit atomic per WORKGROUP reserves both
+        // ranges (low word: next-path queue, high word: shadow queue) — per-wave atomics on one counter cap the
+        // kernel at ~88 waves/us (MI355X_MICROARCH.md "dequeue") ----
+        const unsigned long long mc = __ballot(cont), m0 = __ballot(sh0), m1 = __ballot(sh1);
+        const uint32_t wc = (uint32_t)__popcll(mc), w0 = (uint32_t)__popcll(m0), w1 = (uint32_t)__popcll(m1);
+        if (lane == 0) s_cnt[wave] = (unsigned long long)wc | ((unsigned long long)(w0 + w1) << 32);
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            unsigned long long tot = 0;
+            for (int k = 0; k < SHADE_BLOCK / 64; k++) tot += s_cnt[k];
+            s_base = tot ? atomicAdd(reinterpret_cast<unsigned long long*>(&cnt->n_next), tot) : 0ull;
+        }
+        __syncthreads();
+        unsigned long long base = s_base;
+        for (uint32_t k = 0; k < wave; k++) base += s_cnt[k];
+        __syncthreads();   // s_cnt / s_base are rewritten by the next iteration
+        const uint32_t j = (uint32_t)base + (uint32_t)__popcll(mc & lt);
+        const uint32_t qb = (uint32_t)(base >> 32);
         if (cont) {
             nxt.ox[j] = rayO.x; nxt.oy[j] = rayO.y; nxt.oz[j] = rayO.z; nxt.dx[j] = rayD.x; nxt.dy[j] = rayD.y; nxt.dz[j] = rayD.z;
             nxt.tx[j] = throughput.x; nxt.ty[j] = throughput.y; nxt.tz[j] = throughput.z;
@@ -220,17 +241,20 @@ __global__ __launch_bounds__(SHADE_BLOCK) void k_shade(SceneView sc, PipelineOpt
             nxt.p0x[j] = c0.x; nxt.p0y[j] = c0.y; nxt.p0z[j] = c0.z; nxt.p1x[j] = c1.x; nxt.p1y[j] = c1.y; nxt.p1z[j] = c1.z;
             nxt.last_pdf[j] = lastPdf; nxt.rng[j] = rng; nxt.slot[j] = slot; nxt.flags[j] = flags;
         }
-        const uint32_t q0 = wave_append(&cnt->n_shadow, sh0);
+        const uint32_t q0 = qb + (uint32_t)__popcll(m0 & lt);
         if (sh0) { shq.ox[q0] = s0o.x; shq.oy[q0] = s0o.y; shq.oz[q0] = s0o.z; shq.dx[q0] = s0d.x; shq.dy[q0] = s0d.y; shq.dz[q0] = s0d.z; shq.tmax[q0] = s0t; shq.target[q0] = (j << 1); }
-        const uint32_t q1 = wave_append(&cnt->n_shadow, sh1);
+        const uint32_t q1 = qb + w0 + (uint32_t)__popcll(m1 & lt);
         if (sh1) { shq.ox[q1] = s1o.x; shq.oy[q1] = s1o.y; shq.oz[q1] = s1o.z; shq.dx[q1] = s1d.x; shq.dy[q1] = s1d.y; shq.dz[q1] = s1d.z; shq.tmax[q1] = s1t; shq.target[q1] = (j << 1) | 1u; }
     }
 }
 
 // between bounces: account the rays just traced, rotate the queues, reset the dequeue heads
-__global__ void k_advance(Counters* cnt, int after_raygen) {
+__global__ void k_advance(Counters* cnt, int after_raygen, uint32_t total, uint32_t masked) {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
-    if (after_raygen) { cnt->samples += cnt->n_cur; cnt->zombies_cur = 0; cnt->zombies_next = 0; cnt->n_next = 0; cnt->n_shadow = 0; cnt->head_closest = 0; cnt->head_shadow = 0; return; }
+    if (after_raygen) {   // k_raygen filled slots [0,total); `masked` of them lie outside the image
+        cnt->n_cur = total; cnt->samples += total - masked; cnt->zombies_cur = masked; cnt->zombies_next = 0;
+        cnt->n_next = 0; cnt->n_shadow = 0; cnt->head_closest = 0; cnt->head_shadow = 0; return;
+    }
     cnt->closest_rays += cnt->n_cur - cnt->zombies_cur;
     cnt->zombies_cur = cnt->zombies_next; cnt->zombies_next = 0;
     cnt->shadow_rays += cnt->n_shadow;
@@ -239,22 +263,31 @@ __global__ void k_advance(Counters* cnt, int after_raygen) {
 }
 
 // storeColor main.hlsl:43-51 over the `s_count` samples of this chunk (summed in sample order, main.hlsl:83-92)
-__global__ __launch_bounds__(SHADE_BLOCK) void k_film(ShardView sh, PipelineOpts opts, const float4* lbuf, uint32_t s_count, int first_chunk, int last_chunk,
+__global__ __launch_bounds__(SHADE_BLOCK) void k_film(ShardView sh, PipelineOpts opts, const float4* lbuf, uint32_t s_count, uint32_t n_launches, int first_chunk, int last_chunk,
                                                         uint32_t sample_count, float4* color, float4* film) {
+    // lbuf holds n_launches launches of s_count samples each (slot = (launch*s_count + sample)*pixels + p).  The launches were
+    // traced concurrently but are folded into the film here in launch order, exactly as n_launches sequential dispatches
+    // would (main.hlsl:43-51).  A launch that does not fit in flight is split into chunks (then n_launches == 1 and
+    // first_chunk/last_chunk tell which part of its sample sum this is).
     for (uint32_t p = blockIdx.x * SHADE_BLOCK + threadIdx.x; p < sh.pixels; p += gridDim.x * SHADE_BLOCK) {
         uint32_t x, y;
         if (!shard_pixel(sh, p, x, y)) continue;
-        f3 c = F3(0.0f, 0.0f, 0.0f);
-        if (!first_chunk) { const float4 q = color[p]; c = F3(q.x, q.y, q.z); }
-        for (uint32_t s = 0; s < s_count; s++) { const float4 l = lbuf[(size_t)s * sh.pixels + p]; c = add(c, F3(l.x, l.y, l.z)); }
-        if (!last_chunk) { color[p] = make_float4(c.x, c.y, c.z, 0.0f); continue; }
-        const float spr = (float)opts.samples_per_run;
-        if (sample_count == 0) film[p] = make_float4(c.x / spr, c.y / spr, c.z / spr, 1.0f);
-        else {
-            const float4 f = film[p];
-            const float den = (float)(sample_count + opts.samples_per_run);
-            film[p] = make_float4(f.x + (c.x - f.x) / den, f.y + (c.y - f.y) / den, f.z + (c.z - f.z) / den, f.w + 1.0f);
+        float4 f = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        if (last_chunk && sample_count != 0) f = film[p];
+        for (uint32_t j = 0; j < n_launches; j++) {
+            f3 c = F3(0.0f, 0.0f, 0.0f);
+            if (!first_chunk) { const float4 q = color[p]; c = F3(q.x, q.y, q.z); }
+            for (uint32_t s = 0; s < s_count; s++) { const float4 l = lbuf[((size_t)j * s_count + s) * sh.pixels + p]; c = add(c, F3(l.x, l.y, l.z)); }
+            if (!last_chunk) { color[p] = make_float4(c.x, c.y, c.z, 0.0f); continue; }
+            const float spr = (float)opts.samples_per_run;
+            const uint32_t count = sample_count + j * opts.samples_per_run;
+            if (count == 0) f = make_float4(c.x / spr, c.y / spr, c.z / spr, 1.0f);
+            else {
+                const float den = (float)(count + opts.samples_per_run);
+                f = make_float4(f.x + (c.x - f.x) / den, f.y + (c.y - f.y) / den, f.z + (c.z - f.z) / den, f.w + 1.0f);
+            }
         }
+        if (last_chunk) film[p] = f;
     }
 }
 
@@ -280,9 +313,9 @@ void launch_raygen(hipStream_t s, int grid, const ShardView& sh, const CameraCon
 void launch_shade(hipStream_t s, int grid, const SceneView& sc, const PipelineOpts& o, const PathState& cur, const HitBuf& hits, const PathState& nxt, const ShadowQueue& q, float4* lbuf, Counters* cnt) {
     hipLaunchKernelGGL(k_shade, dim3(grid), dim3(SHADE_BLOCK), 0, s, sc, o, cur, hits, nxt, q, lbuf, cnt);
 }
-void launch_advance(hipStream_t s, Counters* cnt, int after_raygen) { hipLaunchKernelGGL(k_advance, dim3(1), dim3(1), 0, s, cnt, after_raygen); }
-void launch_film(hipStream_t s, int grid, const ShardView& sh, const PipelineOpts& o, const float4* lbuf, uint32_t s_count, int first_chunk, int last_chunk, uint32_t sample_count, float4* color, float4* film) {
-    hipLaunchKernelGGL(k_film, dim3(grid), dim3(SHADE_BLOCK), 0, s, sh, o, lbuf, s_count, first_chunk, last_chunk, sample_count, color, film);
+void launch_advance(hipStream_t s, Counters* cnt, int after_raygen, uint32_t total, uint32_t masked) { hipLaunchKernelGGL(k_advance, dim3(1), dim3(1), 0, s, cnt, after_raygen, total, masked); }
+void launch_film(hipStream_t s, int grid, const ShardView& sh, const PipelineOpts& o, const float4* lbuf, uint32_t s_count, uint32_t n_launches, int first_chunk, int last_chunk, uint32_t sample_count, float4* color, float4* film) {
+    hipLaunchKernelGGL(k_film, dim3(grid), dim3(SHADE_BLOCK), 0, s, sh, o, lbuf, s_count, n_launches, first_chunk, last_chunk, sample_count, color, film);
 }
 void launch_unpack_film(hipStream_t s, int grid, const ShardView& sh, const float4* packed, uint32_t nshards, uint32_t first_shard, size_t stride, float4* full) {
     hipLaunchKernelGGL(k_unpack_film, dim3(grid), dim3(SHADE_BLOCK), 0, s, sh, packed, nshards, first_shard, stride, full);

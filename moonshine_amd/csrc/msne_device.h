@@ -65,7 +65,13 @@ struct SceneView {
     const AliasEntry* alias;          // entry 0 = header {count, sum}
     EnvView env;
     uint32_t tlas_root;               // MAX_UINT when the scene is empty
+    uint32_t root_in_blas;            // 1: tlas_root is the root of the merged world BLAS (no TLAS level at all)
 };
+// All visible identity-transform instances are merged into ONE "world BLAS" whose triangle records carry their owning
+// instance in TriRec::pad; the TLAS then holds one pseudo-instance for it (InstanceRec flag bit 2) next to the
+// transformed instances.  Lanes inside it run with cur_inst == WORLD_INSTANCE.
+constexpr uint32_t WORLD_INSTANCE = 0xFFFFFFFEu;
+constexpr uint32_t INST_FLAG_VISIBLE = 1u, INST_FLAG_IDENTITY = 2u, INST_FLAG_WORLD = 4u;
 
 // ---- wavefront state (SoA, one slot per in-flight path; two sets ping-pong between bounces) ----
 struct PathState {
@@ -82,6 +88,7 @@ struct PathState {
 };
 constexpr uint32_t PATH_FLAG_DELTA = 1u << 16;
 constexpr uint32_t PATH_FLAG_ZOMBIE = 1u << 17;
+constexpr uint32_t PATH_FLAG_MASKED = 1u << 18;   // slot of a pixel outside the image (edge tiles): dropped by the first k_shade
 constexpr int PATH_STATE_WORDS = 22;
 
 struct HitBuf { uint32_t* inst; uint32_t* geo; uint32_t* prim; float* u; float* v; };
@@ -93,7 +100,8 @@ struct ShadowQueue {
 
 // device-side counters; one instance per context
 struct Counters {
-    uint32_t n_cur, n_next, n_shadow, zombies_cur;      // zombies: queue entries that only wait to be finalized (no ray)
+    uint32_t n_next, n_shadow;                          // appended to with ONE 64-bit atomic per workgroup (low = n_next, high = n_shadow)
+    uint32_t n_cur, zombies_cur;                        // zombies: queue entries that only wait to be finalized (no ray)
     uint32_t head_closest, head_shadow, zombies_next, pad2;
     unsigned long long closest_rays, shadow_rays, samples, pad3;
 };
@@ -114,6 +122,7 @@ struct ShardView {
     uint32_t width, height, tile_size, tiles_x, tiles_y;
     uint32_t shard_index, shard_count, local_tiles;   // local tile k = global tile shard_index + k*shard_count
     uint32_t pixels;                                  // local_tiles * tile_size^2 (padded: edge tiles keep masked pixels)
+    uint32_t valid_pixels;                            // pixels of this shard that lie inside the image
 };
 
 }  // namespace msne

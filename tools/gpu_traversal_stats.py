@@ -15,4 +15,5 @@ print(json.dumps({"closest_rays": st["closest_rays"], "shadow_rays": st["shadow_
                   "gpu_V_n_closest": t["closest_node_visits"] / st["closest_rays"], "gpu_V_t_closest": t["closest_tri_tests"] / st["closest_rays"],
                   "gpu_V_n_shadow": t["shadow_node_visits"] / st["shadow_rays"], "gpu_V_t_shadow": t["shadow_tri_tests"] / st["shadow_rays"],
                   "oracle": {k: fx[k] for k in ("V_n_closest", "V_t_closest", "V_n_shadow", "V_t_shadow")},
+                  "closest_profile": t["closest_profile"], "shadow_profile": t["shadow_profile"],
                   "ms": {k: st[k] for k in ("trace_closest_ms", "trace_shadow_ms", "shade_ms", "render_ms")}}))
