@@ -26,23 +26,24 @@ HBM_PEAK = 8.0e12  # B/s, /opt/skills/guides/MI355X_MICROARCH.md "HBM3E peak BW"
 
 def cpu_baseline(fixture):
     """The oracle (a scalar C restatement, kind="port") timed on this host's cores on a bounded sample of the
-    same workload: S1 at 480x270, 4 spp.  Reported baseline only — never the product path."""
+    same workload: S1 at 1920x1080, 6 spp (about 10-30 s of CPU work).  Reported baseline only — never the product path."""
     from oracle import orc
     orc.build()
     cores = os.cpu_count() or 1
     c = orc.Context(threads=cores)
-    s, l = scenes.s1(c, extent=(480, 270))
+    W, H, SPP = 1920, 1080, 16
+    s, l = scenes.s1(c, extent=(W, H))
     c.set_pipeline(samples_per_run=1, max_bounces=8, env_samples_per_bounce=1, mesh_samples_per_bounce=1)
     c.render(s, l, launches=1)          # builds the BVH, touches memory
     c.reset_counters()
     t0 = time.perf_counter()
-    c.render(s, l, launches=4)
+    c.render(s, l, launches=SPP)
     dt = time.perf_counter() - t0
     k = c.counters()
     rays = k["closest_rays"] + k["shadow_rays"]
     return {"value": rays / dt / 1e6, "unit": "Mrays/s", "cores": cores, "kind": "port",
-            "sample": "S1 (1 003 520 tris) at 480x270, 4 spp, max_bounces 8, env+mesh NEE; %d rays in %.2f s; Msamples/s %.3f"
-                      % (rays, dt, k["samples"] / dt / 1e6)}
+            "sample": "S1 (1 003 520 tris) at %dx%d, %d spp, max_bounces 8, env+mesh NEE; %d rays in %.2f s on %d threads; Msamples/s %.3f"
+                      % (W, H, SPP, rays, dt, cores, k["samples"] / dt / 1e6)}
 
 
 def main():
@@ -61,11 +62,17 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != a.gpus:
         raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d (launch N>1 with torch.distributed.run)" % (a.gpus, world))
-    torch.cuda.set_device(local_rank)
+    # MSNE_BENCH_BACKEND=gloo is a debugging aid: several ranks may then share one GPU and the gather goes through host memory
+    backend = os.environ.get("MSNE_BENCH_BACKEND", "nccl")
+    dev = local_rank if backend == "nccl" else local_rank % max(torch.cuda.device_count(), 1)
+    torch.cuda.set_device(dev)
     if world > 1:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", dev))
+        else:
+            dist.init_process_group(backend)
 
-    ctx = api.Context(device=local_rank, shard_index=rank, shard_count=world)
+    ctx = api.Context(device=dev, shard_index=rank, shard_count=world)
     sensor, lens = scenes.s1(ctx, extent=(a.width, a.height), env=a.env)
     ctx.set_pipeline(samples_per_run=1, max_bounces=8, env_samples_per_bounce=1, mesh_samples_per_bounce=1)
     ctx.set_profiling(kernel_events=True, traversal_counters=False)
@@ -80,11 +87,18 @@ def main():
         return torch.as_tensor(_W(), device="cuda")
 
     def gather():
+        # ONE gather of the packed films to rank 0 (RCCL over xGMI), then k_unpack_film on rank 0
         if world == 1:
             return
         t = film_tensor()
+        if backend != "nccl":
+            t = t.cpu()
         if rank == 0:
-            dist.gather(t, list(gathered.view(world, -1).unbind(0)), dst=0)
+            parts = list(gathered.view(world, -1).unbind(0)) if backend == "nccl" else [torch.empty_like(t) for _ in range(world)]
+            dist.gather(t, parts, dst=0)
+            if backend != "nccl":
+                gathered.copy_(torch.cat(parts))
+            torch.cuda.synchronize()
             ctx.unpack_gathered(sensor, gathered.data_ptr(), world)
         else:
             dist.gather(t, None, dst=0)
@@ -95,7 +109,8 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
-    ctx.render(sensor, lens, launches=max(a.warmup, 1) if a.warmup else 0, readback=False) if a.warmup else None
+    if a.warmup:
+        ctx.render(sensor, lens, launches=a.warmup, readback=False)
     gather()
     ctx.clear_sensor(sensor)
     ctx.reset_stats()
@@ -123,6 +138,12 @@ def main():
         avg_ms = st["trace_closest_ms"] / nl
         bytes_per_launch = b_ray * st["closest_rays"] / nl
         achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+        # HBM bytes per launch from the committed PMC passes (tools/profile_round.sh; FETCH_SIZE x2 + WRITE_SIZE) — only valid
+        # for the exact configuration they were collected on
+        traffic = None
+        tp = os.path.join(ROOT, "profiles", "r01_traffic.json")
+        if os.path.exists(tp) and world == 1 and a.steps == 64 and (a.width, a.height, a.env) == (1920, 1080, "constant"):
+            traffic = json.load(open(tp))["traffic_bytes_per_launch"]
         out = {
             "metric": "Mrays/sec, 1M-tri scene @1080p", "value": rays / dt / 1e6, "unit": "Mrays/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3,
@@ -133,7 +154,7 @@ def main():
             "msamples_per_s": samples / dt / 1e6,
             "rays": {"closest": closest, "shadow": shadow, "per_sample": rays / max(samples, 1.0)},
             "roofline": {"bound": "hbm", "kernel": "k_trace_closest", "achieved": achieved, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
-                         "frac": achieved / (HBM_PEAK / 1e9), "traffic": None,
+                         "frac": achieved / (HBM_PEAK / 1e9), "traffic": traffic, "algorithmic_bytes_per_launch": bytes_per_launch,
                          "bytes_per_ray": b_ray, "rays_per_launch": st["closest_rays"] / nl, "avg_launch_ms": avg_ms, "launches": nl},
             "whole_path_roofline_frac": (rays / dt * b_ray + samples / dt * (fx["B_shade"] + 32)) / HBM_PEAK / world,
             "kernel_ms": {"trace_closest": st["trace_closest_ms"], "trace_shadow": st["trace_shadow_ms"], "shade": st["shade_ms"], "render": st["render_ms"]},
