@@ -208,6 +208,20 @@ int MsneGetStats(const HdMoonshine*, MsneStats*);
 void MsneResetStats(HdMoonshine*);
 const char* MsneGetLastError(const HdMoonshine*);   /* NULL ctx → last creation error */
 
+/* ---- file-level entry points: Scene.fromGlbExr (Scene.zig:28-62), Rgba2D.load/save (exr.zig:137-229) ---- */
+typedef struct MsneGlbInfo { uint32_t meshes, materials, instances, textures, triangles; LensHandle lens; } MsneGlbInfo;
+/* World.fromGlb + Camera.Lens.fromGlb (World.zig:233-363, Camera.zig:26-51): appends the GLB's meshes, materials,
+ * instances and its first camera (as a lens) to the context.  0 on success; MsneGetIoError() says why not. */
+int MsneLoadGlb(HdMoonshine*, const char* glb_path, MsneGlbInfo* info_out);
+/* Rgba2D.load + BackgroundManager.addBackground (Scene.zig:49-55): equirectangular EXR → environment */
+int MsneSetBackgroundExr(HdMoonshine*, const char* exr_path);
+/* Rgba2D.save (exr.zig:137-206): the sensor's host buffer as a 3-channel (B,G,R) FLOAT scanline EXR; alpha is dropped */
+int MsneSaveSensorExr(HdMoonshine*, SensorHandle, Extent2D, const char* exr_path);
+/* the EXR codec itself.  Load: call with rgba_out == NULL to get the extent, then again with a buffer of w*h*4 floats. */
+int MsneExrLoad(const char* exr_path, float* rgba_out, Extent2D* extent_inout);
+int MsneExrSave(const char* exr_path, const float* rgba, Extent2D extent);
+const char* MsneGetIoError(void);
+
 /* ------------------------------------------------------------------ */
 /* Part 3 — diagnostics for parity tests and profiling (no reference   */
 /* equivalent; never needed by a renderer front end)                   */

@@ -118,6 +118,12 @@ SYMBOLS = [
     ("MsneGetStats", C.c_int, [_vp, C.POINTER(MsneStats)]),
     ("MsneResetStats", None, [_vp]),
     ("MsneGetLastError", C.c_char_p, [_vp]),
+    ("MsneLoadGlb", C.c_int, [_vp, C.c_char_p, _vp]),
+    ("MsneSetBackgroundExr", C.c_int, [_vp, C.c_char_p]),
+    ("MsneSaveSensorExr", C.c_int, [_vp, _u32, Extent2D, C.c_char_p]),
+    ("MsneExrLoad", C.c_int, [C.c_char_p, _vp, C.POINTER(Extent2D)]),
+    ("MsneExrSave", C.c_int, [C.c_char_p, _vp, Extent2D]),
+    ("MsneGetIoError", C.c_char_p, []),
     ("MsneSetProfiling", None, [_vp, C.c_int, C.c_int]),
     ("MsneGetTraversalCounters", C.c_int, [_vp, C.POINTER(C.c_uint64)]),
     ("MsneTraceRays", C.c_int, [_vp, _vp, _u32, C.c_int, _vp, _vp]),
@@ -130,6 +136,29 @@ SYMBOLS = [
 
 class MoonshineError(RuntimeError):
     pass
+
+
+class MsneGlbInfo(C.Structure):
+    _fields_ = [(n, C.c_uint32) for n in ("meshes", "materials", "instances", "textures", "triangles", "lens")]
+
+
+def exr_load(path):
+    """EXR file -> (H, W, 4) float32 (the library's codec; no GPU needed)."""
+    L = load_library()
+    e = Extent2D(0, 0)
+    if L.MsneExrLoad(path.encode(), None, C.byref(e)) != 0:
+        raise MoonshineError("MsneExrLoad: %s" % L.MsneGetIoError().decode())
+    out = np.zeros((e.height, e.width, 4), np.float32)
+    if L.MsneExrLoad(path.encode(), out.ctypes.data_as(C.c_void_p), C.byref(e)) != 0:
+        raise MoonshineError("MsneExrLoad: %s" % L.MsneGetIoError().decode())
+    return out
+
+
+def exr_save(path, rgba):
+    L = load_library()
+    a = np.ascontiguousarray(rgba, np.float32)
+    if L.MsneExrSave(path.encode(), a.ctypes.data_as(C.c_void_p), Extent2D(a.shape[1], a.shape[0])) != 0:
+        raise MoonshineError("MsneExrSave: %s" % L.MsneGetIoError().decode())
 
 
 def load_library(path=None):
@@ -252,6 +281,22 @@ class Context:
         a = _f32(rgba, (height, width, 4))
         if self.L.MsneSetBackground(self.h, _ptr(a), Extent2D(width, height)) != 0:
             self._err("MsneSetBackground")
+
+    def load_glb(self, path):
+        """World.fromGlb + Lens.fromGlb: returns (lens handle, info dict)."""
+        info = MsneGlbInfo()
+        if self.L.MsneLoadGlb(self.h, path.encode(), C.byref(info)) != 0:
+            raise MoonshineError("MsneLoadGlb(%s): %s" % (path, self.L.MsneGetIoError().decode()))
+        return int(info.lens), {n: int(getattr(info, n)) for n, _ in MsneGlbInfo._fields_}
+
+    def set_background_exr(self, path):
+        if self.L.MsneSetBackgroundExr(self.h, path.encode()) != 0:
+            raise MoonshineError("MsneSetBackgroundExr(%s): %s" % (path, self.L.MsneGetIoError().decode()))
+
+    def save_exr(self, sensor, path):
+        w, h = self._extents[sensor]
+        if self.L.MsneSaveSensorExr(self.h, sensor, Extent2D(w, h), path.encode()) != 0:
+            raise MoonshineError("MsneSaveSensorExr(%s): %s" % (path, self.L.MsneGetIoError().decode()))
 
     def create_sensor(self, width, height):
         s = int(self.L.HdMoonshineCreateSensor(self.h, Extent2D(width, height)))

@@ -1,4 +1,5 @@
-"""Builds libmoonshine_amd.so (HIP kernels + C ABI) for gfx950 with hipcc, in-tree.
+"""Builds libmoonshine_amd.so (HIP kernels + C ABI + host-side scene I/O) for gfx950 with hipcc, in-tree, and the
+`offline` CLI that links against it.
 
 hipcc cross-compiles without a GPU.  -ffp-contract=off is part of the numerical contract of the
 hot path (every f32 operation is a single IEEE operation, see csrc/msne_math.h)."""
@@ -8,11 +9,16 @@ import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
+HOST = os.path.join(HERE, "host")
 SOURCES = ["context.hip", "bvh_build.hip", "trace.hip", "integrator.hip", "env.hip"]
+HOST_SOURCES = ["exr.cpp", "png.cpp", "glb.cpp", "scene_io.cpp"]      # plain C++ above the C ABI
 LIB = os.path.join(HERE, "libmoonshine_amd.so")
+OFFLINE = os.path.join(HERE, "offline")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+CXX = os.environ.get("CXX", "g++")
 EXTRA = os.environ.get("MSNE_CXXFLAGS", "").split()
-FLAGS = EXTRA + ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math", "-Wall", "-Wno-unused-function"]
+FLAGS = EXTRA + ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math", "-Wall", "-Wno-unused-function", "-Wno-comment"]
+HOST_FLAGS = ["-O2", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Wall", "-Wno-comment"]
 
 
 def _stale(out, deps):
@@ -20,7 +26,8 @@ def _stale(out, deps):
 
 
 def build(force=False, verbose=False):
-    hdrs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")] + [os.path.join(HERE, "..", "include", "moonshine_amd.h")]
+    api_h = os.path.join(HERE, "..", "include", "moonshine_amd.h")
+    hdrs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")] + [api_h]
     objdir = os.path.join(HERE, "build")
     os.makedirs(objdir, exist_ok=True)
     objs, procs = [], []
@@ -33,11 +40,23 @@ def build(force=False, verbose=False):
             if verbose:
                 print(" ".join(cmd))
             procs.append((src, subprocess.Popen(cmd)))
+    for src in HOST_SOURCES:
+        s = os.path.join(HOST, src)
+        o = os.path.join(objdir, "host_" + src.replace(".cpp", ".o"))
+        objs.append(o)
+        if force or _stale(o, [s, os.path.join(HOST, "host.h"), api_h]):
+            cmd = [CXX] + HOST_FLAGS + ["-c", s, "-o", o]
+            if verbose:
+                print(" ".join(cmd))
+            procs.append((src, subprocess.Popen(cmd)))
     for src, p in procs:
         if p.wait() != 0:
-            raise RuntimeError("hipcc failed on %s" % src)
+            raise RuntimeError("compile failed on %s" % src)
     if force or procs or _stale(LIB, objs):
-        subprocess.check_call([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs)
+        subprocess.check_call([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs + ["-lz"])
+    cli = os.path.join(HOST, "offline.cpp")
+    if force or _stale(OFFLINE, [cli, LIB, api_h]):
+        subprocess.check_call([CXX] + HOST_FLAGS + ["-o", OFFLINE, cli, "-L" + HERE, "-lmoonshine_amd", "-Wl,-rpath,$ORIGIN", "-Wl,-rpath-link," + os.path.join(os.environ.get("ROCM_PATH", "/opt/rocm"), "lib")])
     return LIB
 
 

@@ -1,0 +1,123 @@
+"""CPU tests of the rows either side of the hot path: the EXR codec and the GLB importer.
+The importer is exercised against the oracle through tests/shim (no GPU needed); the same files are loaded by the HIP
+library in tests/test_gpu_io.py."""
+import math
+import os
+
+import numpy as np
+import pytest
+
+from moonshine_amd import api, assets, scenes
+from tests import io_common as io
+
+
+def bits(a):
+    return np.ascontiguousarray(a, np.float32).view(np.uint32)
+
+
+@pytest.mark.parametrize("channels,ptype,comp", [("RGB", "float", "none"), ("RGBA", "float", "zip"), ("RGB", "half", "zips"), ("RGBA", "half", "zip"), ("BGR", "float", "zips")])
+def test_exr_reader_against_independent_writer(tmp_path, channels, ptype, comp):
+    rs = np.random.default_rng(0)
+    img = (rs.random((37, 53, 4)) * 4).astype(np.float32)      # 37 rows: ZIP's last block is partial
+    p = str(tmp_path / "a.exr")
+    open(p, "wb").write(assets.exr_bytes(img, channels, ptype, comp))
+    got = api.exr_load(p)
+    ref = img.astype(np.float16).astype(np.float32) if ptype == "half" else img.copy()
+    if "A" not in channels:
+        ref[..., 3] = 1.0
+    assert np.array_equal(bits(got), bits(ref))
+
+
+def test_exr_writer_layout_and_roundtrip(tmp_path):
+    rs = np.random.default_rng(1)
+    img = rs.normal(size=(9, 13, 4)).astype(np.float32)
+    p = str(tmp_path / "b.exr")
+    api.exr_save(p, img)
+    raw = open(p, "rb").read()
+    assert raw[:4] == (20000630).to_bytes(4, "little")
+    i = raw.index(b"channels\0chlist\0")
+    assert raw[i + 20:i + 22] == b"B\0" and b"G\0" in raw[i:i + 80] and b"R\0" in raw[i:i + 80]      # B,G,R header order (exr.zig:178-183)
+    assert b"A\0\x02" not in raw[i:i + 80]                                                                 # alpha dropped (exr.zig:158-172)
+    got = api.exr_load(p)
+    assert np.array_equal(bits(got[..., :3]), bits(img[..., :3])) and np.all(got[..., 3] == 1.0)
+
+
+def test_exr_rejects_garbage(tmp_path):
+    p = str(tmp_path / "c.exr")
+    open(p, "wb").write(b"not an exr at all")
+    with pytest.raises(api.MoonshineError):
+        api.exr_load(p)
+    good = assets.exr_bytes(np.ones((4, 4, 4), np.float32), "RGB", "float", "zip")
+    open(p, "wb").write(good[:len(good) - 9])
+    with pytest.raises(api.MoonshineError):
+        api.exr_load(p)
+
+
+def test_config0_single_triangle_glb_on_the_cpu_integrator(tmp_path, orc):
+    """BASELINE.json configs[0]: single-triangle glTF + constant env, 64x64, 1 spp, depth 1 — scalar CPU integrator (plumbing)."""
+    glb, exr = str(tmp_path / "tri.glb"), str(tmp_path / "white.exr")
+    io.write_single_triangle(glb, exr)
+    c = orc.Context(threads=2)
+    lens, info = io.oracle_load(orc, c, glb, exr)
+    assert info == dict(meshes=1, materials=1, instances=1, textures=3, triangles=1, lens=0)
+    s = c.create_sensor(64, 64)
+    c.set_pipeline(samples_per_run=1, max_bounces=1, env_samples_per_bounce=1, mesh_samples_per_bounce=0)
+    c.render(s, lens)
+    img = c.sensor_data(s)
+    assert np.all(img[..., 3] == 1.0) and np.isfinite(img).all()
+    assert np.array_equal(img[0, 0, :3], np.float32([1, 1, 1]))            # corner: environment
+    centre = img[36, 32, :3]
+    assert 0.0 < centre[0] <= 0.81 and centre[1] < centre[0] and centre[2] < centre[0]   # red Lambert triangle under a white sky
+    hit = (img[..., 1] < 0.99)
+    assert 0.15 < hit.mean() < 0.4                                          # triangle area at this camera
+    # the same scene built directly through the API (Z-up, rows x,z,y of the glTF node matrix — World.zig:341-345)
+    d = orc.Context(threads=2)
+    m = d.create_material(scenes.LAMBERT, d.solid_texture(0.5, 0.5), d.solid_texture(0.0, 0.0, 0.0), color=d.solid_texture(0.8, 0.3, 0.3))
+    T = np.array([[1, 0, 0, 0], [0, 0, 1, 0], [0, 1, 0, 0]], np.float32)
+    d.create_instance([(d.create_mesh([(-1, -1, 0), (1, -1, 0), (0, 1, 0)], [[0, 1, 2]]), m, False)], transform=T)
+    d.set_background(np.ones(4, np.float32), 1, 1)
+    dl = d.create_lens(d.make_lens((0, 3, 0), (0, -1, 0), (0, 0, 1), 0.8))       # glTF camera at (0,0,3) looking down -z, y up
+    ds = d.create_sensor(64, 64)
+    d.set_pipeline(samples_per_run=1, max_bounces=1, env_samples_per_bounce=1, mesh_samples_per_bounce=0)
+    d.render(ds, dl)
+    assert rel_l2(img, d.sensor_data(ds)) < 1e-6
+
+
+def rel_l2(a, b):
+    return float(np.linalg.norm(a[..., :3].astype(np.float64) - b[..., :3]) / np.linalg.norm(b[..., :3].astype(np.float64)))
+
+
+@pytest.mark.parametrize("u32", [False, True])
+def test_gallery_import_rules(tmp_path, orc, u32):
+    glb, exr = str(tmp_path / "gallery.glb"), str(tmp_path / "sky.exr")
+    io.write_gallery(glb, exr, u32=u32)
+    c = orc.Context(threads=os.cpu_count())
+    lens, info = io.oracle_load(orc, c, glb, exr)
+    assert info["instances"] == 6 and info["meshes"] == 6 and info["materials"] == 6 and info["triangles"] == 4 * 320 + 4
+    # texture handles: per material normal+emissive (+color, +metal/rough): Floor 3, Mirror 3, Glass 2, Gold 5, Textured 5, Emitter 3
+    assert info["textures"] == 3 + 3 + 2 + 5 + 5 + 3
+    assert c.alias_table()[0]["alias"] == 2                       # only the "Emitter…" quad is sampled (World.zig:270)
+    rgb, lum = c.env()
+    assert rgb.shape[0] == 32                                     # S = floorPow2(32) from the 64x32 half/ZIP sky
+    s = c.create_sensor(96, 64)
+    c.set_pipeline(samples_per_run=4, max_bounces=6, env_samples_per_bounce=1, mesh_samples_per_bounce=1)
+    c.render(s, lens)
+    img = c.sensor_data(s)
+    assert np.isfinite(img).all() and img[..., :3].mean() > 0.05 and img[..., :3].std() > 0.02
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "gallery_96x64_4spp.npy"))
+    assert np.array_equal(bits(img), bits(g))
+
+
+def test_glb_errors(tmp_path, orc):
+    c = orc.Context()
+    s = io.shim(orc)
+    bad = str(tmp_path / "bad.glb")
+    open(bad, "wb").write(b"glTF\x02\0\0\0\x10\0\0\0junk")
+    import ctypes as C
+    info = (C.c_uint32 * 6)()
+    assert s.ShimLoadGlb(C.c_void_p(c.h), bad.encode(), info) != 0
+    b = assets.GlbBuilder()
+    b.node(mesh=b.mesh([dict(positions=[(0, 0, 0), (1, 0, 0), (0, 1, 0)], indices=[0, 1, 2], material=b.material("m"))]))
+    nocam = str(tmp_path / "nocam.glb")
+    open(nocam, "wb").write(b.tobytes())
+    assert s.ShimLoadGlb(C.c_void_p(c.h), nocam.encode(), info) != 0 and b"NoCameraInGlb" in s.ShimError()     # Camera.zig:30
