@@ -6,6 +6,7 @@ with deterministic tie-breaks, so the GPU film equals the oracle's film bit for 
 tolerance (relative per-pixel L2 < 1e-4) is asserted as well and must hold a fortiori.
 """
 import math
+import os
 
 import numpy as np
 import pytest
@@ -277,3 +278,61 @@ def test_hydra_abi_smoke(gpu_api):
     img3 = np.ctypeslib.as_array(L.HdMoonshineGetSensorData(h, sensor), shape=(32, 32, 4)).copy()
     assert np.all(img3[..., :3] == 1.0)
     L.HdMoonshineDestroy(h)
+
+
+# ---- BASELINE.json full-size workload (S1: 1 003 520 triangles at 1920x1080): size-independent properties ----
+@pytest.fixture(scope="module")
+def s1_full(gpu_api):
+    c = gpu_api.Context()
+    s, l = scenes.s1(c, extent=(1920, 1080))
+    c.set_pipeline(samples_per_run=1, max_bounces=8, env_samples_per_bounce=1, mesh_samples_per_bounce=1)
+    c.render(s, l, launches=3)          # three launches traced concurrently (one wavefront pass)
+    return c, s, l, c.sensor_data(s), c.counters()
+
+
+def test_s1_full_size_tiles_match_oracle(orc, s1_full):
+    """the oracle renders a few 64x64 tiles of the full-size frame (tile t -> shard t mod G, so shard_count = #tiles picks one);
+    those tiles of the GPU film must be bit-identical"""
+    _, _, _, film, _ = s1_full
+    ntiles = 30 * 17
+    for t in (0, 137, 263, 400, 509):       # sky corner, sphere field, ground, bottom edge (partial tile: 1080 = 16*64 + 56)
+        oc = orc.Context(threads=os.cpu_count(), shard_index=t, shard_count=ntiles)
+        s, l = scenes.s1(oc, extent=(1920, 1080))
+        oc.set_pipeline(samples_per_run=1, max_bounces=8, env_samples_per_bounce=1, mesh_samples_per_bounce=1)
+        oc.render(s, l, launches=3)
+        x0, y0 = (t % 30) * 64, (t // 30) * 64
+        a, b = film[y0:y0 + 64, x0:x0 + 64], oc.sensor_data(s)[y0:y0 + 64, x0:x0 + 64]
+        assert a.shape == b.shape and a.size > 0
+        assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), "tile %d differs" % t
+
+
+def test_s1_full_size_batching_and_sharding_invariance(gpu_api, s1_full):
+    """concurrent launches == sequential launches == tile-sharded render, bit for bit, at the benchmark's size"""
+    c, s, l, film, counters = s1_full
+    assert counters["samples"] == 3 * 1920 * 1080
+    c.clear_sensor(s)
+    for _ in range(3):
+        c.render(s, l, launches=1)
+    assert np.array_equal(c.sensor_data(s).view(np.uint32), film.view(np.uint32))
+    assert np.isfinite(film).all() and film[..., :3].min() >= 0.0
+    import ctypes as C
+    G = 2
+    shards = [gpu_api.Context(shard_index=i, shard_count=G) for i in range(G)]
+    hs = []
+    for sc in shards:
+        ss, ll = scenes.s1(sc, extent=(1920, 1080))
+        sc.set_pipeline(samples_per_run=1, max_bounces=8, env_samples_per_bounce=1, mesh_samples_per_bounce=1)
+        sc.render(ss, ll, launches=3, readback=False)
+        hs.append(ss)
+    hip = C.CDLL("libamdhip64.so.7")
+    hip.hipMalloc.argtypes = [C.POINTER(C.c_void_p), C.c_size_t]
+    hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+    n4 = shards[0].packed_film(hs[0])[1]
+    gathered = C.c_void_p()
+    assert hip.hipMalloc(C.byref(gathered), G * n4 * 16) == 0
+    for i, (sc, ss) in enumerate(zip(shards, hs)):
+        assert hip.hipMemcpy(C.c_void_p(gathered.value + i * n4 * 16), C.c_void_p(sc.packed_film(ss)[0]), n4 * 16, 3) == 0
+    shards[0].unpack_gathered(hs[0], gathered.value, G)
+    assert np.array_equal(shards[0].sensor_data(hs[0]).view(np.uint32), film.view(np.uint32))
+    tot = {k: sum(sc.counters()[k] for sc in shards) for k in ("closest_rays", "shadow_rays", "samples")}
+    assert tot == counters
