@@ -119,13 +119,23 @@ struct HdMoonshine {
     // environment
     DevBuf<float4> d_env_rgb; DevBuf<float> d_env_lum; EnvView env{};
     // wavefront
-    PathBuffers paths[2];
-    DevBuf<uint32_t> d_hit_u; DevBuf<float> d_hit_f;
-    DevBuf<float> d_shq_f; DevBuf<uint32_t> d_shq_u;
+    // A pipe = one independent wavefront pipeline (state ping-pong, hit/shadow queues, counters, two streams).  A batch of
+    // launches is split over up to n_pipes pipes that run concurrently: while one pipe is in the thin tail of a bounce
+    // (a few long rays, most CUs idle) the others' bulk work fills the machine.
+    struct Pipe {
+        PathBuffers paths[2];
+        DevBuf<uint32_t> hit_u, shq_u, spill, spill2; DevBuf<float> hit_f, shq_f;
+        DevBuf<Counters> counters;
+        hipStream_t s0 = nullptr, s1 = nullptr;   // s1: k_trace_shadow, overlapped with the next bounce's k_trace_closest
+        size_t cap = 0;
+    };
+    static constexpr int MAX_PIPES = 4;
+    Pipe pipes[MAX_PIPES];
+    int n_pipes = 1;                               // $MSNE_PIPES (measured on S1: more pipes never won — bigger batches beat overlapped smaller ones)
+    size_t single_pipe_paths = 48u << 20;          // batches at least this large run on one pipe (tails are negligible there)
     DevBuf<float4> d_lbuf;
-    size_t wf_cap = 0, lbuf_cap = 0;
-    DevBuf<Counters> d_counters;
-    DevBuf<uint32_t> d_spill; DevBuf<uint32_t> d_overflow; DevBuf<unsigned long long> d_trace_stats;
+    size_t lbuf_cap = 0;
+    DevBuf<uint32_t> d_overflow; DevBuf<unsigned long long> d_trace_stats;
     int trace_grid = 1024, shade_grid = 2048;
     uint32_t tune[4] = { 16, 24, 24, 8 };   // traversal: lane-refill threshold, phase-vote thresholds (node, triangle, instance); $MSNE_TUNE=a,b,c,d
     size_t max_inflight = 160u << 20;  // most paths traced concurrently (276 B of wavefront state each, allocated on demand); $MSNE_MAX_INFLIGHT
@@ -149,7 +159,7 @@ struct HdMoonshine {
     bool upload_materials();
     bool rebuild_accel();
     bool ensure_scene();
-    bool ensure_wavefront(size_t paths, size_t slots);
+    bool ensure_wavefront(size_t paths_per_pipe, size_t slots, int npipes);
     SceneView scene_view() const;
     bool set_background(const float* rgba, Extent2D e);
     bool render(uint32_t sensor, uint32_t lens, uint32_t launches, bool readback);
@@ -442,19 +452,25 @@ bool HdMoonshine::set_background(const float* rgba, Extent2D e) {
 }
 
 // ---------------- wavefront buffers ----------------
-bool HdMoonshine::ensure_wavefront(size_t npaths, size_t slots) {
-    if (npaths > wf_cap) {
-        const size_t c = (npaths + 255) & ~(size_t)255;
-        if (!paths[0].ensure(c) || !paths[1].ensure(c) || !d_hit_u.alloc(3 * c) || !d_hit_f.alloc(2 * c) || !d_shq_f.alloc(7 * 2 * c) || !d_shq_u.alloc(2 * c)) { fail("out of device memory (wavefront state)"); wf_cap = 0; return false; }
-        wf_cap = c;
+bool HdMoonshine::ensure_wavefront(size_t npaths, size_t slots, int npipes) {
+    for (int k = 0; k < npipes; k++) {
+        Pipe& pp = pipes[k];
+        if (!pp.s0 && (hipStreamCreateWithFlags(&pp.s0, hipStreamNonBlocking) != hipSuccess || hipStreamCreateWithFlags(&pp.s1, hipStreamNonBlocking) != hipSuccess)) { fail("cannot create HIP streams"); return false; }
+        if (npaths > pp.cap) {
+            const size_t c = (npaths + 255) & ~(size_t)255;
+            pp.cap = 0;
+            if (!pp.paths[0].ensure(c) || !pp.paths[1].ensure(c) || !pp.hit_u.alloc(3 * c) || !pp.hit_f.alloc(2 * c) || !pp.shq_f.alloc(7 * 2 * c) || !pp.shq_u.alloc(2 * c)) { fail("out of device memory (wavefront state)"); return false; }
+            pp.cap = c;
+        }
+        if (!pp.counters.p) { if (!pp.counters.alloc(1)) return false; if (hipMemsetAsync(pp.counters.p, 0, sizeof(Counters), stream) != hipSuccess) return false; }
+        if (!pp.spill.p && (!pp.spill.alloc(trace_spill_words(trace_grid)) || !pp.spill2.alloc(trace_spill_words(trace_grid)))) { fail("out of device memory (traversal spill)"); return false; }
     }
     if (slots > lbuf_cap) { if (!d_lbuf.alloc(slots)) { fail("out of device memory (sample buffer)"); lbuf_cap = 0; return false; } lbuf_cap = slots; }
-    if (!d_counters.p) { if (!d_counters.alloc(1)) return false; if (hipMemsetAsync(d_counters.p, 0, sizeof(Counters), stream) != hipSuccess) return false; }
-    if (!d_spill.p) {
-        if (!d_spill.alloc(trace_spill_words(trace_grid)) || !d_overflow.alloc(1) || !d_trace_stats.alloc(20)) { fail("out of device memory (traversal spill)"); return false; }
+    if (!d_overflow.p) {
+        if (!d_overflow.alloc(1) || !d_trace_stats.alloc(20)) { fail("out of device memory"); return false; }
         if (hipMemsetAsync(d_overflow.p, 0, 4, stream) != hipSuccess || hipMemsetAsync(d_trace_stats.p, 0, 160, stream) != hipSuccess) return false;
     }
-    return true;
+    return hipStreamSynchronize(stream) == hipSuccess;
 }
 
 static CameraConsts make_camera(const Lens& lens, uint32_t W, uint32_t H) {   // camera.hlsl:14-29, evaluated once per launch instead of per thread
@@ -495,58 +511,101 @@ bool HdMoonshine::render(uint32_t sensor, uint32_t lens, uint32_t launches, bool
     const size_t per_launch = P * (size_t)spr;
     const uint32_t max_batch = per_launch <= max_inflight ? (uint32_t)std::max<size_t>(1, max_inflight / per_launch) : 1u;
     const uint32_t chunk = per_launch <= max_inflight ? spr : (uint32_t)std::max<size_t>(1, max_inflight / P);
-    if (!ensure_wavefront(P * (size_t)chunk * std::min<uint32_t>(max_batch, launches), P * (size_t)chunk * std::min<uint32_t>(max_batch, launches))) return false;
+    const uint32_t first_batch = chunk == spr ? std::min<uint32_t>(max_batch, launches) : 1u;
+    // pipes for a batch of nb launches: one when the batch is huge or cannot be split, else up to n_pipes
+    auto pipes_for = [&](uint32_t nb) -> int { return (chunk != spr || nb < 2 || per_launch * nb >= single_pipe_paths) ? 1 : (int)std::min<uint32_t>((uint32_t)n_pipes, nb); };
+    {
+        const int K = pipes_for(first_batch);
+        const size_t per_pipe = chunk == spr ? per_launch * ((first_batch + K - 1) / K) : P * (size_t)chunk;
+        if (!ensure_wavefront(per_pipe, chunk == spr ? per_launch * first_batch : P * (size_t)chunk, K)) return false;
+    }
     const SceneView sv = scene_view();
     const CameraConsts cam = make_camera(lenses[lens], s->extent.width, s->extent.height);
-    HitBuf hits{ d_hit_u.p, d_hit_u.p + wf_cap, d_hit_u.p + 2 * wf_cap, d_hit_f.p, d_hit_f.p + wf_cap };
-    const size_t qc = 2 * wf_cap;
-    ShadowQueue shq{ d_shq_f.p, d_shq_f.p + qc, d_shq_f.p + 2 * qc, d_shq_f.p + 3 * qc, d_shq_f.p + 4 * qc, d_shq_f.p + 5 * qc, d_shq_f.p + 6 * qc, d_shq_u.p };
-    const PathState st[2] = { paths[0].view(), paths[1].view() };
     events_used = 0; spans.clear();
     hipEvent_t ev_begin = nullptr, ev_end = nullptr;
     ev_begin = next_event(); ev_end = next_event();
     if (ev_begin) (void)hipEventRecord(ev_begin, stream);
-    auto timed = [&](int kind, auto&& fn) {
+    const uint32_t max_iter = opts.max_bounces + 3;   // hits b = 0..max_bounces+1, + one pass to retire zombies
+    auto timed2 = [&](int kind, hipStream_t st_, auto&& fn) {
         if (!profile) { fn(); return; }
         hipEvent_t a = next_event(), b = next_event();
         const size_t ia = events_used - 2, ib = events_used - 1;
-        if (a) (void)hipEventRecord(a, stream);
+        if (a) (void)hipEventRecord(a, st_);
         fn();
-        if (b) (void)hipEventRecord(b, stream);
+        if (b) (void)hipEventRecord(b, st_);
         spans.push_back(Span{ ia, ib, kind });
     };
-    const uint32_t max_iter = opts.max_bounces + 3;   // hits b = 0..max_bounces+1, + one pass to retire zombies
-    // one wavefront pass over `ns` samples per pixel starting at sample index `first_sample`
-    auto trace_pass = [&](uint32_t first_sample, uint32_t ns) -> bool {
-        CHECK_HIP(this, hipMemsetAsync(d_counters.p, 0, 32, stream));   // queue counts + heads
-        launch_raygen(stream, shade_grid, s->shard, cam, opts, first_sample, ns, st[0], d_counters.p);
-        launch_advance(stream, d_counters.p, 1, ns * s->shard.pixels, ns * (s->shard.pixels - s->shard.valid_pixels));
+    // One wavefront pass of a pipe over `ns` samples per pixel starting at sample index `first_sample`; finished samples
+    // go to lbuf[0 .. ns*P).  Two streams per pipe: k_trace_closest / k_shade / bookkeeping on s0, k_trace_shadow on s1 —
+    // the shadow rays of bounce b are only needed by k_shade(b+1), so k_trace_shadow(b) overlaps k_trace_closest(b+1).
+    auto trace_pass = [&](Pipe& pp, uint32_t first_sample, uint32_t ns, float4* lbuf) -> bool {
+        const size_t cap = pp.cap, qc = 2 * cap;
+        const HitBuf hits{ pp.hit_u.p, pp.hit_u.p + cap, pp.hit_u.p + 2 * cap, pp.hit_f.p, pp.hit_f.p + cap };
+        const ShadowQueue shq{ pp.shq_f.p, pp.shq_f.p + qc, pp.shq_f.p + 2 * qc, pp.shq_f.p + 3 * qc, pp.shq_f.p + 4 * qc, pp.shq_f.p + 5 * qc, pp.shq_f.p + 6 * qc, pp.shq_u.p };
+        const PathState st[2] = { pp.paths[0].view(), pp.paths[1].view() };
+        Counters* cnt = pp.counters.p;
+        CHECK_HIP(this, hipMemsetAsync(cnt, 0, 32, pp.s0));   // queue counts + heads
+        launch_raygen(pp.s0, shade_grid, s->shard, cam, opts, first_sample, ns, st[0], cnt);
+        launch_advance(pp.s0, cnt, 1, ns * s->shard.pixels, ns * (s->shard.pixels - s->shard.valid_pixels));
+        hipEvent_t shadow_done = nullptr;
         for (uint32_t b = 0; b < max_iter; b++) {
             const PathState& cur = st[b & 1]; const PathState& nxt = st[(b + 1) & 1];
-            timed(0, [&] { launch_trace_closest(stream, trace_grid, trace_stats, sv, cur, hits, d_counters.p, d_spill.p, d_overflow.p, d_trace_stats.p, tune); });
-            timed(2, [&] { launch_shade(stream, shade_grid, sv, opts, cur, hits, nxt, shq, d_lbuf.p, d_counters.p); });
-            timed(1, [&] { launch_trace_shadow(stream, trace_grid, trace_stats, sv, shq, nxt, d_counters.p, d_spill.p, d_overflow.p, d_trace_stats.p, tune); });
-            launch_advance(stream, d_counters.p, 0, 0, 0);
+            timed2(0, pp.s0, [&] { launch_trace_closest(pp.s0, trace_grid, trace_stats, sv, cur, hits, cnt, pp.spill.p, d_overflow.p, d_trace_stats.p, tune); });
+            if (shadow_done) CHECK_HIP(this, hipStreamWaitEvent(pp.s0, shadow_done, 0));   // k_shade(b) consumes the results of k_trace_shadow(b-1)
+            launch_advance(pp.s0, cnt, 3, 0, 0);
+            timed2(2, pp.s0, [&] { launch_shade(pp.s0, shade_grid, sv, opts, cur, hits, nxt, shq, lbuf, cnt); });
+            launch_advance(pp.s0, cnt, 2, 0, 0);
+            hipEvent_t shade_done = next_event();
+            if (!shade_done) { fail("hipEventCreate failed"); return false; }
+            CHECK_HIP(this, hipEventRecord(shade_done, pp.s0));
+            CHECK_HIP(this, hipStreamWaitEvent(pp.s1, shade_done, 0));
+            timed2(1, pp.s1, [&] { launch_trace_shadow(pp.s1, trace_grid, trace_stats, sv, shq, nxt, cnt, pp.spill2.p, d_overflow.p, d_trace_stats.p, tune); });
+            shadow_done = next_event();
+            if (!shadow_done) { fail("hipEventCreate failed"); return false; }
+            CHECK_HIP(this, hipEventRecord(shadow_done, pp.s1));
             if (b >= 15 && (b & 3) == 3) {   // long tails (max_bounces = 1024 offline): poll the queue length every 4 bounces
                 uint32_t n_cur = 0;
-                CHECK_HIP(this, hipMemcpyAsync(&n_cur, &d_counters.p->n_cur, 4, hipMemcpyDeviceToHost, stream));
-                CHECK_HIP(this, hipStreamSynchronize(stream));
+                CHECK_HIP(this, hipMemcpyAsync(&n_cur, &cnt->n_cur, 4, hipMemcpyDeviceToHost, pp.s0));
+                CHECK_HIP(this, hipStreamSynchronize(pp.s0));
                 if (n_cur == 0) break;
             }
+        }
+        if (shadow_done) CHECK_HIP(this, hipStreamWaitEvent(pp.s0, shadow_done, 0));
+        launch_advance(pp.s0, cnt, 3, 0, 0);
+        return true;
+    };
+    // fork the pipes after everything queued on the main stream so far, join them back before k_film
+    auto run_batch = [&](uint32_t first_sample, uint32_t ns_total, uint32_t ns_unit, int K) -> bool {
+        hipEvent_t fork = next_event();
+        if (!fork) { fail("hipEventCreate failed"); return false; }
+        CHECK_HIP(this, hipEventRecord(fork, stream));
+        const uint32_t units = ns_total / ns_unit;
+        uint32_t u0 = 0;
+        for (int k = 0; k < K; k++) {
+            const uint32_t nu = units / K + ((uint32_t)k < units % K ? 1u : 0u);
+            if (!nu) continue;
+            Pipe& pp = pipes[k];
+            CHECK_HIP(this, hipStreamWaitEvent(pp.s0, fork, 0));
+            if (!trace_pass(pp, first_sample + u0 * ns_unit, nu * ns_unit, d_lbuf.p + (size_t)u0 * ns_unit * P)) return false;
+            hipEvent_t join = next_event();
+            if (!join) { fail("hipEventCreate failed"); return false; }
+            CHECK_HIP(this, hipEventRecord(join, pp.s0));
+            CHECK_HIP(this, hipStreamWaitEvent(stream, join, 0));
+            u0 += nu;
         }
         return true;
     };
     for (uint32_t l = 0; l < launches;) {
         if (chunk == spr) {
             const uint32_t nb = std::min(max_batch, launches - l);
-            if (!trace_pass(s->sample_count, nb * spr)) return false;
+            if (!run_batch(s->sample_count, nb * spr, spr, pipes_for(nb))) return false;
             launch_film(stream, shade_grid, s->shard, opts, d_lbuf.p, spr, nb, 1, 1, s->sample_count, s->color.p, s->film_packed.p);
             s->sample_count += nb * spr;   // hydra.zig:360, nb times
             stats.launches += nb; l += nb;
         } else {
             for (uint32_t s0 = 0; s0 < spr; s0 += chunk) {
                 const uint32_t sc = std::min(chunk, spr - s0);
-                if (!trace_pass(s->sample_count + s0, sc)) return false;
+                if (!run_batch(s->sample_count + s0, sc, sc, 1)) return false;
                 launch_film(stream, shade_grid, s->shard, opts, d_lbuf.p, sc, 1, s0 == 0, s0 + sc == spr, s->sample_count, s->color.p, s->film_packed.p);
             }
             s->sample_count += spr;
@@ -571,6 +630,7 @@ bool HdMoonshine::render(uint32_t sensor, uint32_t lens, uint32_t launches, bool
 HdMoonshine::~HdMoonshine() {
     (void)hipSetDevice(device);
     if (stream) (void)hipStreamSynchronize(stream);
+    for (auto& pp : pipes) { if (pp.s0) { (void)hipStreamSynchronize(pp.s0); (void)hipStreamDestroy(pp.s0); } if (pp.s1) { (void)hipStreamSynchronize(pp.s1); (void)hipStreamDestroy(pp.s1); } }
     for (auto* m : meshes) delete m;
     for (auto* s : sensors) { if (s->host) (void)hipHostFree(s->host); delete s; }
     for (auto e : events) (void)hipEventDestroy(e);
@@ -602,6 +662,8 @@ HdMoonshine* MsneCreate(const MsneConfig* cfg_in) {
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, dev) == hipSuccess) { c->trace_grid = prop.multiProcessorCount * trace_blocks_per_cu(); c->shade_grid = prop.multiProcessorCount * 8; }
     if (const char* e = getenv("MSNE_MAX_INFLIGHT")) c->max_inflight = (size_t)atoll(e);
+    if (const char* e = getenv("MSNE_PIPES")) c->n_pipes = std::max(1, std::min((int)HdMoonshine::MAX_PIPES, atoi(e)));
+    if (const char* e = getenv("MSNE_SINGLE_PIPE_PATHS")) c->single_pipe_paths = (size_t)atoll(e);
     if (const char* e = getenv("MSNE_TUNE")) { unsigned a, b, d, f; if (sscanf(e, "%u,%u,%u,%u", &a, &b, &d, &f) == 4) { c->tune[0] = a; c->tune[1] = b; c->tune[2] = d; c->tune[3] = f; } }
     if (const char* e = getenv("MSNE_TRACE_BLOCKS_PER_CU")) c->trace_grid = prop.multiProcessorCount * atoi(e);
     c->opts = PipelineOpts{ 1, 1024, 0, 0, 0, 0, 0 };                 // hydra.zig:97-105
@@ -747,7 +809,10 @@ int MsneReserve(HdMoonshine* c, SensorHandle sh, uint32_t launches) {
     if (per_launch == 0) return 0;
     const size_t nb = per_launch <= c->max_inflight ? std::min<size_t>(std::max<size_t>(1, c->max_inflight / per_launch), std::max<uint32_t>(launches, 1)) : 1;
     const size_t n = per_launch <= c->max_inflight ? per_launch * nb : P * std::max<size_t>(1, c->max_inflight / P);
-    return c->ensure_wavefront(n, n) ? 0 : -1;
+    const uint32_t nbu = (uint32_t)nb;
+    const int K = (per_launch > c->max_inflight || nbu < 2 || per_launch * nbu >= c->single_pipe_paths) ? 1 : (int)std::min<uint32_t>((uint32_t)c->n_pipes, nbu);
+    const size_t per_pipe = per_launch <= c->max_inflight ? per_launch * ((nbu + K - 1) / K) : n;
+    return c->ensure_wavefront(per_pipe, n, K) ? 0 : -1;
 }
 int MsneRender(HdMoonshine* c, SensorHandle s, LensHandle l, uint32_t launches, int readback) {
     LOCK(c);
@@ -775,10 +840,12 @@ int MsneGetStats(const HdMoonshine* cc, MsneStats* out) {
     LOCK(c);
     if (!out || !c->bind()) return -1;
     *out = c->stats;
-    if (c->d_counters.p) {
+    out->closest_rays = out->shadow_rays = out->samples = 0;
+    for (auto& pp : c->pipes) {
+        if (!pp.counters.p) continue;
         Counters h{};
-        if (hipMemcpy(&h, c->d_counters.p, sizeof h, hipMemcpyDeviceToHost) != hipSuccess) return -1;
-        out->closest_rays = h.closest_rays; out->shadow_rays = h.shadow_rays; out->samples = h.samples;
+        if (hipMemcpy(&h, pp.counters.p, sizeof h, hipMemcpyDeviceToHost) != hipSuccess) return -1;
+        out->closest_rays += h.closest_rays; out->shadow_rays += h.shadow_rays; out->samples += h.samples;
     }
     return 0;
 }
@@ -786,7 +853,7 @@ void MsneResetStats(HdMoonshine* c) {
     LOCK(c);
     if (!c->bind()) return;
     c->stats = MsneStats{};
-    if (c->d_counters.p) (void)hipMemset(c->d_counters.p, 0, sizeof(Counters));
+    for (auto& pp : c->pipes) if (pp.counters.p) (void)hipMemset(pp.counters.p, 0, sizeof(Counters));
     if (c->d_trace_stats.p) (void)hipMemset(c->d_trace_stats.p, 0, 160);
 }
 
@@ -803,13 +870,13 @@ int MsneGetTraversalCounters(HdMoonshine* c, uint64_t out[20]) {   // [0..3] clo
 // rays: 7 floats each (origin, direction, tmax); out_ids 4 per ray {hit, instance, geometry, primitive}; out_tuv 3 per ray
 int MsneTraceRays(HdMoonshine* c, const float* rays, uint32_t n, int any_hit, uint32_t* out_ids, float* out_tuv) {
     LOCK(c);
-    if (!c->bind() || !c->ensure_scene() || !c->ensure_wavefront(1, 1)) return -1;
+    if (!c->bind() || !c->ensure_scene() || !c->ensure_wavefront(1, 1, 1)) return -1;
     if (n == 0) return 0;
     DevBuf<float> dr; DevBuf<uint32_t> di; DevBuf<float> dt;
     if (!dr.alloc(7 * (size_t)n) || !di.alloc(4 * (size_t)n) || !dt.alloc(3 * (size_t)n)) { c->fail("out of device memory (probe)"); return -1; }
     if (hipMemcpyAsync(dr.p, rays, 28 * (size_t)n, hipMemcpyHostToDevice, c->stream) != hipSuccess) return -1;
-    if (hipMemsetAsync(&c->d_counters.p->head_closest, 0, 4, c->stream) != hipSuccess) return -1;
-    launch_trace_probe(c->stream, c->trace_grid, c->scene_view(), dr.p, n, any_hit, &c->d_counters.p->head_closest, di.p, dt.p, c->d_spill.p, c->d_overflow.p, c->tune);
+    if (hipMemsetAsync(&c->pipes[0].counters.p->head_closest, 0, 4, c->stream) != hipSuccess) return -1;
+    launch_trace_probe(c->stream, c->trace_grid, c->scene_view(), dr.p, n, any_hit, &c->pipes[0].counters.p->head_closest, di.p, dt.p, c->pipes[0].spill.p, c->d_overflow.p, c->tune);
     if (hipMemcpyAsync(out_ids, di.p, 16 * (size_t)n, hipMemcpyDeviceToHost, c->stream) != hipSuccess) return -1;
     if (hipMemcpyAsync(out_tuv, dt.p, 12 * (size_t)n, hipMemcpyDeviceToHost, c->stream) != hipSuccess) return -1;
     if (hipStreamSynchronize(c->stream) != hipSuccess) { c->fail("probe failed"); return -1; }

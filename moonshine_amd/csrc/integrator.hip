@@ -248,18 +248,24 @@ __global__ __launch_bounds__(SHADE_BLOCK) void k_shade(SceneView sc, PipelineOpt
     }
 }
 
-// between bounces: account the rays just traced, rotate the queues, reset the dequeue heads
-__global__ void k_advance(Counters* cnt, int after_raygen, uint32_t total, uint32_t masked) {
+// queue bookkeeping between the kernels of a bounce
+// mode 1: after k_raygen (slots [0,total) filled, `masked` of them outside the image)
+// mode 2: after k_shade(b)  — rotate the path queue: what k_shade appended becomes the queue of k_trace_closest(b+1)
+// mode 3: before k_shade(b) — k_trace_shadow(b-1) is done: account its rays, free the shadow queue
+// (2 and 3 are separate so that k_trace_shadow(b) can overlap k_trace_closest(b+1) on a second stream)
+__global__ void k_advance(Counters* cnt, int mode, uint32_t total, uint32_t masked) {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
-    if (after_raygen) {   // k_raygen filled slots [0,total); `masked` of them lie outside the image
+    if (mode == 1) {
         cnt->n_cur = total; cnt->samples += total - masked; cnt->zombies_cur = masked; cnt->zombies_next = 0;
-        cnt->n_next = 0; cnt->n_shadow = 0; cnt->head_closest = 0; cnt->head_shadow = 0; return;
+        cnt->n_next = 0; cnt->n_shadow = 0; cnt->head_closest = 0; cnt->head_shadow = 0;
+    } else if (mode == 2) {
+        cnt->closest_rays += cnt->n_cur - cnt->zombies_cur;
+        cnt->zombies_cur = cnt->zombies_next; cnt->zombies_next = 0;
+        cnt->n_cur = cnt->n_next; cnt->n_next = 0; cnt->head_closest = 0;
+    } else {
+        cnt->shadow_rays += cnt->n_shadow;
+        cnt->n_shadow = 0; cnt->head_shadow = 0;
     }
-    cnt->closest_rays += cnt->n_cur - cnt->zombies_cur;
-    cnt->zombies_cur = cnt->zombies_next; cnt->zombies_next = 0;
-    cnt->shadow_rays += cnt->n_shadow;
-    cnt->n_cur = cnt->n_next; cnt->n_next = 0; cnt->n_shadow = 0;
-    cnt->head_closest = 0; cnt->head_shadow = 0;
 }
 
 // storeColor main.hlsl:43-51 over the `s_count` samples of this chunk (summed in sample order, main.hlsl:83-92)
@@ -313,7 +319,7 @@ void launch_raygen(hipStream_t s, int grid, const ShardView& sh, const CameraCon
 void launch_shade(hipStream_t s, int grid, const SceneView& sc, const PipelineOpts& o, const PathState& cur, const HitBuf& hits, const PathState& nxt, const ShadowQueue& q, float4* lbuf, Counters* cnt) {
     hipLaunchKernelGGL(k_shade, dim3(grid), dim3(SHADE_BLOCK), 0, s, sc, o, cur, hits, nxt, q, lbuf, cnt);
 }
-void launch_advance(hipStream_t s, Counters* cnt, int after_raygen, uint32_t total, uint32_t masked) { hipLaunchKernelGGL(k_advance, dim3(1), dim3(1), 0, s, cnt, after_raygen, total, masked); }
+void launch_advance(hipStream_t s, Counters* cnt, int mode, uint32_t total, uint32_t masked) { hipLaunchKernelGGL(k_advance, dim3(1), dim3(1), 0, s, cnt, mode, total, masked); }
 void launch_film(hipStream_t s, int grid, const ShardView& sh, const PipelineOpts& o, const float4* lbuf, uint32_t s_count, uint32_t n_launches, int first_chunk, int last_chunk, uint32_t sample_count, float4* color, float4* film) {
     hipLaunchKernelGGL(k_film, dim3(grid), dim3(SHADE_BLOCK), 0, s, sh, o, lbuf, s_count, n_launches, first_chunk, last_chunk, sample_count, color, film);
 }
