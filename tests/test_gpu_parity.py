@@ -336,3 +336,51 @@ def test_s1_full_size_batching_and_sharding_invariance(gpu_api, s1_full):
     assert np.array_equal(shards[0].sensor_data(hs[0]).view(np.uint32), film.view(np.uint32))
     tot = {k: sum(sc.counters()[k] for sc in shards) for k in ("closest_rays", "shadow_rays", "samples")}
     assert tot == counters
+
+
+def test_hydra_mode_face_varying_attributes(orc, gpu_api):
+    """Hydra's pipeline constants (hydra.zig:97-105): indexed_attributes=false (normals/uvs are per face corner,
+    world.hlsl:130), raw three-component normal texture (material.hlsl:509-514), no flip, f16x4 textures (hydra.zig:47-52)."""
+    P, I = scenes.icosphere(3)
+    corner = I.reshape(-1)
+    fvn = P[corner] / np.linalg.norm(P[corner], axis=1, keepdims=True)
+    fvt = np.stack([np.arctan2(P[corner, 1], P[corner, 0]) / (2 * math.pi) + 0.5, np.arccos(np.clip(P[corner, 2], -1, 1)) / math.pi], -1).astype(np.float32)
+    rs = np.random.default_rng(3)
+    half = rs.random((8, 8, 4)).astype(np.float16)
+    imgs = []
+    for c in (gpu_api.Context(), orc.Context(threads=8)):
+        mesh = c.create_mesh(P, I, normals=fvn, texcoords=fvt)
+        col = c.create_texture(half, 8, 8, "r16g16b16a16_sfloat")
+        m = c.create_material(scenes.STANDARD_PBR, c.solid_texture(0.05, -0.03, 1.0), c.solid_texture(0.0, 0.0, 0.0), color=col,
+                              metalness=c.solid_texture(0.2), roughness=c.solid_texture(0.5), ior=1.5)
+        c.create_instance([(mesh, m, False)])
+        c.set_pipeline(samples_per_run=1, max_bounces=1024, env_samples_per_bounce=0, mesh_samples_per_bounce=0,
+                       flip_image=False, indexed_attributes=False, two_component_normal_texture=False)
+        s = c.create_sensor(64, 48); l = c.create_lens(c.make_lens((-3, 0.2, 0.4), (1, 0, 0), (0, 0, 1), 0.8))
+        c.render(s, l, launches=8)
+        imgs.append(c.sensor_data(s))
+    assert_film_equal(imgs[0], imgs[1], "hydra mode")
+
+
+def test_launch_larger_than_inflight_budget(orc, gpu_api, monkeypatch):
+    """a launch whose samples do not fit the in-flight budget is traced in chunks of its samples (same film, same counters)"""
+    monkeypatch.setenv("MSNE_MAX_INFLIGHT", "10000")      # 64x48 pixels -> chunks of 3 samples out of 8
+    gc = gpu_api.Context(); oc = orc.Context(threads=8)
+    imgs = []
+    for c in (gc, oc):
+        s, l = scenes.cornell(c, extent=(64, 48))
+        c.set_pipeline(samples_per_run=8, max_bounces=6, env_samples_per_bounce=0, mesh_samples_per_bounce=1)
+        c.render(s, l, launches=2)
+        imgs.append(c.sensor_data(s))
+    assert_film_equal(imgs[0], imgs[1], "chunked launch")
+    assert gc.counters() == {k: v for k, v in oc.counters().items() if k in ("closest_rays", "shadow_rays", "samples")}
+
+
+def test_unsupported_pipeline_is_rejected_loudly(gpu_api):
+    gc = gpu_api.Context()
+    with pytest.raises(gpu_api.MoonshineError, match="more than one"):
+        gc.set_pipeline(env_samples_per_bounce=2)
+    with pytest.raises(gpu_api.MoonshineError):
+        gc.create_material(scenes.LAMBERT, 999, 0)
+    with pytest.raises(gpu_api.MoonshineError):
+        gc.create_mesh(np.zeros((3, 3), np.float32), [[0, 1, 7]])
