@@ -70,19 +70,20 @@ struct SensorH {
 };
 
 struct PathBuffers {
-    DevBuf<float> f;      // 19 float arrays
-    DevBuf<uint32_t> u;   // 3 uint arrays
+    DevBuf<float> f;      // ro, rd (float4 each) + 13 float arrays
+    DevBuf<uint32_t> u;   // rng, slot
     size_t cap = 0;
     PathState view() const {
         PathState s; float* b = f.p; size_t c = cap;
-        s.ox = b + 0 * c; s.oy = b + 1 * c; s.oz = b + 2 * c; s.dx = b + 3 * c; s.dy = b + 4 * c; s.dz = b + 5 * c;
-        s.tx = b + 6 * c; s.ty = b + 7 * c; s.tz = b + 8 * c; s.lx = b + 9 * c; s.ly = b + 10 * c; s.lz = b + 11 * c;
-        s.p0x = b + 12 * c; s.p0y = b + 13 * c; s.p0z = b + 14 * c; s.p1x = b + 15 * c; s.p1y = b + 16 * c; s.p1z = b + 17 * c;
-        s.last_pdf = b + 18 * c;
-        s.rng = u.p; s.slot = u.p + c; s.flags = u.p + 2 * c;
+        s.ro = reinterpret_cast<float4*>(b); s.rd = reinterpret_cast<float4*>(b + 4 * c);
+        b += 8 * c;
+        s.tx = b + 0 * c; s.ty = b + 1 * c; s.tz = b + 2 * c; s.lx = b + 3 * c; s.ly = b + 4 * c; s.lz = b + 5 * c;
+        s.p0x = b + 6 * c; s.p0y = b + 7 * c; s.p0z = b + 8 * c; s.p1x = b + 9 * c; s.p1y = b + 10 * c; s.p1z = b + 11 * c;
+        s.last_pdf = b + 12 * c;
+        s.rng = u.p; s.slot = u.p + c;
         return s;
     }
-    bool ensure(size_t c) { if (c <= cap) return true; cap = 0; if (!f.alloc(19 * c) || !u.alloc(3 * c)) return false; cap = c; return true; }
+    bool ensure(size_t c) { if (c <= cap) return true; cap = 0; if (!f.alloc(21 * c) || !u.alloc(2 * c)) return false; cap = c; return true; }
 };
 
 }  // namespace
@@ -124,7 +125,7 @@ struct HdMoonshine {
     // (a few long rays, most CUs idle) the others' bulk work fills the machine.
     struct Pipe {
         PathBuffers paths[2];
-        DevBuf<uint32_t> hit_u, shq_u, spill, spill2; DevBuf<float> hit_f, shq_f;
+        DevBuf<uint32_t> hit_u, spill, spill2; DevBuf<float> shq_f;
         DevBuf<Counters> counters;
         hipStream_t s0 = nullptr, s1 = nullptr;   // s1: k_trace_shadow, overlapped with the next bounce's k_trace_closest
         size_t cap = 0;
@@ -459,7 +460,7 @@ bool HdMoonshine::ensure_wavefront(size_t npaths, size_t slots, int npipes) {
         if (npaths > pp.cap) {
             const size_t c = (npaths + 255) & ~(size_t)255;
             pp.cap = 0;
-            if (!pp.paths[0].ensure(c) || !pp.paths[1].ensure(c) || !pp.hit_u.alloc(3 * c) || !pp.hit_f.alloc(2 * c) || !pp.shq_f.alloc(7 * 2 * c) || !pp.shq_u.alloc(2 * c)) { fail("out of device memory (wavefront state)"); return false; }
+            if (!pp.paths[0].ensure(c) || !pp.paths[1].ensure(c) || !pp.hit_u.alloc(5 * c) || !pp.shq_f.alloc(8 * 2 * c)) { fail("out of device memory (wavefront state)"); return false; }
             pp.cap = c;
         }
         if (!pp.counters.p) { if (!pp.counters.alloc(1)) return false; if (hipMemsetAsync(pp.counters.p, 0, sizeof(Counters), stream) != hipSuccess) return false; }
@@ -540,8 +541,8 @@ bool HdMoonshine::render(uint32_t sensor, uint32_t lens, uint32_t launches, bool
     // the shadow rays of bounce b are only needed by k_shade(b+1), so k_trace_shadow(b) overlaps k_trace_closest(b+1).
     auto trace_pass = [&](Pipe& pp, uint32_t first_sample, uint32_t ns, float4* lbuf) -> bool {
         const size_t cap = pp.cap, qc = 2 * cap;
-        const HitBuf hits{ pp.hit_u.p, pp.hit_u.p + cap, pp.hit_u.p + 2 * cap, pp.hit_f.p, pp.hit_f.p + cap };
-        const ShadowQueue shq{ pp.shq_f.p, pp.shq_f.p + qc, pp.shq_f.p + 2 * qc, pp.shq_f.p + 3 * qc, pp.shq_f.p + 4 * qc, pp.shq_f.p + 5 * qc, pp.shq_f.p + 6 * qc, pp.shq_u.p };
+        const HitBuf hits{ reinterpret_cast<uint4*>(pp.hit_u.p), pp.hit_u.p + 4 * cap };
+        const ShadowQueue shq{ reinterpret_cast<float4*>(pp.shq_f.p), reinterpret_cast<float4*>(pp.shq_f.p + 4 * qc) };
         const PathState st[2] = { pp.paths[0].view(), pp.paths[1].view() };
         Counters* cnt = pp.counters.p;
         CHECK_HIP(this, hipMemsetAsync(cnt, 0, 32, pp.s0));   // queue counts + heads

@@ -42,7 +42,7 @@ __global__ __launch_bounds__(SHADE_BLOCK) void k_raygen(ShardView sh, CameraCons
     for (uint32_t slot = blockIdx.x * SHADE_BLOCK + threadIdx.x; slot < total; slot += gridDim.x * SHADE_BLOCK) {
         uint32_t x = 0, y = 0;
         const uint32_t i = slot;
-        if (!shard_pixel(sh, slot % sh.pixels, x, y)) { st.flags[i] = PATH_FLAG_ZOMBIE | PATH_FLAG_MASKED; st.slot[i] = slot; continue; }
+        if (!shard_pixel(sh, slot % sh.pixels, x, y)) { st.ro[i] = make_float4(0.0f, 0.0f, 0.0f, u2f(PATH_FLAG_ZOMBIE | PATH_FLAG_MASKED)); st.slot[i] = slot; continue; }
         const uint32_t s_local = slot / sh.pixels;
         uint32_t rng = rng_seed(sample_base + s_local, x, y);                       // main.hlsl:85
         f2 r1; r1.x = rng_float(rng); r1.y = rng_float(rng);
@@ -56,11 +56,11 @@ __global__ __launch_bounds__(SHADE_BLOCK) void k_raygen(ShardView sh, CameraCons
         const f3 defocus = add(scale(cam.u, rd.x), scale(cam.v, rd.y));
         const f3 O = add(cam.origin, defocus);
         const f3 D = normalize(sub(sub(add(add(cam.llc, scale(cam.horizontal, uv.x)), scale(cam.vertical, uv.y)), defocus), cam.origin));
-        st.ox[i] = O.x; st.oy[i] = O.y; st.oz[i] = O.z; st.dx[i] = D.x; st.dy[i] = D.y; st.dz[i] = D.z;
+        st.ro[i] = make_float4(O.x, O.y, O.z, u2f(0u)); st.rd[i] = make_float4(D.x, D.y, D.z, 0.0f);
         st.tx[i] = 1.0f; st.ty[i] = 1.0f; st.tz[i] = 1.0f;
         st.lx[i] = 0.0f; st.ly[i] = 0.0f; st.lz[i] = 0.0f;
         st.p0x[i] = 0.0f; st.p0y[i] = 0.0f; st.p0z[i] = 0.0f; st.p1x[i] = 0.0f; st.p1y[i] = 0.0f; st.p1z[i] = 0.0f;
-        st.last_pdf[i] = 0.0f; st.rng[i] = rng; st.slot[i] = slot; st.flags[i] = 0u;
+        st.last_pdf[i] = 0.0f; st.rng[i] = rng; st.slot[i] = slot;
     }
 }
 
@@ -94,7 +94,9 @@ __global__ __launch_bounds__(SHADE_BLOCK) void k_shade(SceneView sc, PipelineOpt
     const unsigned long long lt = lane == 0 ? 0ull : (~0ull >> (64 - lane));
     const uint32_t n_pad = (n + (SHADE_BLOCK - 1u)) & ~(SHADE_BLOCK - 1u);   // trip count uniform per workgroup (it synchronises below)
     for (uint32_t i = blockIdx.x * SHADE_BLOCK + threadIdx.x; i < n_pad; i += gridDim.x * SHADE_BLOCK) {
-        const bool live = i < n && !(cur.flags[i] & PATH_FLAG_MASKED);
+        float4 ro4 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        if (i < n) ro4 = cur.ro[i];
+        const bool live = i < n && !(f2u(ro4.w) & PATH_FLAG_MASKED);
         bool cont = false, sh0 = false, sh1 = false;
         // state carried to the next bounce
         f3 rayO = F3(0, 0, 0), rayD = F3(0, 0, 1), throughput = F3(0, 0, 0), L = F3(0, 0, 0), c0 = F3(0, 0, 0), c1 = F3(0, 0, 0);
@@ -102,17 +104,18 @@ __global__ __launch_bounds__(SHADE_BLOCK) void k_shade(SceneView sc, PipelineOpt
         float s0t = 0.0f, s1t = 0.0f, lastPdf = 0.0f;
         uint32_t rng = 0, slot = 0, flags = 0;
         if (live) {
-            rayO = F3(cur.ox[i], cur.oy[i], cur.oz[i]); rayD = F3(cur.dx[i], cur.dy[i], cur.dz[i]);
+            { const float4 rd4 = cur.rd[i]; rayO = F3(ro4.x, ro4.y, ro4.z); rayD = F3(rd4.x, rd4.y, rd4.z); }
             throughput = F3(cur.tx[i], cur.ty[i], cur.tz[i]);
             L = F3(cur.lx[i], cur.ly[i], cur.lz[i]);
-            lastPdf = cur.last_pdf[i]; rng = cur.rng[i]; slot = cur.slot[i]; flags = cur.flags[i];
+            lastPdf = cur.last_pdf[i]; rng = cur.rng[i]; slot = cur.slot[i]; flags = f2u(ro4.w);
             // light samples of the previous bounce, in the reference's order (env, then mesh)
             L = add(L, F3(cur.p0x[i], cur.p0y[i], cur.p0z[i]));
             L = add(L, F3(cur.p1x[i], cur.p1y[i], cur.p1z[i]));
             const uint32_t bounceCount = flags & 0xFFFFu;
             const bool isLastMaterialDelta = (flags & PATH_FLAG_DELTA) != 0;
             bool done = (flags & PATH_FLAG_ZOMBIE) != 0;
-            const uint32_t hinst = hits.inst[i];
+            const uint4 hrec = hits.rec[i];
+            const uint32_t hinst = hrec.x;
             if (!done && hinst == MAX_UINT) {
                 // miss epilogue, integrator.hlsl:168-181
                 if (env_n == 0 || bounceCount == 0 || isLastMaterialDelta) L = add(L, mul(throughput, env_incoming_radiance(sc.env, rayD)));
@@ -124,9 +127,9 @@ __global__ __launch_bounds__(SHADE_BLOCK) void k_shade(SceneView sc, PipelineOpt
                 done = true;
             }
             if (!done) {
-                const uint32_t hgeo = hits.geo[i], hprim = hits.prim[i];
+                const uint32_t hgeo = hits.geo[i], hprim = hrec.y;
                 GeometryRec geometry;
-                const Attrs attrs = mesh_attributes_world(sc, opts.indexed_attributes != 0, hinst, hgeo, hprim, F2(hits.u[i], hits.v[i]), geometry);
+                const Attrs attrs = mesh_attributes_world(sc, opts.indexed_attributes != 0, hinst, hgeo, hprim, F2(u2f(hrec.z), u2f(hrec.w)), geometry);
                 const MaterialRec mrec = sc.materials[geometry.material];
                 const Frame textureFrame = get_texture_frame(sc, mrec, opts.two_component_normal_texture != 0, attrs.texcoord, attrs.frame);
                 const f3 emissiveLight = tex_sample_rgb(sc, mrec.emissive, attrs.texcoord);
@@ -235,16 +238,16 @@ __global__ __launch_bounds__(SHADE_BLOCK) void k_shade(SceneView sc, PipelineOpt
         const uint32_t j = (uint32_t)base + (uint32_t)__popcll(mc & lt);
         const uint32_t qb = (uint32_t)(base >> 32);
         if (cont) {
-            nxt.ox[j] = rayO.x; nxt.oy[j] = rayO.y; nxt.oz[j] = rayO.z; nxt.dx[j] = rayD.x; nxt.dy[j] = rayD.y; nxt.dz[j] = rayD.z;
+            nxt.ro[j] = make_float4(rayO.x, rayO.y, rayO.z, u2f(flags)); nxt.rd[j] = make_float4(rayD.x, rayD.y, rayD.z, 0.0f);
             nxt.tx[j] = throughput.x; nxt.ty[j] = throughput.y; nxt.tz[j] = throughput.z;
             nxt.lx[j] = L.x; nxt.ly[j] = L.y; nxt.lz[j] = L.z;
             nxt.p0x[j] = c0.x; nxt.p0y[j] = c0.y; nxt.p0z[j] = c0.z; nxt.p1x[j] = c1.x; nxt.p1y[j] = c1.y; nxt.p1z[j] = c1.z;
-            nxt.last_pdf[j] = lastPdf; nxt.rng[j] = rng; nxt.slot[j] = slot; nxt.flags[j] = flags;
+            nxt.last_pdf[j] = lastPdf; nxt.rng[j] = rng; nxt.slot[j] = slot;
         }
         const uint32_t q0 = qb + (uint32_t)__popcll(m0 & lt);
-        if (sh0) { shq.ox[q0] = s0o.x; shq.oy[q0] = s0o.y; shq.oz[q0] = s0o.z; shq.dx[q0] = s0d.x; shq.dy[q0] = s0d.y; shq.dz[q0] = s0d.z; shq.tmax[q0] = s0t; shq.target[q0] = (j << 1); }
+        if (sh0) { shq.o[q0] = make_float4(s0o.x, s0o.y, s0o.z, s0t); shq.d[q0] = make_float4(s0d.x, s0d.y, s0d.z, u2f(j << 1)); }
         const uint32_t q1 = qb + w0 + (uint32_t)__popcll(m1 & lt);
-        if (sh1) { shq.ox[q1] = s1o.x; shq.oy[q1] = s1o.y; shq.oz[q1] = s1o.z; shq.dx[q1] = s1d.x; shq.dy[q1] = s1d.y; shq.dz[q1] = s1d.z; shq.tmax[q1] = s1t; shq.target[q1] = (j << 1) | 1u; }
+        if (sh1) { shq.o[q1] = make_float4(s1o.x, s1o.y, s1o.z, s1t); shq.d[q1] = make_float4(s1d.x, s1d.y, s1d.z, u2f((j << 1) | 1u)); }
     }
 }
 

@@ -75,8 +75,8 @@ constexpr uint32_t INST_FLAG_VISIBLE = 1u, INST_FLAG_IDENTITY = 2u, INST_FLAG_WO
 
 // ---- wavefront state (SoA, one slot per in-flight path; two sets ping-pong between bounces) ----
 struct PathState {
-    float* ox; float* oy; float* oz;
-    float* dx; float* dy; float* dz;
+    float4* ro;                          // ray origin xyz | w = flags (bit pattern): the trace kernels fetch a ray with 2 x 16-B loads
+    float4* rd;                          // ray direction xyz | w unused
     float* tx; float* ty; float* tz;     // throughput
     float* lx; float* ly; float* lz;     // accumulated radiance
     float* p0x; float* p0y; float* p0z;  // pending env-NEE contribution (zeroed by k_trace_shadow if occluded)
@@ -84,18 +84,18 @@ struct PathState {
     float* last_pdf;
     uint32_t* rng;
     uint32_t* slot;                      // sample slot: s_local * pixels + pixel_local
-    uint32_t* flags;                     // bits 0..15 bounce count, bit 16 last material delta, bit 17 zombie (finalize only)
+    // flags (in ro.w): bits 0..15 bounce count, bit 16 last material delta, bit 17 zombie (finalize only), bit 18 masked
 };
 constexpr uint32_t PATH_FLAG_DELTA = 1u << 16;
 constexpr uint32_t PATH_FLAG_ZOMBIE = 1u << 17;
 constexpr uint32_t PATH_FLAG_MASKED = 1u << 18;   // slot of a pixel outside the image (edge tiles): dropped by the first k_shade
-constexpr int PATH_STATE_WORDS = 22;
+constexpr int PATH_STATE_WORDS = 23;
 
-struct HitBuf { uint32_t* inst; uint32_t* geo; uint32_t* prim; float* u; float* v; };
+struct HitBuf { uint4* rec; uint32_t* geo; };   // rec = {instance, primitive, u bits, v bits}: one 16-B store per finished ray (+ geo)
 
 struct ShadowQueue {
-    float* ox; float* oy; float* oz; float* dx; float* dy; float* dz; float* tmax;
-    uint32_t* target;   // (next-state index << 1) | which (0 env, 1 mesh)
+    float4* o;   // origin xyz | w = tmax
+    float4* d;   // direction xyz | w = target bits: (next-state index << 1) | which (0 env, 1 mesh)
 };
 
 // device-side counters; one instance per context

@@ -337,12 +337,14 @@ __global__ __launch_bounds__(TRACE_BLOCK, TRACE_WPS) void k_trace_closest(SceneV
     unsigned long long nv = 0, nt = 0;
     trace_wave_loop<false, STATS>(sc, n, &cnt->head_closest, lds_stack, spill, overflow, tune,
         [&](uint32_t i, f3& o, f3& d, float& tmax) -> bool {
-            if (st.flags[i] & PATH_FLAG_ZOMBIE) return false;
-            o = F3(st.ox[i], st.oy[i], st.oz[i]); d = F3(st.dx[i], st.dy[i], st.dz[i]); tmax = INFINITY_F;
+            const float4 ro = st.ro[i];
+            if (f2u(ro.w) & PATH_FLAG_ZOMBIE) return false;
+            const float4 rd = st.rd[i];
+            o = F3(ro.x, ro.y, ro.z); d = F3(rd.x, rd.y, rd.z); tmax = INFINITY_F;
             return true;
         },
         [&](uint32_t i, const Lane& L) {
-            hits.inst[i] = L.best.inst; hits.geo[i] = L.best.geo; hits.prim[i] = L.best.prim; hits.u[i] = L.best.u; hits.v[i] = L.best.v;
+            hits.rec[i] = make_uint4(L.best.inst, L.best.prim, f2u(L.best.u), f2u(L.best.v)); hits.geo[i] = L.best.geo;
         }, nv, nt, stat_out + 4);
     if (STATS) { atomicAdd(&stat_out[0], nv); atomicAdd(&stat_out[1], nt); }
 }
@@ -355,12 +357,13 @@ __global__ __launch_bounds__(TRACE_BLOCK, TRACE_WPS) void k_trace_shadow(SceneVi
     unsigned long long nv = 0, nt = 0;
     trace_wave_loop<true, STATS>(sc, n, &cnt->head_shadow, lds_stack, spill, overflow, tune,
         [&](uint32_t i, f3& o, f3& d, float& tmax) -> bool {
-            o = F3(q.ox[i], q.oy[i], q.oz[i]); d = F3(q.dx[i], q.dy[i], q.dz[i]); tmax = q.tmax[i];
+            const float4 qo = q.o[i], qd = q.d[i];
+            o = F3(qo.x, qo.y, qo.z); d = F3(qd.x, qd.y, qd.z); tmax = qo.w;
             return true;
         },
         [&](uint32_t i, const Lane& L) {
             if (L.best.inst != MAX_UINT) {   // ShadowIntersection::hit → lightSample.pdf = 0 (light.hlsl:75-77,154-156): the pending contribution vanishes
-                const uint32_t tg = q.target[i], j = tg >> 1;
+                const uint32_t tg = f2u(q.d[i].w), j = tg >> 1;
                 if (tg & 1u) { next.p1x[j] = 0.0f; next.p1y[j] = 0.0f; next.p1z[j] = 0.0f; }
                 else { next.p0x[j] = 0.0f; next.p0y[j] = 0.0f; next.p0z[j] = 0.0f; }
             }
