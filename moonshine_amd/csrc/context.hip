@@ -207,7 +207,7 @@ static int64_t add_texture(HdMoonshine* c, const void* bytes, uint32_t w, uint32
 bool HdMoonshine::upload_textures() {
     size_t total = 0;
     std::vector<TexDesc> desc(textures.size());
-    for (size_t i = 0; i < textures.size(); i++) { desc[i] = TexDesc{ (uint32_t)total, textures[i].w, textures[i].h, 0 }; total += (size_t)textures[i].w * textures[i].h; }
+    for (size_t i = 0; i < textures.size(); i++) { desc[i] = TexDesc{ (uint32_t)total, textures[i].w, textures[i].h, 0, make_float4(textures[i].rgba[0], textures[i].rgba[1], textures[i].rgba[2], textures[i].rgba[3]) }; total += (size_t)textures[i].w * textures[i].h; }
     if (!d_texels.alloc(total) || !d_texdesc.alloc(desc.size())) { fail("out of device memory (textures)"); return false; }
     for (size_t i = 0; i < textures.size(); i++)
         CHECK_HIP(this, hipMemcpyAsync(d_texels.p + desc[i].offset, textures[i].rgba.data(), textures[i].rgba.size() * 4, hipMemcpyHostToDevice, stream));
@@ -268,6 +268,7 @@ bool HdMoonshine::rebuild_accel() {
     // flat geometry table + per-instance offsets (Accel.zig:362-412)
     std::vector<GeometryRec> geos; std::vector<uint32_t> geo_offset(instances.size());
     for (size_t i = 0; i < instances.size(); i++) { geo_offset[i] = (uint32_t)geos.size(); for (auto& g : instances[i].geos) geos.push_back(g); }
+    for (auto& g : geos) if (g.mesh < meshes.size()) g.sampled = (g.sampled ? GEO_SAMPLED : 0u) | (meshes[g.mesh]->has_texcoords ? GEO_HAS_TEXCOORDS : 0u) | (meshes[g.mesh]->has_normals ? GEO_HAS_NORMALS : 0u);
     for (auto& g : geos) {
         if (g.mesh >= meshes.size()) { fail("instance references an unknown mesh"); return false; }
         if (g.material >= materials.size()) { fail("instance references an unknown material"); return false; }
@@ -460,7 +461,7 @@ bool HdMoonshine::ensure_wavefront(size_t npaths, size_t slots, int npipes) {
         if (npaths > pp.cap) {
             const size_t c = (npaths + 255) & ~(size_t)255;
             pp.cap = 0;
-            if (!pp.paths[0].ensure(c) || !pp.paths[1].ensure(c) || !pp.hit_u.alloc(5 * c) || !pp.shq_f.alloc(8 * 2 * c)) { fail("out of device memory (wavefront state)"); return false; }
+            if (!pp.paths[0].ensure(c) || !pp.paths[1].ensure(c) || !pp.hit_u.alloc(4 * c) || !pp.shq_f.alloc(8 * 2 * c)) { fail("out of device memory (wavefront state)"); return false; }
             pp.cap = c;
         }
         if (!pp.counters.p) { if (!pp.counters.alloc(1)) return false; if (hipMemsetAsync(pp.counters.p, 0, sizeof(Counters), stream) != hipSuccess) return false; }
@@ -541,7 +542,7 @@ bool HdMoonshine::render(uint32_t sensor, uint32_t lens, uint32_t launches, bool
     // the shadow rays of bounce b are only needed by k_shade(b+1), so k_trace_shadow(b) overlaps k_trace_closest(b+1).
     auto trace_pass = [&](Pipe& pp, uint32_t first_sample, uint32_t ns, float4* lbuf) -> bool {
         const size_t cap = pp.cap, qc = 2 * cap;
-        const HitBuf hits{ reinterpret_cast<uint4*>(pp.hit_u.p), pp.hit_u.p + 4 * cap };
+        const HitBuf hits{ reinterpret_cast<uint4*>(pp.hit_u.p) };
         const ShadowQueue shq{ reinterpret_cast<float4*>(pp.shq_f.p), reinterpret_cast<float4*>(pp.shq_f.p + 4 * qc) };
         const PathState st[2] = { pp.paths[0].view(), pp.paths[1].view() };
         Counters* cnt = pp.counters.p;

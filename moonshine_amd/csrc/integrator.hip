@@ -127,9 +127,9 @@ __global__ __launch_bounds__(SHADE_BLOCK) void k_shade(SceneView sc, PipelineOpt
                 done = true;
             }
             if (!done) {
-                const uint32_t hgeo = hits.geo[i], hprim = hrec.y;
+                const uint32_t htri = hrec.y;
                 GeometryRec geometry;
-                const Attrs attrs = mesh_attributes_world(sc, opts.indexed_attributes != 0, hinst, hgeo, hprim, F2(u2f(hrec.z), u2f(hrec.w)), geometry);
+                const Attrs attrs = mesh_attributes_world(sc, opts.indexed_attributes != 0, hinst, 0u, 0u, F2(u2f(hrec.z), u2f(hrec.w)), geometry, htri);
                 const MaterialRec mrec = sc.materials[geometry.material];
                 const Frame textureFrame = get_texture_frame(sc, mrec, opts.two_component_normal_texture != 0, attrs.texcoord, attrs.frame);
                 const f3 emissiveLight = tex_sample_rgb(sc, mrec.emissive, attrs.texcoord);
@@ -144,9 +144,10 @@ __global__ __launch_bounds__(SHADE_BLOCK) void k_shade(SceneView sc, PipelineOpt
                 const f3 woSs = frame_world_to_frame(shadingFrame, woWs);
 
                 // emission, integrator.hlsl:108-124
-                if (mesh_n == 0 || bounceCount == 0 || !geometry.sampled || isLastMaterialDelta) {
+                const bool geo_sampled = (geometry.sampled & GEO_SAMPLED) != 0;
+                if (mesh_n == 0 || bounceCount == 0 || !geo_sampled || isLastMaterialDelta) {
                     if (dot(woWs, attrs.triangleFrame.n) > 0.0f) L = add(L, mul(throughput, emissiveLight));
-                } else if (geometry.sampled) {
+                } else if (geo_sampled) {
                     const float sum = sc.alias[0].select;
                     const float lightPdf = area_to_solid_angle(attrs.position, rayO, rayD, attrs.triangleFrame.n) / sum;
                     if (lightPdf > 0.0f) { const float weight = power_heuristic(1, lastPdf, mesh_n, lightPdf); L = add(L, scale(mul(throughput, emissiveLight), weight)); }

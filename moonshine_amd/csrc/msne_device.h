@@ -38,11 +38,16 @@ struct alignas(16) InstanceRec {
 };
 static_assert(sizeof(InstanceRec) == 112, "InstanceRec size");
 
-struct GeometryRec { uint32_t mesh, material, sampled; };                    // world.hlsl:19-23 (12 B)
+// world.hlsl:19-23 (12 B).  `sampled`: bit 0 = sampled for emitted light (the reference's bool32), bits 1/2 = the mesh has
+// texcoords / normals (lets k_shade skip the MeshRec load for bare meshes)
+struct GeometryRec { uint32_t mesh, material, sampled; };
+constexpr uint32_t GEO_SAMPLED = 1u, GEO_HAS_TEXCOORDS = 2u, GEO_HAS_NORMALS = 4u;
 struct MeshRec { const float* positions; const float* texcoords; const float* normals; const uint32_t* indices; }; // world.hlsl:25-31 (32 B)
 // reference: Material{normal,emissive,type,addr}+variant buffer (MaterialManager.zig:35-77); flattened here to one 32-B record
 struct alignas(16) MaterialRec { uint32_t normal, emissive, type, color, metalness, roughness; float ior; uint32_t pad; };
-struct TexDesc { uint32_t offset, w, h, pad; };                              // texel offset into SceneView::texels (float4)
+// texel offset into SceneView::texels (float4).  `first` repeats texel 0: 1x1 textures — every constant material
+// parameter (World.zig:44-228) — are then served by the descriptor load alone, one dependent load less per fetch
+struct alignas(16) TexDesc { uint32_t offset, w, h, pad; float4 first; };
 struct AliasEntry { uint32_t alias; float select; uint32_t instance, geometry, primitive; };  // light.hlsl:17-22,112-116 (20 B)
 
 struct EnvView {
@@ -91,7 +96,9 @@ constexpr uint32_t PATH_FLAG_ZOMBIE = 1u << 17;
 constexpr uint32_t PATH_FLAG_MASKED = 1u << 18;   // slot of a pixel outside the image (edge tiles): dropped by the first k_shade
 constexpr int PATH_STATE_WORDS = 23;
 
-struct HitBuf { uint4* rec; uint32_t* geo; };   // rec = {instance, primitive, u bits, v bits}: one 16-B store per finished ray (+ geo)
+// rec = {instance, triangle slot in SceneView::tris, u bits, v bits}: ONE 16-B store per finished ray; k_shade reads the
+// 48-B triangle record (vertices + geometry + primitive) instead of chasing instance → geometry → mesh → indices → positions
+struct HitBuf { uint4* rec; };
 
 struct ShadowQueue {
     float4* o;   // origin xyz | w = tmax

@@ -30,6 +30,7 @@ __device__ __forceinline__ float4 sample_bilinear(const float4* texels, uint32_t
 }
 __device__ __forceinline__ float4 tex_sample(const SceneView& sc, uint32_t idx, f2 uv) {
     const TexDesc t = sc.textures[idx];
+    if (t.w == 1 && t.h == 1) return t.first;
     return sample_bilinear(sc.texels + t.offset, t.w, t.h, uv.x, uv.y, false);
 }
 __device__ __forceinline__ f3 tex_sample_rgb(const SceneView& sc, uint32_t idx, f2 uv) { float4 o = tex_sample(sc, idx, uv); return F3(o.x, o.y, o.z); }
@@ -59,18 +60,38 @@ __device__ __forceinline__ Frame frame_in_space(const Frame& f, const m34& toMes
 __device__ __forceinline__ f3 ld3(const float* p, uint32_t i) { return F3(p[3 * (size_t)i], p[3 * (size_t)i + 1], p[3 * (size_t)i + 2]); }
 __device__ __forceinline__ f2 ld2(const float* p, uint32_t i) { return F2(p[2 * (size_t)i], p[2 * (size_t)i + 1]); }
 
-// MeshAttributes::lookupAndInterpolate(...).inWorld(...)  world.hlsl:114-176; also returns the geometry record
+// MeshAttributes::lookupAndInterpolate(...).inWorld(...)  world.hlsl:114-176; also returns the geometry record.
+// Two entry points: by (instance, geometry, primitive) — the reference's chain instance → geometry → mesh → indices →
+// positions, used for sampled light triangles — and by triangle-record slot for surface hits (`tri_slot` != MAX_UINT):
+// the BVH's 48-B record already holds the three vertices (bit-identical copies), the geometry and the primitive index,
+// which removes three dependent loads from every hit; indices are only fetched when the mesh has normals or texcoords.
 __device__ __forceinline__ Attrs mesh_attributes_world(const SceneView& sc, bool indexed_attributes, uint32_t instanceIndex, uint32_t geometryIndex,
-                                                       uint32_t primitiveIndex, f2 attribs, GeometryRec& geo_out) {
+                                                       uint32_t primitiveIndex, f2 attribs, GeometryRec& geo_out, uint32_t tri_slot = MAX_UINT) {
     const InstanceRec* inst = sc.instances + instanceIndex;
-    const uint32_t instanceID = inst->geo_offset;
-    const GeometryRec g = sc.geometries[instanceID + geometryIndex];
-    geo_out = g;
-    const MeshRec mesh = sc.meshes[g.mesh];
     const f3 bary = F3(1.0f - attribs.x - attribs.y, attribs.x, attribs.y);
     Attrs a;
-    const uint32_t i0 = mesh.indices[3 * (size_t)primitiveIndex], i1 = mesh.indices[3 * (size_t)primitiveIndex + 1], i2 = mesh.indices[3 * (size_t)primitiveIndex + 2];
-    const f3 p0 = ld3(mesh.positions, i0), p1 = ld3(mesh.positions, i1), p2 = ld3(mesh.positions, i2);
+    f3 p0, p1, p2; uint32_t i0 = 0, i1 = 0, i2 = 0;
+    GeometryRec g; MeshRec mesh;
+    if (tri_slot != MAX_UINT) {
+        const uint4* tp = reinterpret_cast<const uint4*>(sc.tris + tri_slot);
+        const uint4 ta = tp[0], tb = tp[1], tc = tp[2];
+        const uint32_t instanceID = inst->geo_offset;
+        p0 = F3(u2f(ta.x), u2f(ta.y), u2f(ta.z)); p1 = F3(u2f(ta.w), u2f(tb.x), u2f(tb.y)); p2 = F3(u2f(tb.z), u2f(tb.w), u2f(tc.x));
+        geometryIndex = tc.y; primitiveIndex = tc.z;
+        g = sc.geometries[instanceID + geometryIndex];
+        mesh.positions = nullptr; mesh.texcoords = nullptr; mesh.normals = nullptr; mesh.indices = nullptr;
+        if (g.sampled & (GEO_HAS_TEXCOORDS | GEO_HAS_NORMALS)) {
+            mesh = sc.meshes[g.mesh];
+            if (indexed_attributes) { i0 = mesh.indices[3 * (size_t)primitiveIndex]; i1 = mesh.indices[3 * (size_t)primitiveIndex + 1]; i2 = mesh.indices[3 * (size_t)primitiveIndex + 2]; }
+        }
+    } else {
+        const uint32_t instanceID = inst->geo_offset;
+        g = sc.geometries[instanceID + geometryIndex];
+        mesh = sc.meshes[g.mesh];
+        i0 = mesh.indices[3 * (size_t)primitiveIndex]; i1 = mesh.indices[3 * (size_t)primitiveIndex + 1]; i2 = mesh.indices[3 * (size_t)primitiveIndex + 2];
+        p0 = ld3(mesh.positions, i0); p1 = ld3(mesh.positions, i1); p2 = ld3(mesh.positions, i2);
+    }
+    geo_out = g;
     a.position = interp3(bary, p0, p1, p2);
     uint32_t a0, a1, a2;
     if (indexed_attributes) { a0 = i0; a1 = i1; a2 = i2; }

@@ -72,7 +72,7 @@ __device__ __forceinline__ bool tri_intersect(f3 o, const RayK& k, f3 v0, f3 v1,
 
 __device__ __forceinline__ float safe_inv(float d) { return absf(d) < 1e-30f ? (d < 0.0f ? -1e30f : 1e30f) : 1.0f / d; }
 
-struct Hit { uint32_t inst, geo, prim; float t, u, v; };
+struct Hit { uint32_t inst, geo, prim, tri; float t, u, v; };   // tri = slot of the hit triangle's record in SceneView::tris
 
 // per-lane traversal state
 struct Lane {
@@ -109,7 +109,7 @@ __device__ __forceinline__ void lane_set_space(Lane& L, f3 o, f3 d) {
 __device__ __forceinline__ void lane_begin(Lane& L, const SceneView& sc, f3 o, f3 d, float tmax) {
     L.o_w = o; L.d_w = d;
     lane_set_space(L, o, d);
-    L.best.inst = MAX_UINT; L.best.geo = 0; L.best.prim = 0; L.best.t = tmax; L.best.u = 0.0f; L.best.v = 0.0f;
+    L.best.inst = MAX_UINT; L.best.geo = 0; L.best.prim = 0; L.best.tri = 0; L.best.t = tmax; L.best.u = 0.0f; L.best.v = 0.0f;
     L.sp = 0; L.in_blas = sc.root_in_blas != 0u; L.cur_inst = WORLD_INSTANCE;   // only used when the root IS the world BLAS
     L.cur = sc.tlas_root; L.have = sc.tlas_root != MAX_UINT;
 }
@@ -201,6 +201,7 @@ __device__ __forceinline__ bool step_tri(Lane& L, const SceneView& sc, unsigned 
     const bool closer = hit && (t < L.best.t || tie);
     L.best.t = closer ? t : L.best.t; L.best.u = closer ? u : L.best.u; L.best.v = closer ? v : L.best.v;
     L.best.inst = closer ? inst : L.best.inst; L.best.geo = closer ? c.y : L.best.geo; L.best.prim = closer ? c.z : L.best.prim;
+    L.best.tri = closer ? idx : L.best.tri;
     return false;
 }
 
@@ -305,7 +306,7 @@ __device__ __forceinline__ void trace_wave_loop(const SceneView& sc, uint32_t n,
                 my = base + r;
                 f3 o, d; float tmax;
                 if (load(my, o, d, tmax)) { lane_begin(L, sc, o, d, tmax); active = L.have; if (!active) store(my, L); }
-                else { L.best.inst = MAX_UINT; L.best.geo = 0; L.best.prim = 0; L.best.u = 0.0f; L.best.v = 0.0f; L.best.t = 0.0f; store(my, L); }
+                else { L.best.inst = MAX_UINT; L.best.geo = 0; L.best.prim = 0; L.best.tri = 0; L.best.u = 0.0f; L.best.v = 0.0f; L.best.t = 0.0f; store(my, L); }
             }
         }
         lap(1);
@@ -344,7 +345,7 @@ __global__ __launch_bounds__(TRACE_BLOCK, TRACE_WPS) void k_trace_closest(SceneV
             return true;
         },
         [&](uint32_t i, const Lane& L) {
-            hits.rec[i] = make_uint4(L.best.inst, L.best.prim, f2u(L.best.u), f2u(L.best.v)); hits.geo[i] = L.best.geo;
+            hits.rec[i] = make_uint4(L.best.inst, L.best.tri, f2u(L.best.u), f2u(L.best.v));
         }, nv, nt, stat_out + 4);
     if (STATS) { atomicAdd(&stat_out[0], nv); atomicAdd(&stat_out[1], nt); }
 }
