@@ -201,7 +201,8 @@ uint32_t MsneGetSampleCount(const HdMoonshine*, SensorHandle);    /* Sensor.samp
 uint64_t MsneGetShardTileCount(const HdMoonshine*, SensorHandle);
 void* MsneGetPackedFilmDevicePtr(const HdMoonshine*, SensorHandle);            /* device pointer, float4[tiles*ts*ts] */
 /* root side: scatter `shard_count` packed films (concatenated in shard order, each padded to max tiles per shard)
- * from device memory into the sensor's full row-major film and its host buffer */
+ * from device memory into the sensor's full row-major film and its host buffer.  The gathered buffer must be complete
+ * when this is called (the library's streams are non-blocking: synchronise the stream that filled it first). */
 int MsneUnpackGatheredFilm(HdMoonshine*, SensorHandle, const void* gathered_device_ptr, uint32_t shard_count);
 
 int MsneGetStats(const HdMoonshine*, MsneStats*);

@@ -320,7 +320,8 @@ bool HdMoonshine::rebuild_accel() {
         CHECK_HIP(this, hipStreamSynchronize(stream));
         std::swap(nn.p, d_nodes.p); std::swap(nn.n, d_nodes.n);
     }
-    if (!d_item_src.ensure(std::max(d_tris.n, N + 2)) || !d_tlas_items.ensure(N + 2)) { fail("out of device memory (items)"); return false; }
+    // TLAS items: 8 slots per TLAS node with instance leaves (item = item_base + child slot), at most one such node per instance
+    if (!d_item_src.ensure(std::max(d_tris.n, 8 * (N + 2))) || !d_tlas_items.ensure(8 * (N + 2))) { fail("out of device memory (items)"); return false; }
     // counters: node count resumes after the BLAS region (the previous TLAS is discarded)
     { uint32_t c[4] = { blas_nodes_end, blas_tris_end, 0u, 0u }; CHECK_HIP(this, hipMemcpyAsync(d_build_counters.p, c, 16, hipMemcpyHostToDevice, stream)); CHECK_HIP(this, hipStreamSynchronize(stream)); }
     for (size_t i = 0; i < N; i++) {

@@ -3,12 +3,17 @@
 // written by closesthit/miss/shadowmiss in main.hlsl:102-118) over the driver-built TLAS/BLAS
 // (engine/hrtsystem/Accel.zig:94-184,484).
 //
-// Design (gfx950): persistent waves.  A wave reserves a private chunk of the compacted ray queue with one
-// atomicAdd (its first chunk is static — no atomic at all), and every LANE refills itself from that chunk
-// the moment its ray terminates (ballot + prefix popcount), so the wave never idles on its slowest ray.
-// Each lane walks the two-level 8-wide quantized BVH (80-B nodes, 48-B triangles) with a short per-lane
-// stack in LDS ([entry][thread] layout → conflict-free ds_read/ds_write_b32), spilling to HBM only beyond
-// STACK_LDS entries.  No MFMA: this is pointer chasing + 3-vector math.
+// Design (gfx950).  The kernels are VALU-issue bound (rocprofv3: SQ_ACTIVE_INST_VALU ≈ 100 % of SIMD time,
+// HBM traffic far below peak), so everything here minimises vector instructions per node visit:
+//  * persistent waves: a wave reserves a private chunk of the compacted ray queue with one atomicAdd (its first
+//    chunk is static), and every LANE refills itself from that chunk when its ray terminates;
+//  * the per-lane stack (LDS, [entry][word][thread] → conflict-free) holds child GROUPS, not children: one
+//    2-word entry {base, hit bits | type bits} names every hit-but-unvisited internal child of a node, so a node
+//    visit pushes at most once and never materialises per-child entries;
+//  * the builder places a node's children in octant order (slot bit k set = child on the + side of axis k), so
+//    the visit order is a 2-KB LDS table lookup lut[ray octant][hit bits] instead of a distance sort;
+//  * near/far planes are chosen by ray sign once per node (12 v_cndmask), not by min/max per child;
+//  * leaf triangles are decoded lazily, one triangle per iteration, so lanes stay in step whatever the leaf sizes.
 // Box tests use fmaf and a relative slack (they only gate which triangles are tested); the triangle test is
 // the watertight Woop–Benthin–Wald test evaluated op-for-op like the test oracle, and equal-t ties resolve
 // to the smallest (instance, geometry, primitive), so results do not depend on BVH shape or visit order.
@@ -20,12 +25,9 @@ constexpr int TRACE_BLOCK = 256;
 #ifndef TRACE_WPS
 #define TRACE_WPS 6          // resident waves per SIMD the trace kernels are register-allocated for (= blocks of 256 per CU)
 #endif
-constexpr int STACK_LDS = 24;
-constexpr int STACK_SPILL = 232;          // total depth 256 entries per lane
-constexpr uint32_t ENT_SENTINEL = 0xFFFFFFFFu;     // leaving a transformed instance: restore the world-space ray
-constexpr uint32_t ENT_SENTINEL_ID = 0xFFFFFFFEu;  // leaving an identity-transform instance
-constexpr uint32_t ENT_KIND_TRI = 1u << 30;
-constexpr uint32_t ENT_KIND_INST = 2u << 30;
+constexpr int STACK_LDS = 12;             // group entries per lane kept in LDS (2 words each)
+constexpr int STACK_SPILL = 116;          // further entries per lane in HBM (2 words each)
+constexpr uint32_t GRP_NODE = 0u, GRP_INST = 1u << 16, GRP_SENTINEL = 2u << 16, GRP_KIND_MASK = 3u << 16;
 struct TraceTune { uint32_t refill, t_node, t_tri, t_inst; };   // lane-refill and phase-vote thresholds (lanes of 64)
 
 struct RayK { int kx, ky, kz; float Sx, Sy, Sz; };
@@ -72,155 +74,166 @@ __device__ __forceinline__ bool tri_intersect(f3 o, const RayK& k, f3 v0, f3 v1,
 
 __device__ __forceinline__ float safe_inv(float d) { return absf(d) < 1e-30f ? (d < 0.0f ? -1e30f : 1e30f) : 1.0f / d; }
 
-struct Hit { uint32_t inst, geo, prim, tri; float t, u, v; };   // tri = slot of the hit triangle's record in SceneView::tris
+struct Hit { uint32_t inst, tri; float t, u, v; };   // tri = slot of the hit triangle's record in SceneView::tris
 
 // per-lane traversal state
 struct Lane {
-    f3 o_w, d_w;      // world-space ray
-    f3 o, d, id;      // current-space ray and reciprocal direction
+    f3 o, id;          // current-space ray origin and reciprocal direction
     RayK rk;
     Hit best;
-    uint32_t cur;     // entry being processed when `have`
+    uint32_t g0, g1;   // current child group: g0 = base index, g1 = hit bits (0..7) | type bits (8..15) | kind (16..17)
+    uint32_t tbase, mlo, mhi, lhits;   // leaf group of the last visited BLAS node: item base, 8 meta bytes, hit leaf slots
+    uint32_t tcur;     // triangle being walked: index | remaining << 28 (0 = none)
+    uint32_t octbase;  // ray octant << 8 (row of the order table)
     uint32_t cur_inst;
     int sp;
-    bool have, in_blas;
+    bool in_blas;
 };
 
 struct StackRef { uint32_t* lds; uint32_t* spill; uint32_t spill_stride; uint32_t* overflow; };
 
-__device__ __forceinline__ void lane_push(Lane& L, const StackRef& S, uint32_t e) {   // general (slow-path) push
-    if (L.sp < STACK_LDS) S.lds[L.sp * TRACE_BLOCK + threadIdx.x] = e;
-    else if (L.sp < STACK_LDS + STACK_SPILL) S.spill[(size_t)(L.sp - STACK_LDS) * S.spill_stride] = e;
-    else { *S.overflow = 1u; return; }
+__device__ __forceinline__ void lane_push(Lane& L, const StackRef& S, uint32_t e0, uint32_t e1) {   // general push (any depth)
+    if (L.sp < STACK_LDS) { S.lds[(2 * L.sp) * TRACE_BLOCK + threadIdx.x] = e0; S.lds[(2 * L.sp + 1) * TRACE_BLOCK + threadIdx.x] = e1; }
+    else if (L.sp < STACK_LDS + STACK_SPILL) {
+        S.spill[(size_t)(2 * (L.sp - STACK_LDS)) * S.spill_stride] = e0; S.spill[(size_t)(2 * (L.sp - STACK_LDS) + 1) * S.spill_stride] = e1;
+    } else { *S.overflow = 1u; return; }
     L.sp++;
 }
-__device__ __forceinline__ uint32_t lane_pop(Lane& L, const StackRef& S) {
+__device__ __forceinline__ void lane_pop(Lane& L, const StackRef& S) {
     L.sp--;
-    if (__builtin_expect(L.sp >= STACK_LDS, 0)) return S.spill[(size_t)(L.sp - STACK_LDS) * S.spill_stride];
-    return S.lds[L.sp * TRACE_BLOCK + threadIdx.x];
+    if (__builtin_expect(L.sp >= STACK_LDS, 0)) {
+        L.g0 = S.spill[(size_t)(2 * (L.sp - STACK_LDS)) * S.spill_stride]; L.g1 = S.spill[(size_t)(2 * (L.sp - STACK_LDS) + 1) * S.spill_stride];
+    } else { L.g0 = S.lds[(2 * L.sp) * TRACE_BLOCK + threadIdx.x]; L.g1 = S.lds[(2 * L.sp + 1) * TRACE_BLOCK + threadIdx.x]; }
 }
 
 __device__ __forceinline__ void lane_set_space(Lane& L, f3 o, f3 d) {
-    L.o = o; L.d = d;
+    L.o = o;
     L.id = F3(safe_inv(d.x), safe_inv(d.y), safe_inv(d.z));
     L.rk = rayk_make(d);
+    L.octbase = ((L.id.x < 0.0f ? 1u : 0u) | (L.id.y < 0.0f ? 2u : 0u) | (L.id.z < 0.0f ? 4u : 0u)) << 8;
 }
 
-__device__ __forceinline__ void lane_begin(Lane& L, const SceneView& sc, f3 o, f3 d, float tmax) {
-    L.o_w = o; L.d_w = d;
+__device__ __forceinline__ bool lane_begin(Lane& L, const SceneView& sc, f3 o, f3 d, float tmax) {
     lane_set_space(L, o, d);
-    L.best.inst = MAX_UINT; L.best.geo = 0; L.best.prim = 0; L.best.tri = 0; L.best.t = tmax; L.best.u = 0.0f; L.best.v = 0.0f;
+    L.best.inst = MAX_UINT; L.best.tri = 0; L.best.t = tmax; L.best.u = 0.0f; L.best.v = 0.0f;
     L.sp = 0; L.in_blas = sc.root_in_blas != 0u; L.cur_inst = WORLD_INSTANCE;   // only used when the root IS the world BLAS
-    L.cur = sc.tlas_root; L.have = sc.tlas_root != MAX_UINT;
+    L.g0 = sc.tlas_root; L.g1 = sc.tlas_root != MAX_UINT ? (GRP_NODE | 0x0101u) : 0u;   // a group of one: the root itself
+    L.tcur = 0; L.lhits = 0; L.tbase = 0; L.mlo = 0; L.mhi = 0;
+    return sc.tlas_root != MAX_UINT;
 }
 
-// ---- the three step bodies.  The wave loop decides, per iteration, which bodies run (see trace_wave_loop). ----
+// ---- the step bodies.  The wave loop decides, per iteration, which bodies run (see trace_wave_loop). ----
 
-// internal node: 5 x 16-B loads, 8 quantised box tests; the nearest hit child becomes the current entry, the others are
-// pushed.  Straight-line code: every child slot computes its entry and issues an UNCONDITIONAL ds_write — to its stack
-// position if it was hit, to a per-thread trash row otherwise — so the hot path has no exec-mask branches at all
-// (the earlier per-child conditional pushes cost ~76 branches / ~310 SALU instructions per node visit).
+// Takes the next child of the lane's group in octant order; what is left of the group goes back on the stack.
+// Returns the child's index (node index for GRP_NODE, TLAS item for GRP_INST).
+__device__ __forceinline__ uint32_t group_take(Lane& L, const StackRef& S, const uint8_t* lut) {
+    const uint32_t hits = L.g1 & 0xffu;
+    const uint32_t s = lut[L.octbase + hits];
+    const uint32_t bit = 1u << s;
+    const uint32_t rest = L.g1 & ~bit;
+    const uint32_t idx = L.g0 + __popc((L.g1 >> 8) & 0xffu & (bit - 1u));
+    if (__builtin_expect(L.sp >= STACK_LDS, 0)) {
+        if (rest & 0xffu) lane_push(L, S, L.g0, rest);
+    } else {   // branch-free: the write always happens, the stack pointer only moves if something is left
+        S.lds[(2 * L.sp) * TRACE_BLOCK + threadIdx.x] = L.g0; S.lds[(2 * L.sp + 1) * TRACE_BLOCK + threadIdx.x] = rest;
+        L.sp += (rest & 0xffu) ? 1 : 0;
+    }
+    L.g1 = 0u;
+    return idx;
+}
+
+// internal node: 5 x 16-B loads, 8 quantised box tests → 8 hit bits.  Straight-line code, no per-child entries:
+// the hit internal children become the lane's new group, the hit leaves its leaf group (BLAS) or an instance group (TLAS).
 template <bool STATS>
-__device__ __forceinline__ void step_node(Lane& L, const SceneView& sc, const StackRef& S, unsigned long long& nv) {
-    const uint32_t cur = L.cur;
-    const uint4* np = reinterpret_cast<const uint4*>(sc.nodes + cur);
+__device__ __forceinline__ void step_node(Lane& L, const SceneView& sc, const StackRef& S, uint32_t node, unsigned long long& nv) {
+    const uint4* np = reinterpret_cast<const uint4*>(sc.nodes + node);
     const uint4 w0 = np[0], w1 = np[1], w2 = np[2], w3 = np[3], w4 = np[4];
     if (STATS) nv++;
     const float nox = u2f(w0.x), noy = u2f(w0.y), noz = u2f(w0.z);
     const uint32_t ex = w0.w & 0xff, ey = (w0.w >> 8) & 0xff, ez = (w0.w >> 16) & 0xff, imask = w0.w >> 24;
-    const uint32_t child_base = w1.x, item_base = w1.y;
-    const uint32_t meta_lo = w1.z, meta_hi = w1.w;
     const float ax = u2f(ex << 23) * L.id.x, ay = u2f(ey << 23) * L.id.y, az = u2f(ez << 23) * L.id.z;
     const float bx = (nox - L.o.x) * L.id.x, by = (noy - L.o.y) * L.id.y, bz = (noz - L.o.z) * L.id.z;
-    // byte planes: qlo[0] = w2.xy, qlo[1] = w2.zw, qlo[2] = w3.xy, qhi[0] = w3.zw, qhi[1] = w4.xy, qhi[2] = w4.zw
-    const uint32_t qw[12] = { w2.x, w2.y, w2.z, w2.w, w3.x, w3.y, w3.z, w3.w, w4.x, w4.y, w4.z, w4.w };
+    // byte planes: qlo[0] = w2.xy, qlo[1] = w2.zw, qlo[2] = w3.xy, qhi[0] = w3.zw, qhi[1] = w4.xy, qhi[2] = w4.zw.
+    // a = scale * id has the sign of id, so the entry plane of an axis is qlo when id >= 0 and qhi otherwise
+    const bool sx = L.id.x < 0.0f, sy = L.id.y < 0.0f, sz = L.id.z < 0.0f;
+    const uint32_t nx[2] = { sx ? w3.z : w2.x, sx ? w3.w : w2.y }, fx[2] = { sx ? w2.x : w3.z, sx ? w2.y : w3.w };
+    const uint32_t ny[2] = { sy ? w4.x : w2.z, sy ? w4.y : w2.w }, fy[2] = { sy ? w2.z : w4.x, sy ? w2.w : w4.y };
+    const uint32_t nz[2] = { sz ? w4.z : w3.x, sz ? w4.w : w3.y }, fz[2] = { sz ? w3.x : w4.z, sz ? w3.y : w4.w };
     const float tlimit = L.best.t;
-    const uint32_t leaf_kind = L.in_blas ? ENT_KIND_TRI : ENT_KIND_INST;
-    const uint32_t leaf_cnt_mask = L.in_blas ? 3u : 0u;
-    uint32_t ent[8]; uint32_t hitmask = 0; uint32_t next_entry = 0; float nearest_t = 3.0e38f; uint32_t nearest_bit = 0;
+    uint32_t hits8 = 0;
 #pragma unroll
     for (int i = 0; i < 8; i++) {
         const int wi = i >> 2, sh = (i & 3) * 8;
-        const float lx = (float)((qw[0 + wi] >> sh) & 0xff), ly = (float)((qw[2 + wi] >> sh) & 0xff), lz = (float)((qw[4 + wi] >> sh) & 0xff);
-        const float hx = (float)((qw[6 + wi] >> sh) & 0xff), hy = (float)((qw[8 + wi] >> sh) & 0xff), hz = (float)((qw[10 + wi] >> sh) & 0xff);
-        const float t0x = __builtin_fmaf(lx, ax, bx), t1x = __builtin_fmaf(hx, ax, bx);
-        const float t0y = __builtin_fmaf(ly, ay, by), t1y = __builtin_fmaf(hy, ay, by);
-        const float t0z = __builtin_fmaf(lz, az, bz), t1z = __builtin_fmaf(hz, az, bz);
-        const float n = fmaxf(fmaxf(fminf(t0x, t1x), fminf(t0y, t1y)), fmaxf(fminf(t0z, t1z), 0.0f));
-        const float f = fminf(fminf(fmaxf(t0x, t1x), fmaxf(t0y, t1y)), fminf(fmaxf(t0z, t1z), tlimit));
-        const uint32_t m = ((i < 4 ? meta_lo : meta_hi) >> sh) & 0xff;
-        const bool internal = (imask >> i) & 1u;
-        const bool hit = (internal || m != 0xffu) && n <= f * 1.00001f;
-        const uint32_t e_int = child_base + __popc(imask & ((1u << i) - 1u));
-        const uint32_t e_leaf = leaf_kind | (((m >> 5) & leaf_cnt_mask) << 28) | (item_base + (m & 31u));
-        ent[i] = internal ? e_int : e_leaf;
-        hitmask |= hit ? (1u << i) : 0u;
-        const bool nearer = hit && n < nearest_t;
-        nearest_t = nearer ? n : nearest_t;
-        next_entry = nearer ? ent[i] : next_entry;
-        nearest_bit = nearer ? (1u << i) : nearest_bit;
+        const float t0x = __builtin_fmaf((float)((nx[wi] >> sh) & 0xff), ax, bx), t1x = __builtin_fmaf((float)((fx[wi] >> sh) & 0xff), ax, bx);
+        const float t0y = __builtin_fmaf((float)((ny[wi] >> sh) & 0xff), ay, by), t1y = __builtin_fmaf((float)((fy[wi] >> sh) & 0xff), ay, by);
+        const float t0z = __builtin_fmaf((float)((nz[wi] >> sh) & 0xff), az, bz), t1z = __builtin_fmaf((float)((fz[wi] >> sh) & 0xff), az, bz);
+        const float n = fmaxf(fmaxf(t0x, t0y), fmaxf(t0z, 0.0f));
+        const float f = fminf(fminf(t1x, t1y), fminf(t1z, tlimit));
+        hits8 |= (n <= f * 1.00001f) ? (1u << i) : 0u;
     }
-    const uint32_t rest = hitmask & ~nearest_bit;
-    const uint32_t npush = __popc(rest);
-    if (__builtin_expect(L.sp + (int)npush > STACK_LDS, 0)) {
-        // rare deep path: general pushes (LDS, then the HBM spill area)
-#pragma unroll
-        for (int i = 0; i < 8; i++) if ((rest >> i) & 1u) lane_push(L, S, ent[i]);
-    } else {
-        uint32_t* row0 = S.lds + threadIdx.x;
-#pragma unroll
-        for (int i = 0; i < 8; i++) {
-            const uint32_t pos = ((rest >> i) & 1u) ? (uint32_t)L.sp + __popc(rest & ((1u << i) - 1u)) : (uint32_t)STACK_LDS;   // STACK_LDS = trash row
-            row0[pos * TRACE_BLOCK] = ent[i];
-        }
-        L.sp += (int)npush;
+    // empty slots (inverted boxes) can pass the slack test when the node is tiny against its distance: they are
+    // never internal (imask), their leaf meta is 0xff (skipped in step_tri) and their TLAS item is MAX_UINT (step_inst)
+    const uint32_t ihits = hits8 & imask, lhits = hits8 & ~imask;
+    L.g0 = w1.x; L.g1 = GRP_NODE | (imask << 8) | ihits;
+    if (L.in_blas) { L.tbase = w1.y; L.mlo = w1.z; L.mhi = w1.w; L.lhits = lhits; }
+    else if (lhits) {   // TLAS: hit leaves are instances, item slot = item_base + child slot; visit them before the internal children
+        if (ihits) lane_push(L, S, L.g0, L.g1);
+        L.g0 = w1.y; L.g1 = GRP_INST | 0xff00u | lhits;
     }
-    L.cur = next_entry; L.have = hitmask != 0u;
 }
 
-// ONE triangle of a leaf per call (entry = kind | (remaining-1) << 28 | index), so lanes stay in step whatever the
-// leaf sizes.  Returns true when an any-hit ray is finished.
+// ONE triangle per call: a new leaf of the lane's leaf group is decoded when the previous one is exhausted.
+// Returns true when an any-hit ray is finished.
 template <bool ANY_HIT, bool STATS>
 __device__ __forceinline__ bool step_tri(Lane& L, const SceneView& sc, unsigned long long& nt) {
-    const uint32_t cur = L.cur;
-    const uint32_t rem = (cur >> 28) & 3u, idx = cur & 0x0FFFFFFFu;
-    if (rem) L.cur = ENT_KIND_TRI | ((rem - 1u) << 28) | (idx + 1u); else L.have = false;
-    const uint4* tp = reinterpret_cast<const uint4*>(sc.tris + idx);
-    const uint4 a = tp[0], b = tp[1], c = tp[2];
-    if (STATS) nt++;
-    float t, u, v;
-    const bool hit = tri_intersect(L.o, L.rk, F3(u2f(a.x), u2f(a.y), u2f(a.z)), F3(u2f(a.w), u2f(b.x), u2f(b.y)), F3(u2f(b.z), u2f(b.w), u2f(c.x)), t, u, v);
-    const uint32_t inst = L.cur_inst == WORLD_INSTANCE ? c.w : L.cur_inst;   // world BLAS: the triangle record names its instance
-    if (ANY_HIT) {
-        const bool occluded = hit && t < L.best.t;
-        L.best.inst = occluded ? inst : L.best.inst;
-        return occluded;
+    uint32_t rem = L.tcur >> 28, idx = L.tcur & 0x0FFFFFFFu;
+    {   // next leaf of the group (selected in when rem == 0)
+        const bool fresh = rem == 0u;
+        const uint32_t s = (uint32_t)__builtin_ctz(L.lhits | 0x100u);   // any order: every hit leaf of the node is tested
+        const uint32_t m = ((s < 4u ? L.mlo : L.mhi) >> ((s & 3u) * 8u)) & 0xffu;
+        const uint32_t cnt = m == 0xffu ? 0u : (m >> 5) + 1u;
+        idx = fresh ? L.tbase + (m & 31u) : idx;
+        rem = fresh ? cnt : rem;
+        L.lhits = fresh ? (L.lhits & (L.lhits - 1u)) : L.lhits;
     }
-    const bool tie = t == L.best.t && L.best.inst != MAX_UINT
-        && (inst < L.best.inst || (inst == L.best.inst && (c.y < L.best.geo || (c.y == L.best.geo && c.z < L.best.prim))));
-    const bool closer = hit && (t < L.best.t || tie);
-    L.best.t = closer ? t : L.best.t; L.best.u = closer ? u : L.best.u; L.best.v = closer ? v : L.best.v;
-    L.best.inst = closer ? inst : L.best.inst; L.best.geo = closer ? c.y : L.best.geo; L.best.prim = closer ? c.z : L.best.prim;
-    L.best.tri = closer ? idx : L.best.tri;
-    return false;
+    bool done = false;
+    if (rem) {
+        const uint4* tp = reinterpret_cast<const uint4*>(sc.tris + idx);
+        const uint4 a = tp[0], b = tp[1], c = tp[2];
+        if (STATS) nt++;
+        float t, u, v;
+        const bool hit = tri_intersect(L.o, L.rk, F3(u2f(a.x), u2f(a.y), u2f(a.z)), F3(u2f(a.w), u2f(b.x), u2f(b.y)), F3(u2f(b.z), u2f(b.w), u2f(c.x)), t, u, v);
+        const uint32_t inst = L.cur_inst == WORLD_INSTANCE ? c.w : L.cur_inst;   // world BLAS: the triangle record names its instance
+        if (ANY_HIT) {
+            done = hit && t < L.best.t;
+            L.best.inst = done ? inst : L.best.inst;
+        } else {
+            bool closer = hit && t < L.best.t;
+            if (__builtin_expect(hit && t == L.best.t && L.best.inst != MAX_UINT, 0)) {   // exact tie: smallest (instance, geometry, primitive) wins
+                const TriRec* bt = sc.tris + L.best.tri;
+                const uint32_t bgeo = bt->geo, bprim = bt->prim;
+                closer = inst < L.best.inst || (inst == L.best.inst && (c.y < bgeo || (c.y == bgeo && c.z < bprim)));
+            }
+            L.best.t = closer ? t : L.best.t; L.best.u = closer ? u : L.best.u; L.best.v = closer ? v : L.best.v;
+            L.best.inst = closer ? inst : L.best.inst; L.best.tri = closer ? idx : L.best.tri;
+        }
+        rem--; idx++;
+    }
+    L.tcur = rem ? (idx | (rem << 28)) : 0u;
+    return done;
 }
 
-// instance leaf (enter the BLAS in instance space; t is preserved: d is not renormalised) or sentinel (leave it)
-__device__ __forceinline__ void step_inst(Lane& L, const SceneView& sc, const StackRef& S) {
-    const uint32_t cur = L.cur;
-    L.have = false;
-    if (cur >= ENT_SENTINEL_ID) {
-        if (cur == ENT_SENTINEL) lane_set_space(L, L.o_w, L.d_w);
-        L.in_blas = false;
-        return;
-    }
-    const uint32_t item = cur & 0x3FFFFFFFu;
+// TLAS leaf: enter the instance's BLAS in instance space (t is preserved: d is not renormalised).  The ray is
+// restored when the sentinel entry pushed here is popped.
+template <class Load>
+__device__ __forceinline__ void step_inst(Lane& L, const SceneView& sc, const StackRef& S, uint32_t item, uint32_t my, Load load) {
     const uint32_t ii = sc.tlas_items[item];
+    if (ii == MAX_UINT) return;
     const InstanceRec* ir = sc.instances + ii;
     const uint32_t root = ir->blas_root, flags = ir->flags;
-    if (!(flags & 1u) || root == MAX_UINT) return;
-    if (flags & 2u) {
-        lane_push(L, S, ENT_SENTINEL_ID);   // identity transform: M·(o,1) = o and M·d = d exactly, the ray is left as is
+    if (!(flags & INST_FLAG_VISIBLE) || root == MAX_UINT) return;
+    if (flags & INST_FLAG_IDENTITY) {
+        lane_push(L, S, 0u, GRP_SENTINEL);   // identity transform: M·(o,1) = o and M·d = d exactly, the ray is left as is
     } else {
         const float4* mp = reinterpret_cast<const float4*>(&ir->world_to_instance);
         const float4 r0 = mp[0], r1 = mp[1], r2 = mp[2];
@@ -228,11 +241,13 @@ __device__ __forceinline__ void step_inst(Lane& L, const SceneView& sc, const St
         M.m[0][0] = r0.x; M.m[0][1] = r0.y; M.m[0][2] = r0.z; M.m[0][3] = r0.w;
         M.m[1][0] = r1.x; M.m[1][1] = r1.y; M.m[1][2] = r1.z; M.m[1][3] = r1.w;
         M.m[2][0] = r2.x; M.m[2][1] = r2.y; M.m[2][2] = r2.z; M.m[2][3] = r2.w;
-        lane_set_space(L, m34_mul_point(M, L.o_w), m34_mul_vec(M, L.d_w));
-        lane_push(L, S, ENT_SENTINEL);
+        f3 o, d; float tmax;
+        (void)load(my, o, d, tmax);   // the world-space ray is not kept in registers
+        lane_set_space(L, m34_mul_point(M, o), m34_mul_vec(M, d));
+        lane_push(L, S, 1u, GRP_SENTINEL);
     }
     L.in_blas = true; L.cur_inst = (flags & INST_FLAG_WORLD) ? WORLD_INSTANCE : ii;
-    L.cur = root; L.have = true;
+    L.g0 = root; L.g1 = GRP_NODE | 0x0101u;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -271,17 +286,29 @@ struct WaveQueue {
     }
 };
 
+// visit-order table: lut[octant << 8 | hit bits] = the hit slot s with the smallest (s ^ octant) — slot == octant is the
+// child the ray enters first, slot == ~octant the one it reaches last (the builder places children in octant order)
+__device__ __forceinline__ void order_table_init(uint8_t* lut) {
+    for (uint32_t e = threadIdx.x; e < 2048u; e += TRACE_BLOCK) {
+        const uint32_t oct = e >> 8, mask = e & 255u;
+        uint32_t best = 0, bestkey = 8;
+        for (uint32_t s = 0; s < 8; s++) if (((mask >> s) & 1u) && (s ^ oct) < bestkey) { bestkey = s ^ oct; best = s; }
+        lut[e] = (uint8_t)best;
+    }
+    __syncthreads();
+}
+
 // Wave loop shared by the three kernels.  `load(i, o, d, tmax)` returns false for entries without a ray;
 // `store(i, lane)` receives the finished lane.
 template <bool ANY_HIT, bool STATS, class Load, class Store>
-__device__ __forceinline__ void trace_wave_loop(const SceneView& sc, uint32_t n, uint32_t* head, uint32_t* lds_stack, uint32_t* spill, uint32_t* overflow,
+__device__ __forceinline__ void trace_wave_loop(const SceneView& sc, uint32_t n, uint32_t* head, uint32_t* lds_stack, const uint8_t* lut, uint32_t* spill, uint32_t* overflow,
                                                 TraceTune tune, Load load, Store store, unsigned long long& nv, unsigned long long& nt, unsigned long long* prof) {
     const uint32_t lane = threadIdx.x & 63u;
     const unsigned long long lt = lane == 0 ? 0ull : (~0ull >> (64 - lane));
     const uint32_t gtid = blockIdx.x * TRACE_BLOCK + threadIdx.x;
     StackRef S{ lds_stack, spill + gtid, gridDim.x * TRACE_BLOCK, overflow };
     WaveQueue wq(n, head);
-    Lane L; L.have = false; L.sp = 0;
+    Lane L; L.sp = 0; L.g1 = 0; L.tcur = 0; L.lhits = 0;
     bool active = false; uint32_t my = 0;
     // STATS builds: wave-cycle profile of the loop sections (s_memtime), accumulated per wave
     unsigned long long cyc[8] = { 0, 0, 0, 0, 0, 0, 0, 0 }, tprev = 0;
@@ -289,10 +316,16 @@ __device__ __forceinline__ void trace_wave_loop(const SceneView& sc, uint32_t n,
     if (STATS) tprev = __builtin_readcyclecounter();
     for (;;) {
         if (STATS) cyc[7] += 1;   // iterations
-        // (a) lanes without a current entry pop one, or finish when their stack is empty
-        if (active && !L.have) {
+        // (a) lanes with neither triangles nor a child group pop a group, or finish when their stack is empty
+        if (active && !(L.tcur | L.lhits | (L.g1 & 0xffu))) {
             if (L.sp == 0) { store(my, L); active = false; }
-            else { L.cur = lane_pop(L, S); L.have = true; }
+            else {
+                lane_pop(L, S);
+                if (__builtin_expect((L.g1 & GRP_KIND_MASK) == GRP_SENTINEL, 0)) {   // leaving an instance: back to the world-space ray
+                    if (L.g0 & 1u) { f3 o, d; float tmax; (void)load(my, o, d, tmax); lane_set_space(L, o, d); }
+                    L.in_blas = false; L.g1 = 0u;
+                }
+            }
         }
         lap(0);
         // (b) idle lanes take new rays from the wave's private chunk
@@ -305,38 +338,49 @@ __device__ __forceinline__ void trace_wave_loop(const SceneView& sc, uint32_t n,
             if (!active && r < got) {
                 my = base + r;
                 f3 o, d; float tmax;
-                if (load(my, o, d, tmax)) { lane_begin(L, sc, o, d, tmax); active = L.have; if (!active) store(my, L); }
-                else { L.best.inst = MAX_UINT; L.best.geo = 0; L.best.prim = 0; L.best.tri = 0; L.best.u = 0.0f; L.best.v = 0.0f; L.best.t = 0.0f; store(my, L); }
+                if (load(my, o, d, tmax)) { active = lane_begin(L, sc, o, d, tmax); if (!active) store(my, L); }
+                else { L.best.inst = MAX_UINT; L.best.tri = 0; L.best.u = 0.0f; L.best.v = 0.0f; L.best.t = 0.0f; store(my, L); }
             }
         }
         lap(1);
         if (!__ballot(active)) { if (wq.exhausted) break; continue; }
         // (c) phase vote: an expensive body runs only when enough lanes want it (or it is the most wanted one), so
         // lanes of the same kind are batched over time instead of every body running at low utilisation every iteration
-        const uint32_t kind = !active ? 4u : (L.cur >= ENT_SENTINEL_ID ? 2u : (L.cur >> 30));
-        const uint32_t nn = (uint32_t)__popcll(__ballot(kind == 0u)), nt_ = (uint32_t)__popcll(__ballot(kind == 1u)), ni = (uint32_t)__popcll(__ballot(kind == 2u));
-        const bool do_n = nn && (nn >= tune.t_node || (nn >= nt_ && nn >= ni));
-        const bool do_t = nt_ && (nt_ >= tune.t_tri || (nt_ > nn && nt_ >= ni));
-        const bool do_i = ni && (ni >= tune.t_inst || (ni > nn && ni > nt_));
+        const bool want_t = active && (L.tcur | L.lhits);
+        const bool want_n = active && !want_t && (L.g1 & 0xffu);
+        const uint32_t nn = (uint32_t)__popcll(__ballot(want_n)), nt_ = (uint32_t)__popcll(__ballot(want_t));
+        const bool do_n = nn && (nn >= tune.t_node || nn >= nt_);
+        const bool do_t = nt_ && (nt_ >= tune.t_tri || nt_ > nn);
         lap(2);
-        if (do_n && kind == 0u) step_node<STATS>(L, sc, S, nv);
+        if (do_n && want_n) {
+            const uint32_t kind = L.g1 & GRP_KIND_MASK;
+            const uint32_t idx = group_take(L, S, lut);
+            if (__builtin_expect(kind == GRP_INST, 0)) step_inst(L, sc, S, idx, my, load);
+            else step_node<STATS>(L, sc, S, idx, nv);
+        }
         lap(3);
-        if (STATS && do_n) cyc[6] += __popcll(__ballot(kind == 0u));   // node-lane steps
-        if (do_t && kind == 1u) { if (step_tri<ANY_HIT, STATS>(L, sc, nt)) { L.sp = 0; L.have = false; store(my, L); active = false; } }
+        if (STATS && do_n) cyc[6] += __popcll(__ballot(want_n));   // node-lane steps
+        if (do_t && want_t) {
+            if (step_tri<ANY_HIT, STATS>(L, sc, nt)) { L.sp = 0; L.g1 = 0; L.tcur = 0; L.lhits = 0; store(my, L); active = false; }
+        }
         lap(4);
-        if (do_i && kind == 2u) step_inst(L, sc, S);
         lap(5);
     }
     if (STATS && (threadIdx.x & 63u) == 0) for (int k = 0; k < 8; k++) atomicAdd(&prof[k], cyc[k]);
 }
 
+#define TRACE_LDS_DECL \
+    __shared__ uint32_t lds_stack[2 * STACK_LDS * TRACE_BLOCK]; \
+    __shared__ uint8_t lds_lut[2048]; \
+    order_table_init(lds_lut)
+
 template <bool STATS>
 __global__ __launch_bounds__(TRACE_BLOCK, TRACE_WPS) void k_trace_closest(SceneView sc, PathState st, HitBuf hits, Counters* cnt,
                                                                 uint32_t* spill, uint32_t* overflow, unsigned long long* stat_out, TraceTune tune) {
-    __shared__ uint32_t lds_stack[(STACK_LDS + 1) * TRACE_BLOCK];   // + one trash row for the branch-free pushes
+    TRACE_LDS_DECL;
     const uint32_t n = cnt->n_cur;
     unsigned long long nv = 0, nt = 0;
-    trace_wave_loop<false, STATS>(sc, n, &cnt->head_closest, lds_stack, spill, overflow, tune,
+    trace_wave_loop<false, STATS>(sc, n, &cnt->head_closest, lds_stack, lds_lut, spill, overflow, tune,
         [&](uint32_t i, f3& o, f3& d, float& tmax) -> bool {
             const float4 ro = st.ro[i];
             if (f2u(ro.w) & PATH_FLAG_ZOMBIE) return false;
@@ -353,10 +397,10 @@ __global__ __launch_bounds__(TRACE_BLOCK, TRACE_WPS) void k_trace_closest(SceneV
 template <bool STATS>
 __global__ __launch_bounds__(TRACE_BLOCK, TRACE_WPS) void k_trace_shadow(SceneView sc, ShadowQueue q, PathState next, Counters* cnt,
                                                                uint32_t* spill, uint32_t* overflow, unsigned long long* stat_out, TraceTune tune) {
-    __shared__ uint32_t lds_stack[(STACK_LDS + 1) * TRACE_BLOCK];   // + one trash row for the branch-free pushes
+    TRACE_LDS_DECL;
     const uint32_t n = cnt->n_shadow;
     unsigned long long nv = 0, nt = 0;
-    trace_wave_loop<true, STATS>(sc, n, &cnt->head_shadow, lds_stack, spill, overflow, tune,
+    trace_wave_loop<true, STATS>(sc, n, &cnt->head_shadow, lds_stack, lds_lut, spill, overflow, tune,
         [&](uint32_t i, f3& o, f3& d, float& tmax) -> bool {
             const float4 qo = q.o[i], qd = q.d[i];
             o = F3(qo.x, qo.y, qo.z); d = F3(qd.x, qd.y, qd.z); tmax = qo.w;
@@ -377,16 +421,19 @@ template <bool ANY_HIT>
 __global__ __launch_bounds__(TRACE_BLOCK, TRACE_WPS) void k_trace_probe(SceneView sc, const float* rays /*7 per ray: o,d,tmax*/, uint32_t n, uint32_t* head,
                                                               uint32_t* out_ids /*4 per ray: hit,inst,geo,prim*/, float* out_tuv /*3 per ray*/,
                                                               uint32_t* spill, uint32_t* overflow, TraceTune tune) {
-    __shared__ uint32_t lds_stack[(STACK_LDS + 1) * TRACE_BLOCK];   // + one trash row for the branch-free pushes
+    TRACE_LDS_DECL;
     unsigned long long nv = 0, nt = 0;
-    trace_wave_loop<ANY_HIT, false>(sc, n, head, lds_stack, spill, overflow, tune,
+    trace_wave_loop<ANY_HIT, false>(sc, n, head, lds_stack, lds_lut, spill, overflow, tune,
         [&](uint32_t i, f3& o, f3& d, float& tmax) -> bool {
             const float* r = rays + 7 * (size_t)i;
             o = F3(r[0], r[1], r[2]); d = F3(r[3], r[4], r[5]); tmax = r[6];
             return true;
         },
         [&](uint32_t i, const Lane& L) {
-            out_ids[4 * i] = L.best.inst != MAX_UINT ? 1u : 0u; out_ids[4 * i + 1] = L.best.inst; out_ids[4 * i + 2] = L.best.geo; out_ids[4 * i + 3] = L.best.prim;
+            const bool hit = L.best.inst != MAX_UINT;
+            uint32_t geo = 0, prim = 0;
+            if (hit && !ANY_HIT) { geo = sc.tris[L.best.tri].geo; prim = sc.tris[L.best.tri].prim; }
+            out_ids[4 * i] = hit ? 1u : 0u; out_ids[4 * i + 1] = L.best.inst; out_ids[4 * i + 2] = geo; out_ids[4 * i + 3] = prim;
             out_tuv[3 * i] = L.best.t; out_tuv[3 * i + 1] = L.best.u; out_tuv[3 * i + 2] = L.best.v;
         }, nv, nt, nullptr);
 }
@@ -411,6 +458,6 @@ void launch_trace_probe(hipStream_t s, int grid, const SceneView& sc, const floa
     else hipLaunchKernelGGL(k_trace_probe<false>, dim3(grid), dim3(TRACE_BLOCK), 0, s, sc, rays, n, head, out_ids, out_tuv, spill, overflow, tune);
 }
 int trace_blocks_per_cu() { return TRACE_WPS; }
-size_t trace_spill_words(int grid) { return (size_t)grid * TRACE_BLOCK * STACK_SPILL; }
+size_t trace_spill_words(int grid) { return (size_t)grid * TRACE_BLOCK * STACK_SPILL * 2; }
 
 }  // namespace msne

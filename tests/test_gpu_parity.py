@@ -241,8 +241,9 @@ def test_sharded_film_equals_unsharded(gpu_api):
         ptr, n = c.packed_film(ss)
         assert n == n4
         assert hip.hipMemcpy(C.c_void_p(gathered.value + i * n4 * 16), C.c_void_p(ptr), n4 * 16, 3) == 0
+    assert hip.hipDeviceSynchronize() == 0   # device-to-device hipMemcpy does not wait on the host; the library's streams are non-blocking
     shards[0].unpack_gathered(hs[0], gathered.value, G)
-    got = shards[0].sensor_data(hs[0])
+    got =shards[0].sensor_data(hs[0])
     assert np.array_equal(got.view(np.uint32), ref.view(np.uint32))
 
 
@@ -332,9 +333,10 @@ def test_s1_full_size_batching_and_sharding_invariance(gpu_api, s1_full):
     assert hip.hipMalloc(C.byref(gathered), G * n4 * 16) == 0
     for i, (sc, ss) in enumerate(zip(shards, hs)):
         assert hip.hipMemcpy(C.c_void_p(gathered.value + i * n4 * 16), C.c_void_p(sc.packed_film(ss)[0]), n4 * 16, 3) == 0
+    assert hip.hipDeviceSynchronize() == 0   # device-to-device hipMemcpy does not wait on the host; the library's streams are non-blocking
     shards[0].unpack_gathered(hs[0], gathered.value, G)
     assert np.array_equal(shards[0].sensor_data(hs[0]).view(np.uint32), film.view(np.uint32))
-    tot = {k: sum(sc.counters()[k] for sc in shards) for k in ("closest_rays", "shadow_rays", "samples")}
+    tot ={k: sum(sc.counters()[k] for sc in shards) for k in ("closest_rays", "shadow_rays", "samples")}
     assert tot == counters
 
 
