@@ -4,7 +4,7 @@
 // Pipeline (all HIP kernels, host only sequences launches and reads round / level counts):
 //   k_prim_boxes / k_bounds → k_morton (30-bit) → LSD radix sort 4 x 8 bit (k_radix_hist / _scan / _scatter)
 //   → PLOC rounds (k_ploc_nn / _mark / _scan / _merge: bottom-up agglomerative clustering, boxes come with the merges)
-//   → k_collapse (level-synchronous collapse to 8-wide in octant slot order, leaves <= leaf_max items, quantised 80-B nodes)
+//   → k_collapse (level-synchronous collapse to 8-wide in octant slot order, one item per leaf, quantised 80-B nodes)
 //   → k_emit_tris / k_emit_items.
 // The same builder serves BLAS (items = triangles) and TLAS (items = instances).
 #include "msne_device.h"
@@ -138,7 +138,6 @@ __global__ __launch_bounds__(64) void k_radix_scatter(const uint32_t* keys, cons
 constexpr uint32_t REF_LEAF = 0x80000000u;
 struct BinTree {
     uint32_t* left; uint32_t* right;         // child refs of internal node i (bit 31 = leaf: index into the sorted primitives)
-    uint32_t* count;                         // primitives under internal node i
     Box* box;                                // internal node boxes
 };
 
@@ -235,7 +234,6 @@ __global__ __launch_bounds__(PLOC_BLOCK) void k_ploc_merge(const uint32_t* cref,
         const uint32_t rj = cref[j]; const Box bj = cbox[j];
         for (int k = 0; k < 3; k++) { b.lo[k] = fminf(b.lo[k], bj.lo[k]); b.hi[k] = fmaxf(b.hi[k], bj.hi[k]); }
         t.left[id] = ref; t.right[id] = rj; t.box[id] = b;
-        t.count[id] = ((ref & REF_LEAF) ? 1u : t.count[ref]) + ((rj & REF_LEAF) ? 1u : t.count[rj]);
         ref = id;
     }
     oref[pos] = ref; obox[pos] = b;
@@ -250,20 +248,20 @@ __global__ void k_ploc_init(uint32_t n, uint32_t* cref) {
 struct CollapseWork { uint32_t bin; uint32_t wide; };
 
 __global__ void k_collapse(const CollapseWork* work, uint32_t nwork, CollapseWork* next, uint32_t* next_count,
-                           BinTree t, const Box* leaf_boxes, const uint32_t* sorted_idx, uint32_t leaf_max, uint32_t slot_items,
+                           BinTree t, const Box* leaf_boxes, const uint32_t* sorted_idx,
                            Node8* nodes, uint32_t* node_counter, uint32_t* item_counter, uint32_t* item_src) {
     const uint32_t w = blockIdx.x * blockDim.x + threadIdx.x;
     if (w >= nwork) return;
     const uint32_t bin = work[w].bin, widx = work[w].wide;
+    // Every leaf holds ONE primitive: a watertight triangle test costs about five quantised box tests in k_trace_*, so it
+    // pays to box every triangle on its own (S1: 9.3 -> 4.2 triangle tests per ray for 12.5 -> 13.6 node visits).
     uint32_t ch[8]; int nch = 0;
-    auto prims = [&](uint32_t r) -> uint32_t { return (r & REF_LEAF) ? 1u : t.count[r]; };
-    auto leaf_like = [&](uint32_t r) -> bool { return prims(r) <= leaf_max; };
     auto ref_box = [&](uint32_t r) -> Box { return (r & REF_LEAF) ? leaf_boxes[r & ~REF_LEAF] : t.box[r]; };
-    if (leaf_like(bin)) ch[nch++] = bin;
+    if (bin & REF_LEAF) ch[nch++] = bin;
     else { ch[nch++] = t.left[bin]; ch[nch++] = t.right[bin]; }
-    while (nch < 8) {
+    while (nch < 8) {   // open the internal child with the largest surface area until the node is full
         int best = -1; float ba = -1.0f;
-        for (int i = 0; i < nch; i++) if (!leaf_like(ch[i])) { Box b = ref_box(ch[i]); float ar = box_area(b); if (ar > ba) { ba = ar; best = i; } }
+        for (int i = 0; i < nch; i++) if (!(ch[i] & REF_LEAF)) { Box b = ref_box(ch[i]); float ar = box_area(b); if (ar > ba) { ba = ar; best = i; } }
         if (best < 0) break;
         const uint32_t c = ch[best];
         ch[best] = t.left[c]; ch[nch++] = t.right[c];
@@ -274,8 +272,7 @@ __global__ void k_collapse(const CollapseWork* work, uint32_t nwork, CollapseWor
     for (int i = 0; i < nch; i++) {
         cb[i] = ref_box(ch[i]);
         for (int k = 0; k < 3; k++) { nb.lo[k] = fminf(nb.lo[k], cb[i].lo[k]); nb.hi[k] = fmaxf(nb.hi[k], cb[i].hi[k]); }
-        if (leaf_like(ch[i])) n_items += prims(ch[i]);
-        else n_internal++;
+        if (ch[i] & REF_LEAF) n_items++; else n_internal++;
     }
     // Octant placement: slot s stands for the corner direction (s&1 ? +x : -x, s&2 ? +y : -y, s&4 ? +z : -z) of the node.
     // Children are matched to slots greedily by the projection of (child centre - node centre) on that direction, so
@@ -295,7 +292,6 @@ __global__ void k_collapse(const CollapseWork* work, uint32_t nwork, CollapseWor
             child_of_slot[bs] = bi; child_done |= 1u << bi;
         }
     }
-    if (slot_items && n_items) n_items = 8;   // TLAS: the item of the leaf in slot s lives at item_base + s (unused slots = MAX_UINT)
     const uint32_t child_base = n_internal ? atomicAdd(node_counter, n_internal) : 0u;
     const uint32_t item_base = n_items ? atomicAdd(item_counter, n_items) : 0u;
     const uint32_t qpos = n_internal ? atomicAdd(next_count, n_internal) : 0u;
@@ -314,13 +310,10 @@ __global__ void k_collapse(const CollapseWork* work, uint32_t nwork, CollapseWor
         inv_s[k] = u2f((uint32_t)(254 - ex) << 23);   // 2^-(ex-127)
     }
     nd.ex = e[0]; nd.ey = e[1]; nd.ez = e[2];
-    uint32_t imask = 0, ii = 0, io = 0;
-    for (int i = 0; i < 8; i++) {
-        nd.meta[i] = 0xff;
-        for (int k = 0; k < 3; k++) { nd.qlo[k][i] = 255; nd.qhi[k][i] = 0; }
-    }
-    if (slot_items && n_items) for (int s = 0; s < 8; s++) item_src[item_base + s] = MAX_UINT;
-    for (int s = 0; s < 8; s++) {
+    uint32_t imask = 0, lmask = 0, ii = 0, io = 0;
+    for (int i = 0; i < 8; i++) for (int k = 0; k < 3; k++) { nd.qlo[k][i] = 255; nd.qhi[k][i] = 0; }
+    for (int i = 0; i < 7; i++) nd.pad[i] = 0;
+    for (int s = 0; s < 8; s++) {   // internal children and leaf items are both numbered in slot order
         const int i = child_of_slot[s];
         if (i < 0) continue;
         for (int k = 0; k < 3; k++) {
@@ -330,26 +323,16 @@ __global__ void k_collapse(const CollapseWork* work, uint32_t nwork, CollapseWor
             ql = fminf(fmaxf(ql, 0.0f), 255.0f); qh = fminf(fmaxf(qh, 0.0f), 255.0f);
             nd.qlo[k][s] = (uint8_t)ql; nd.qhi[k][s] = (uint8_t)qh;
         }
-        if (leaf_like(ch[i])) {
-            const uint32_t cnt = prims(ch[i]);
-            const uint32_t out = slot_items ? item_base + s : item_base + io;
-            nd.meta[s] = slot_items ? (uint8_t)s : (uint8_t)(((cnt - 1u) << 5) | io);
-            uint32_t stk[8]; int sp = 0; uint32_t q = 0;   // the primitives of the (at most leaf_max-leaf) subtree, left to right
-            stk[sp++] = ch[i];
-            while (sp) {
-                const uint32_t r = stk[--sp];
-                if (r & REF_LEAF) item_src[out + q++] = sorted_idx[r & ~REF_LEAF];
-                else { stk[sp++] = t.right[r]; stk[sp++] = t.left[r]; }
-            }
-            if (!slot_items) io += cnt;
-        } else {   // internal children are numbered in slot order: child index = child_base + popcount(imask below s)
+        if (ch[i] & REF_LEAF) {
+            lmask |= 1u << s;
+            item_src[item_base + io++] = sorted_idx[ch[i] & ~REF_LEAF];
+        } else {
             imask |= 1u << s;
-            nd.meta[s] = 0;
             next[qpos + ii].bin = ch[i]; next[qpos + ii].wide = child_base + ii;
             ii++;
         }
     }
-    nd.imask = (uint8_t)imask;
+    nd.imask = (uint8_t)imask; nd.lmask = (uint8_t)lmask;
     nd.child_base = child_base; nd.item_base = item_base;
     nodes[widx] = nd;
 }
@@ -373,7 +356,7 @@ __global__ void k_emit_tris(const BlasGeo* geos, uint32_t ngeo, const uint32_t* 
 }
 __global__ void k_emit_items(const uint32_t* item_src, uint32_t item_begin, uint32_t n, const uint32_t* ids, uint32_t* out) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) { const uint32_t src = item_src[item_begin + i]; out[item_begin + i] = src == MAX_UINT ? MAX_UINT : ids[src]; }
+    if (i < n) out[item_begin + i] = ids[item_src[item_begin + i]];
 }
 
 // ---------------- host orchestration ----------------
@@ -383,14 +366,14 @@ struct BuildScratch {
     uint32_t cap = 0;
     Box *boxes = nullptr, *sorted = nullptr, *ibox = nullptr;
     uint32_t *keys = nullptr, *keys2 = nullptr, *idx = nullptr, *idx2 = nullptr, *ghist = nullptr, *bounds = nullptr;
-    uint32_t *left = nullptr, *right = nullptr, *count = nullptr;
+    uint32_t *left = nullptr, *right = nullptr;
     CollapseWork *wa = nullptr, *wb = nullptr;
     uint32_t* next_count = nullptr;
     Box *cba = nullptr, *cbb = nullptr;                                       // PLOC cluster boxes (ping-pong)
     uint32_t *cra = nullptr, *crb = nullptr, *nn = nullptr, *pflags = nullptr, *bsum = nullptr, *totals = nullptr;
     uint2* bbase = nullptr;
     void release() {
-        void* p[] = { boxes, sorted, ibox, keys, keys2, idx, idx2, ghist, bounds, left, right, count, wa, wb, next_count,
+        void* p[] = { boxes, sorted, ibox, keys, keys2, idx, idx2, ghist, bounds, left, right, wa, wb, next_count,
                       cba, cbb, cra, crb, nn, pflags, bsum, totals, bbase };
         for (void* q : p) if (q) (void)hipFree(q);
         *this = BuildScratch();
@@ -403,7 +386,7 @@ struct BuildScratch {
         HIPCHK(hipMalloc(&boxes, N * sizeof(Box))); HIPCHK(hipMalloc(&sorted, N * sizeof(Box))); HIPCHK(hipMalloc(&ibox, N * sizeof(Box)));
         HIPCHK(hipMalloc(&keys, N * 4)); HIPCHK(hipMalloc(&keys2, N * 4)); HIPCHK(hipMalloc(&idx, N * 4)); HIPCHK(hipMalloc(&idx2, N * 4));
         HIPCHK(hipMalloc(&ghist, (size_t)ntiles * 256 * 4)); HIPCHK(hipMalloc(&bounds, 6 * 4));
-        HIPCHK(hipMalloc(&left, N * 4)); HIPCHK(hipMalloc(&right, N * 4)); HIPCHK(hipMalloc(&count, N * 4));
+        HIPCHK(hipMalloc(&left, N * 4)); HIPCHK(hipMalloc(&right, N * 4));
         HIPCHK(hipMalloc(&wa, N * sizeof(CollapseWork))); HIPCHK(hipMalloc(&wb, N * sizeof(CollapseWork)));
         HIPCHK(hipMalloc(&next_count, 4));
         const size_t nb = (N + PLOC_BLOCK - 1) / PLOC_BLOCK;
@@ -421,7 +404,7 @@ void bvh_release_scratch() { g_scratch.release(); }
 // Builds a wide BVH over the n boxes in g_scratch.boxes.  Nodes are appended at *node_counter (device),
 // items at *item_counter; item_src[pos] = source box index for final item position pos.
 // Returns the root node index and the root box (host).
-static bool build_from_boxes(hipStream_t s, uint32_t n, uint32_t leaf_max, uint32_t slot_items, Node8* nodes, uint32_t* node_counter, uint32_t node_capacity,
+static bool build_from_boxes(hipStream_t s, uint32_t n, Node8* nodes, uint32_t* node_counter, uint32_t node_capacity,
                              uint32_t* item_counter, uint32_t* item_src, uint32_t* root_out, Box* root_box) {
     BuildScratch& S = g_scratch;
     const uint32_t ntiles = (n + RS_TILE - 1) / RS_TILE;
@@ -439,7 +422,7 @@ static bool build_from_boxes(hipStream_t s, uint32_t n, uint32_t leaf_max, uint3
     }
     // after 4 passes (ka,va) are back in (keys, idx)
     hipLaunchKernelGGL(k_gather_boxes, dim3((n + 255) / 256), dim3(256), 0, s, S.boxes, va, n, S.sorted);
-    BinTree t{ S.left, S.right, S.count, S.ibox };
+    BinTree t{ S.left, S.right, S.ibox };
     uint32_t root_ref;
     if (n >= 2) {
         HIPCHK(hipMemcpyAsync(S.cba, S.sorted, (size_t)n * sizeof(Box), hipMemcpyDeviceToDevice, s));
@@ -480,7 +463,7 @@ static bool build_from_boxes(hipStream_t s, uint32_t n, uint32_t leaf_max, uint3
     CollapseWork *cur = S.wa, *nxt = S.wb;
     while (nwork) {
         HIPCHK(hipMemsetAsync(S.next_count, 0, 4, s));
-        hipLaunchKernelGGL(k_collapse, dim3((nwork + 63) / 64), dim3(64), 0, s, cur, nwork, nxt, S.next_count, t, S.sorted, va, leaf_max, slot_items,
+        hipLaunchKernelGGL(k_collapse, dim3((nwork + 63) / 64), dim3(64), 0, s, cur, nwork, nxt, S.next_count, t, S.sorted, va,
                            nodes, node_counter, item_counter, item_src);
         HIPCHK(hipMemcpyAsync(&nwork, S.next_count, 4, hipMemcpyDeviceToHost, s));
         HIPCHK(hipStreamSynchronize(s));
@@ -502,10 +485,7 @@ bool bvh_build_blas(hipStream_t s, const std::vector<BlasGeo>& geos, uint32_t nt
     uint32_t item_begin = 0;
     HIPCHK(hipMemcpyAsync(&item_begin, tri_counter, 4, hipMemcpyDeviceToHost, s));
     Box rb;
-    // One triangle per leaf: a watertight triangle test costs ~5 quantised box tests in k_trace_*, so it pays to box every
-    // triangle on its own (S1: 9.3 → 4.2 triangle tests per ray for 12.5 → 13.6 node visits).  $MSNE_LEAF_MAX = 1..4 to experiment.
-    static const uint32_t leaf_max = [] { const char* e = getenv("MSNE_LEAF_MAX"); const int v = e ? atoi(e) : 1; return (uint32_t)(v < 1 ? 1 : (v > 4 ? 4 : v)); }();
-    bool ok = build_from_boxes(s, ntris, leaf_max, 0, nodes, node_counter, node_capacity, tri_counter, item_src, root_out, &rb);
+    bool ok = build_from_boxes(s, ntris, nodes, node_counter, node_capacity, tri_counter, item_src, root_out, &rb);
     if (ok) {
         hipLaunchKernelGGL(k_emit_tris, dim3((ntris + 255) / 256), dim3(256), 0, s, dgeos, (uint32_t)geos.size(), item_src, item_begin, ntris, tris);
         HIPCHK(hipStreamSynchronize(s));
@@ -527,13 +507,9 @@ bool bvh_build_tlas(hipStream_t s, const float* host_boxes, const uint32_t* host
     uint32_t item_begin = 0;
     HIPCHK(hipMemcpyAsync(&item_begin, item_counter, 4, hipMemcpyDeviceToHost, s));
     Box rb;
-    bool ok = build_from_boxes(s, n, 1, 1, nodes, node_counter, node_capacity, item_counter, item_src, root_out, &rb);
-    if (ok) {   // 8 item slots per TLAS node that has instance leaves
-        uint32_t item_end = 0;
-        HIPCHK(hipMemcpyAsync(&item_end, item_counter, 4, hipMemcpyDeviceToHost, s));
-        HIPCHK(hipStreamSynchronize(s));
-        const uint32_t m = item_end - item_begin;
-        if (m) hipLaunchKernelGGL(k_emit_items, dim3((m + 255) / 256), dim3(256), 0, s, item_src, item_begin, m, dids, tlas_items);
+    bool ok = build_from_boxes(s, n, nodes, node_counter, node_capacity, item_counter, item_src, root_out, &rb);
+    if (ok) {
+        hipLaunchKernelGGL(k_emit_items, dim3((n + 255) / 256), dim3(256), 0, s, item_src, item_begin, n, dids, tlas_items);
         HIPCHK(hipStreamSynchronize(s));
     }
     (void)hipFree(dids);

@@ -138,7 +138,7 @@ struct HdMoonshine {
     size_t lbuf_cap = 0;
     DevBuf<uint32_t> d_overflow; DevBuf<unsigned long long> d_trace_stats;
     int trace_grid = 1024, shade_grid = 2048;
-    uint32_t tune[4] = { 16, 24, 24, 8 };   // traversal: lane-refill threshold, phase-vote thresholds (node, triangle, instance); $MSNE_TUNE=a,b,c,d
+    uint32_t tune[4] = { 16, 16, 32, 12 };  // traversal: lane-refill threshold, phase-vote thresholds (node lanes, triangle lanes, blocked lanes); $MSNE_TUNE=a,b,c,d
     size_t max_inflight = 160u << 20;  // most paths traced concurrently (276 B of wavefront state each, allocated on demand); $MSNE_MAX_INFLIGHT
     // statistics
     MsneStats stats{};
@@ -320,8 +320,7 @@ bool HdMoonshine::rebuild_accel() {
         CHECK_HIP(this, hipStreamSynchronize(stream));
         std::swap(nn.p, d_nodes.p); std::swap(nn.n, d_nodes.n);
     }
-    // TLAS items: 8 slots per TLAS node with instance leaves (item = item_base + child slot), at most one such node per instance
-    if (!d_item_src.ensure(std::max(d_tris.n, 8 * (N + 2))) || !d_tlas_items.ensure(8 * (N + 2))) { fail("out of device memory (items)"); return false; }
+    if (!d_item_src.ensure(std::max(d_tris.n, N + 2)) || !d_tlas_items.ensure(N + 2)) { fail("out of device memory (items)"); return false; }
     // counters: node count resumes after the BLAS region (the previous TLAS is discarded)
     { uint32_t c[4] = { blas_nodes_end, blas_tris_end, 0u, 0u }; CHECK_HIP(this, hipMemcpyAsync(d_build_counters.p, c, 16, hipMemcpyHostToDevice, stream)); CHECK_HIP(this, hipStreamSynchronize(stream)); }
     for (size_t i = 0; i < N; i++) {

@@ -6,14 +6,16 @@ namespace msne {
 
 // ---- acceleration structure ----
 // 8-wide quantized node, 80 B = 5 x 16 B.  Child boxes: lo = origin + qlo * 2^(e-127) per axis.
-// imask bit i: child i is an internal node at nodes[child_base + popcount(imask & ((1<<i)-1))].
-// otherwise meta[i] == 0xFF: empty; else leaf with ((meta>>5)+1) items starting at item_base + (meta & 31).
+// Children sit in octant order (slot bit k set = the child lies on the + side of axis k of the node).
+// imask bit i: slot i is an internal node at nodes[child_base + popcount(imask & ((1<<i)-1))];
+// lmask bit i: slot i is a leaf holding ONE item (triangle record / TLAS instance) at item_base + popcount(lmask & ((1<<i)-1));
+// neither: empty slot (inverted box).
 struct alignas(16) Node8 {
     float ox, oy, oz;
     uint8_t ex, ey, ez, imask;
     uint32_t child_base;
     uint32_t item_base;
-    uint8_t meta[8];
+    uint8_t lmask, pad[7];
     uint8_t qlo[3][8];
     uint8_t qhi[3][8];
 };
