@@ -141,9 +141,9 @@ def main():
         # HBM bytes per launch from the committed PMC passes (tools/profile_round.sh; FETCH_SIZE x2 + WRITE_SIZE) — only valid
         # for the exact configuration they were collected on
         traffic = None
-        tp = os.path.join(ROOT, "profiles", "r01_traffic.json")
-        if os.path.exists(tp) and world == 1 and a.steps == 64 and (a.width, a.height, a.env) == (1920, 1080, "constant"):
-            traffic = json.load(open(tp))["traffic_bytes_per_launch"]
+        tps = sorted(f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("_traffic.json"))   # newest round last
+        if tps and world == 1 and a.steps == 64 and (a.width, a.height, a.env) == (1920, 1080, "constant"):
+            traffic = json.load(open(os.path.join(ROOT, "profiles", tps[-1])))["traffic_bytes_per_launch"]
         out = {
             "metric": "Mrays/sec, 1M-tri scene @1080p", "value": rays / dt / 1e6, "unit": "Mrays/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3,

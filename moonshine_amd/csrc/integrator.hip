@@ -10,7 +10,7 @@
 
 namespace msne {
 
-constexpr int SHADE_BLOCK = 256;
+constexpr int SHADE_BLOCK = 256;   // k_shade is left at its natural 153 VGPRs (3 waves/SIMD): capping it at 128 / 96 spills and is 15 % / 80 % slower
 
 __device__ __forceinline__ uint32_t wave_append(uint32_t* counter, bool pred) {
     const unsigned long long m = __ballot(pred);
@@ -93,10 +93,51 @@ __global__ __launch_bounds__(SHADE_BLOCK) void k_shade(SceneView sc, PipelineOpt
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     const unsigned long long lt = lane == 0 ? 0ull : (~0ull >> (64 - lane));
     const uint32_t n_pad = (n + (SHADE_BLOCK - 1u)) & ~(SHADE_BLOCK - 1u);   // trip count uniform per workgroup (it synchronises below)
-    for (uint32_t i = blockIdx.x * SHADE_BLOCK + threadIdx.x; i < n_pad; i += gridDim.x * SHADE_BLOCK) {
+    // Paths are shaded in an order sorted by what they will execute (finalise / miss / material type), 256 at a time: the
+    // reference's megakernel diverges per pixel, here a wave runs one BSDF.  Results are per sample slot, so the order
+    // inside a workgroup is free.
+    constexpr uint32_t CAT_NONE = 6u, NCAT = 6u;   // 0 zombie, 1 miss, 2 + material type (MAT_GLASS .. MAT_PBR)
+    __shared__ uint32_t s_cat[NCAT * (SHADE_BLOCK / 64) + 1];
+    __shared__ uint32_t s_perm[SHADE_BLOCK];
+    for (uint32_t base_i = blockIdx.x * SHADE_BLOCK; base_i < n_pad; base_i += gridDim.x * SHADE_BLOCK) {
+        uint32_t cat = CAT_NONE;
+        {
+            const uint32_t i0 = base_i + threadIdx.x;
+            if (i0 < n) {
+                const uint32_t fl = f2u(cur.ro[i0].w);
+                if (!(fl & PATH_FLAG_MASKED)) {
+                    if (fl & PATH_FLAG_ZOMBIE) cat = 0u;
+                    else {
+                        const uint4 hr = hits.rec[i0];
+                        if (hr.x == MAX_UINT) cat = 1u;
+                        else {
+                            const uint32_t geo = sc.tris[hr.y].geo;
+                            cat = 2u + (sc.materials[sc.geometries[sc.instances[hr.x].geo_offset + geo].material].type & 3u);
+                        }
+                    }
+                }
+            }
+            uint32_t rank = 0;
+#pragma unroll
+            for (uint32_t c = 0; c < NCAT; c++) {
+                const unsigned long long m = __ballot(cat == c);
+                if (cat == c) rank = (uint32_t)__popcll(m & lt);
+                if (lane == 0) s_cat[c * (SHADE_BLOCK / 64) + wave] = (uint32_t)__popcll(m);
+            }
+            __syncthreads();
+            if (threadIdx.x == 0) {   // exclusive scan over (category, wave); the total lands in the last entry
+                uint32_t run = 0;
+                for (uint32_t k = 0; k < NCAT * (SHADE_BLOCK / 64); k++) { const uint32_t v = s_cat[k]; s_cat[k] = run; run += v; }
+                s_cat[NCAT * (SHADE_BLOCK / 64)] = run;
+            }
+            __syncthreads();
+            if (cat != CAT_NONE) s_perm[s_cat[cat * (SHADE_BLOCK / 64) + wave] + rank] = threadIdx.x;
+            __syncthreads();
+        }
+        const bool live = threadIdx.x < s_cat[NCAT * (SHADE_BLOCK / 64)];
+        const uint32_t i = live ? base_i + s_perm[threadIdx.x] : n_pad;
         float4 ro4 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-        if (i < n) ro4 = cur.ro[i];
-        const bool live = i < n && !(f2u(ro4.w) & PATH_FLAG_MASKED);
+        if (live) ro4 = cur.ro[i];
         bool cont = false, sh0 = false, sh1 = false;
         // state carried to the next bounce
         f3 rayO = F3(0, 0, 0), rayD = F3(0, 0, 1), throughput = F3(0, 0, 0), L = F3(0, 0, 0), c0 = F3(0, 0, 0), c1 = F3(0, 0, 0);
