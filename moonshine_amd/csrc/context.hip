@@ -429,6 +429,7 @@ SceneView HdMoonshine::scene_view() const {
     SceneView v{};
     v.nodes = d_nodes.p; v.tris = d_tris.p; v.tlas_items = d_tlas_items.p; v.instances = d_instances.p; v.geometries = d_geometries.p;
     v.meshes = d_meshes.p; v.materials = d_materials.p; v.textures = d_texdesc.p; v.texels = d_texels.p; v.alias = d_alias.p;
+    if (!h_alias.empty()) { v.alias_count = h_alias[0].alias; v.alias_sum = h_alias[0].select; }
     v.env = env; v.tlas_root = tlas_root; v.root_in_blas = root_in_blas;
     return v;
 }

@@ -99,6 +99,7 @@ __global__ __launch_bounds__(SHADE_BLOCK) void k_shade(SceneView sc, PipelineOpt
     constexpr uint32_t CAT_NONE = 6u, NCAT = 6u;   // 0 zombie, 1 miss, 2 + material type (MAT_GLASS .. MAT_PBR)
     __shared__ uint32_t s_cat[NCAT * (SHADE_BLOCK / 64) + 1];
     __shared__ uint32_t s_perm[SHADE_BLOCK];
+    __shared__ uint4 s_hit[SHADE_BLOCK], s_geo[SHADE_BLOCK];   // what the sort already fetched: hit record, {geometry record, material type}
     for (uint32_t base_i = blockIdx.x * SHADE_BLOCK; base_i < n_pad; base_i += gridDim.x * SHADE_BLOCK) {
         uint32_t cat = CAT_NONE;
         {
@@ -109,10 +110,14 @@ __global__ __launch_bounds__(SHADE_BLOCK) void k_shade(SceneView sc, PipelineOpt
                     if (fl & PATH_FLAG_ZOMBIE) cat = 0u;
                     else {
                         const uint4 hr = hits.rec[i0];
+                        s_hit[threadIdx.x] = hr;
                         if (hr.x == MAX_UINT) cat = 1u;
                         else {
                             const uint32_t geo = sc.tris[hr.y].geo;
-                            cat = 2u + (sc.materials[sc.geometries[sc.instances[hr.x].geo_offset + geo].material].type & 3u);
+                            const GeometryRec g = sc.geometries[sc.instances[hr.x].geo_offset + geo];
+                            const uint32_t type = sc.materials[g.material].type;
+                            s_geo[threadIdx.x] = make_uint4(g.mesh, g.material, g.sampled, type);
+                            cat = 2u + (type & 3u);
                         }
                     }
                 }
@@ -135,7 +140,8 @@ __global__ __launch_bounds__(SHADE_BLOCK) void k_shade(SceneView sc, PipelineOpt
             __syncthreads();
         }
         const bool live = threadIdx.x < s_cat[NCAT * (SHADE_BLOCK / 64)];
-        const uint32_t i = live ? base_i + s_perm[threadIdx.x] : n_pad;
+        const uint32_t src = live ? s_perm[threadIdx.x] : 0u;   // the thread that classified this path
+        const uint32_t i = live ? base_i + src : n_pad;
         float4 ro4 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
         if (live) ro4 = cur.ro[i];
         bool cont = false, sh0 = false, sh1 = false;
@@ -155,7 +161,7 @@ __global__ __launch_bounds__(SHADE_BLOCK) void k_shade(SceneView sc, PipelineOpt
             const uint32_t bounceCount = flags & 0xFFFFu;
             const bool isLastMaterialDelta = (flags & PATH_FLAG_DELTA) != 0;
             bool done = (flags & PATH_FLAG_ZOMBIE) != 0;
-            const uint4 hrec = hits.rec[i];
+            const uint4 hrec = s_hit[src];
             const uint32_t hinst = hrec.x;
             if (!done && hinst == MAX_UINT) {
                 // miss epilogue, integrator.hlsl:168-181
@@ -169,8 +175,9 @@ __global__ __launch_bounds__(SHADE_BLOCK) void k_shade(SceneView sc, PipelineOpt
             }
             if (!done) {
                 const uint32_t htri = hrec.y;
-                GeometryRec geometry;
-                const Attrs attrs = mesh_attributes_world(sc, opts.indexed_attributes != 0, hinst, 0u, 0u, F2(u2f(hrec.z), u2f(hrec.w)), geometry, htri);
+                const uint4 pg = s_geo[src];
+                GeometryRec geometry; geometry.mesh = pg.x; geometry.material = pg.y; geometry.sampled = pg.z;
+                const Attrs attrs = mesh_attributes_world(sc, opts.indexed_attributes != 0, hinst, 0u, 0u, F2(u2f(hrec.z), u2f(hrec.w)), geometry, htri, true);
                 const MaterialRec mrec = sc.materials[geometry.material];
                 const Frame textureFrame = get_texture_frame(sc, mrec, opts.two_component_normal_texture != 0, attrs.texcoord, attrs.frame);
                 const f3 emissiveLight = tex_sample_rgb(sc, mrec.emissive, attrs.texcoord);
@@ -189,7 +196,7 @@ __global__ __launch_bounds__(SHADE_BLOCK) void k_shade(SceneView sc, PipelineOpt
                 if (mesh_n == 0 || bounceCount == 0 || !geo_sampled || isLastMaterialDelta) {
                     if (dot(woWs, attrs.triangleFrame.n) > 0.0f) L = add(L, mul(throughput, emissiveLight));
                 } else if (geo_sampled) {
-                    const float sum = sc.alias[0].select;
+                    const float sum = sc.alias_sum;
                     const float lightPdf = area_to_solid_angle(attrs.position, rayO, rayD, attrs.triangleFrame.n) / sum;
                     if (lightPdf > 0.0f) { const float weight = power_heuristic(1, lastPdf, mesh_n, lightPdf); L = add(L, scale(mul(throughput, emissiveLight), weight)); }
                 }
@@ -215,8 +222,8 @@ __global__ __launch_bounds__(SHADE_BLOCK) void k_shade(SceneView sc, PipelineOpt
                         }
                         if (mesh_n) {  // integrator.hlsl:147-150 + MeshLights::sample light.hlsl:130-158
                             f2 rand; rand.x = rng_float(rng); rand.y = rng_float(rng);
-                            const uint32_t entryCount = sc.alias[0].alias;
-                            const float sum = sc.alias[0].select;
+                            const uint32_t entryCount = sc.alias_count;
+                            const float sum = sc.alias_sum;
                             if (!(entryCount == 0 || sum == 0.0f)) {
                                 const float scaled = rand.x * (float)entryCount;
                                 uint32_t idx = (uint32_t)scaled;

@@ -70,6 +70,7 @@ struct SceneView {
     const TexDesc* textures;
     const float4* texels;
     const AliasEntry* alias;          // entry 0 = header {count, sum}
+    uint32_t alias_count; float alias_sum;   // copy of the header: kernel arguments instead of a dependent load per path
     EnvView env;
     uint32_t tlas_root;               // MAX_UINT when the scene is empty
     uint32_t root_in_blas;            // 1: tlas_root is the root of the merged world BLAS (no TLAS level at all)

@@ -66,7 +66,8 @@ __device__ __forceinline__ f2 ld2(const float* p, uint32_t i) { return F2(p[2 * 
 // the BVH's 48-B record already holds the three vertices (bit-identical copies), the geometry and the primitive index,
 // which removes three dependent loads from every hit; indices are only fetched when the mesh has normals or texcoords.
 __device__ __forceinline__ Attrs mesh_attributes_world(const SceneView& sc, bool indexed_attributes, uint32_t instanceIndex, uint32_t geometryIndex,
-                                                       uint32_t primitiveIndex, f2 attribs, GeometryRec& geo_out, uint32_t tri_slot = MAX_UINT) {
+                                                       uint32_t primitiveIndex, f2 attribs, GeometryRec& geo_out, uint32_t tri_slot = MAX_UINT,
+                                                       bool geo_known = false /* geo_out already holds the geometry record of the hit */) {
     const InstanceRec* inst = sc.instances + instanceIndex;
     const f3 bary = F3(1.0f - attribs.x - attribs.y, attribs.x, attribs.y);
     Attrs a;
@@ -75,10 +76,9 @@ __device__ __forceinline__ Attrs mesh_attributes_world(const SceneView& sc, bool
     if (tri_slot != MAX_UINT) {
         const uint4* tp = reinterpret_cast<const uint4*>(sc.tris + tri_slot);
         const uint4 ta = tp[0], tb = tp[1], tc = tp[2];
-        const uint32_t instanceID = inst->geo_offset;
         p0 = F3(u2f(ta.x), u2f(ta.y), u2f(ta.z)); p1 = F3(u2f(ta.w), u2f(tb.x), u2f(tb.y)); p2 = F3(u2f(tb.z), u2f(tb.w), u2f(tc.x));
         geometryIndex = tc.y; primitiveIndex = tc.z;
-        g = sc.geometries[instanceID + geometryIndex];
+        g = geo_known ? geo_out : sc.geometries[inst->geo_offset + geometryIndex];
         mesh.positions = nullptr; mesh.texcoords = nullptr; mesh.normals = nullptr; mesh.indices = nullptr;
         if (g.sampled & (GEO_HAS_TEXCOORDS | GEO_HAS_NORMALS)) {
             mesh = sc.meshes[g.mesh];
