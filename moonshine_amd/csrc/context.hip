@@ -26,6 +26,7 @@ int trace_blocks_per_cu();
 void launch_raygen(hipStream_t, int, const ShardView&, const CameraConsts&, const PipelineOpts&, uint32_t, uint32_t, const PathState&, Counters*);
 void launch_shade(hipStream_t, int, const SceneView&, const PipelineOpts&, const PathState&, const HitBuf&, const PathState&, const ShadowQueue&, float4*, Counters*);
 void launch_advance(hipStream_t, Counters*, int, uint32_t, uint32_t);
+void launch_light_tris(hipStream_t, const SceneView&, uint32_t, uint32_t, LightTri*);
 void launch_film(hipStream_t, int, const ShardView&, const PipelineOpts&, const float4*, uint32_t, uint32_t, int, int, uint32_t, float4*, float4*);
 void launch_unpack_film(hipStream_t, int, const ShardView&, const float4*, uint32_t, uint32_t, size_t, float4*);
 void launch_env_build(hipStream_t, const float4*, uint32_t, uint32_t, float4*, float*, const uint32_t*, uint32_t, uint32_t);
@@ -111,6 +112,7 @@ struct HdMoonshine {
     DevBuf<GeometryRec> d_geometries;
     DevBuf<InstanceRec> d_instances;
     DevBuf<AliasEntry> d_alias;
+    DevBuf<LightTri> d_light_tris; bool lights_dirty = true; uint32_t lights_indexed = 0;   // gathered light triangles (rebuilt with the alias table / attribute mode)
     DevBuf<Node8> d_nodes; DevBuf<TriRec> d_tris; DevBuf<uint32_t> d_tlas_items, d_item_src;
     DevBuf<uint32_t> d_build_counters;    // [0] node count, [1] tri count, [2] tlas item count
     uint32_t blas_nodes_end = 0, blas_tris_end = 0;
@@ -413,6 +415,7 @@ bool HdMoonshine::rebuild_accel() {
     h_alias[0].alias = (uint32_t)w.size(); h_alias[0].select = sum;
     if (!d_alias.alloc(h_alias.size())) { fail("out of device memory (alias table)"); return false; }
     CHECK_HIP(this, hipMemcpyAsync(d_alias.p, h_alias.data(), h_alias.size() * sizeof(AliasEntry), hipMemcpyHostToDevice, stream));
+    lights_dirty = true;
     CHECK_HIP(this, hipStreamSynchronize(stream));
     accel_dirty = false;
     return true;
@@ -422,6 +425,15 @@ bool HdMoonshine::ensure_scene() {
     if (textures_dirty && !upload_textures()) return false;
     if ((materials_dirty || !material_updates.empty()) && !upload_materials()) return false;
     if (accel_dirty && !rebuild_accel()) return false;
+    if (lights_dirty || lights_indexed != opts.indexed_attributes) {
+        const uint32_t count = h_alias.empty() ? 0u : h_alias[0].alias;
+        if (count) {
+            if (!d_light_tris.alloc((size_t)count + 1)) { fail("out of device memory (light triangles)"); return false; }
+            launch_light_tris(stream, scene_view(), opts.indexed_attributes, (uint32_t)instances.size(), d_light_tris.p);
+            CHECK_HIP(this, hipStreamSynchronize(stream));
+        }
+        lights_dirty = false; lights_indexed = opts.indexed_attributes;
+    }
     return true;
 }
 
@@ -430,6 +442,7 @@ SceneView HdMoonshine::scene_view() const {
     v.nodes = d_nodes.p; v.tris = d_tris.p; v.tlas_items = d_tlas_items.p; v.instances = d_instances.p; v.geometries = d_geometries.p;
     v.meshes = d_meshes.p; v.materials = d_materials.p; v.textures = d_texdesc.p; v.texels = d_texels.p; v.alias = d_alias.p;
     if (!h_alias.empty()) { v.alias_count = h_alias[0].alias; v.alias_sum = h_alias[0].select; }
+    v.light_tris = d_light_tris.p;
     v.env = env; v.tlas_root = tlas_root; v.root_in_blas = root_in_blas;
     return v;
 }

@@ -64,6 +64,31 @@ __global__ __launch_bounds__(SHADE_BLOCK) void k_raygen(ShardView sh, CameraCons
     }
 }
 
+// one record per alias-table entry (+ one for the zero entry): the loads of MeshAttributes::lookupAndInterpolate (world.hlsl:114-158), done once
+__global__ void k_light_tris(SceneView sc, uint32_t indexed_attributes, uint32_t n_instances, LightTri* out) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i > sc.alias_count) return;
+    AliasEntry en; en.alias = 0; en.select = 0.0f; en.instance = 0; en.geometry = 0; en.primitive = 0;
+    if (i < sc.alias_count) en = sc.alias[1 + i];
+    LightTri r;
+    r.p0x = r.p0y = r.p0z = r.p1x = r.p1y = r.p1z = r.p2x = r.p2y = r.p2z = 0.0f;
+    r.t0x = 0.0f; r.t0y = 0.0f; r.t1x = 1.0f; r.t1y = 0.0f; r.t2x = 1.0f; r.t2y = 1.0f; r.material = 0;
+    if (en.instance < n_instances) {
+        const GeometryRec g = sc.geometries[sc.instances[en.instance].geo_offset + en.geometry];
+        const MeshRec mesh = sc.meshes[g.mesh];
+        const uint32_t i0 = mesh.indices[3 * (size_t)en.primitive], i1 = mesh.indices[3 * (size_t)en.primitive + 1], i2 = mesh.indices[3 * (size_t)en.primitive + 2];
+        const f3 p0 = ld3(mesh.positions, i0), p1 = ld3(mesh.positions, i1), p2 = ld3(mesh.positions, i2);
+        r.p0x = p0.x; r.p0y = p0.y; r.p0z = p0.z; r.p1x = p1.x; r.p1y = p1.y; r.p1z = p1.z; r.p2x = p2.x; r.p2y = p2.y; r.p2z = p2.z;
+        if (mesh.texcoords) {
+            const uint32_t a0 = indexed_attributes ? i0 : en.primitive * 3 + 0, a1 = indexed_attributes ? i1 : en.primitive * 3 + 1, a2 = indexed_attributes ? i2 : en.primitive * 3 + 2;
+            const f2 t0 = ld2(mesh.texcoords, a0), t1 = ld2(mesh.texcoords, a1), t2 = ld2(mesh.texcoords, a2);
+            r.t0x = t0.x; r.t0y = t0.y; r.t1x = t1.x; r.t1y = t1.y; r.t2x = t2.x; r.t2y = t2.y;
+        }
+        r.material = g.material;
+    }
+    out[i] = r;
+}
+
 __device__ __forceinline__ float power_heuristic(uint32_t numf, float fPdf, uint32_t numg, float gPdf) {   // integrator.hlsl:10-16
     const float f = (float)numf * fPdf, g = (float)numg * gPdf;
     const float f2_ = f * f;
@@ -99,7 +124,7 @@ __global__ __launch_bounds__(SHADE_BLOCK) void k_shade(SceneView sc, PipelineOpt
     constexpr uint32_t CAT_NONE = 6u, NCAT = 6u;   // 0 zombie, 1 miss, 2 + material type (MAT_GLASS .. MAT_PBR)
     __shared__ uint32_t s_cat[NCAT * (SHADE_BLOCK / 64) + 1];
     __shared__ uint32_t s_perm[SHADE_BLOCK];
-    __shared__ uint4 s_hit[SHADE_BLOCK], s_geo[SHADE_BLOCK];   // what the sort already fetched: hit record, {geometry record, material type}
+    __shared__ uint4 s_hit[SHADE_BLOCK], s_geo[SHADE_BLOCK], s_mat[2][SHADE_BLOCK];   // what the sort already fetched: hit, geometry and material records
     for (uint32_t base_i = blockIdx.x * SHADE_BLOCK; base_i < n_pad; base_i += gridDim.x * SHADE_BLOCK) {
         uint32_t cat = CAT_NONE;
         {
@@ -115,9 +140,11 @@ __global__ __launch_bounds__(SHADE_BLOCK) void k_shade(SceneView sc, PipelineOpt
                         else {
                             const uint32_t geo = sc.tris[hr.y].geo;
                             const GeometryRec g = sc.geometries[sc.instances[hr.x].geo_offset + geo];
-                            const uint32_t type = sc.materials[g.material].type;
-                            s_geo[threadIdx.x] = make_uint4(g.mesh, g.material, g.sampled, type);
-                            cat = 2u + (type & 3u);
+                            const uint4* mp = reinterpret_cast<const uint4*>(sc.materials + g.material);
+                            const uint4 m0 = mp[0], m1 = mp[1];
+                            s_geo[threadIdx.x] = make_uint4(g.mesh, g.material, g.sampled, 0u);
+                            s_mat[0][threadIdx.x] = m0; s_mat[1][threadIdx.x] = m1;
+                            cat = 2u + (m0.z & 3u);
                         }
                     }
                 }
@@ -178,7 +205,9 @@ __global__ __launch_bounds__(SHADE_BLOCK) void k_shade(SceneView sc, PipelineOpt
                 const uint4 pg = s_geo[src];
                 GeometryRec geometry; geometry.mesh = pg.x; geometry.material = pg.y; geometry.sampled = pg.z;
                 const Attrs attrs = mesh_attributes_world(sc, opts.indexed_attributes != 0, hinst, 0u, 0u, F2(u2f(hrec.z), u2f(hrec.w)), geometry, htri, true);
-                const MaterialRec mrec = sc.materials[geometry.material];
+                MaterialRec mrec;
+                { const uint4 m0 = s_mat[0][src], m1 = s_mat[1][src];
+                  mrec.normal = m0.x; mrec.emissive = m0.y; mrec.type = m0.z; mrec.color = m0.w; mrec.metalness = m1.x; mrec.roughness = m1.y; mrec.ior = u2f(m1.z); mrec.pad = m1.w; }
                 const Frame textureFrame = get_texture_frame(sc, mrec, opts.two_component_normal_texture != 0, attrs.texcoord, attrs.frame);
                 const f3 emissiveLight = tex_sample_rgb(sc, mrec.emissive, attrs.texcoord);
                 const Mat material = material_load(sc, mrec, attrs.texcoord);
@@ -231,14 +260,23 @@ __global__ __launch_bounds__(SHADE_BLOCK) void k_shade(SceneView sc, PipelineOpt
                                 AliasEntry en = alias_load(sc, entryCount, 1 + idx);
                                 if (!coin_flip_remap(en.select, rand.x)) { idx = en.alias; en = alias_load(sc, entryCount, 1 + idx); }
                                 const f2 bary = square_to_triangle(rand);
-                                GeometryRec lgeo;
-                                const Attrs at = mesh_attributes_world(sc, opts.indexed_attributes != 0, en.instance, en.geometry, en.primitive, bary, lgeo);
+                                // MeshAttributes::lookupAndInterpolate(...).inWorld(...) (world.hlsl:114-176) from the light's gathered record
+                                // (position, texcoord and triangle normal are all the light sample uses; same operations, same order)
+                                const uint4* lp = reinterpret_cast<const uint4*>(sc.light_tris + (idx < entryCount ? idx : entryCount));
+                                const uint4 la = lp[0], lb = lp[1], lc = lp[2], ld = lp[3];
+                                const InstanceRec* linst = sc.instances + en.instance;
+                                const m34 ltoWorld = linst->transform, ltoMesh = linst->world_to_instance;
+                                const f3 lp0 = F3(u2f(la.x), u2f(la.y), u2f(la.z)), lp1 = F3(u2f(la.w), u2f(lb.x), u2f(lb.y)), lp2 = F3(u2f(lb.z), u2f(lb.w), u2f(lc.x));
+                                const f3 lbary = F3(1.0f - bary.x - bary.y, bary.x, bary.y);
+                                const f3 at_position = m34_mul_point(ltoWorld, interp3(lbary, lp0, lp1, lp2));
+                                const f2 at_texcoord = interp2(lbary, F2(u2f(lc.y), u2f(lc.z)), F2(u2f(lc.w), u2f(ld.x)), F2(u2f(ld.y), u2f(ld.z)));
+                                const f3 at_n = normalize(m34_mul_transposed(ltoMesh, normalize(cross(sub(lp0, lp2), sub(lp1, lp2)))));
                                 LSample ls;
-                                ls.radiance = tex_sample_rgb(sc, sc.materials[lgeo.material].emissive, at.texcoord);
-                                ls.dirWs = normalize(sub(at.position, attrs.position));
-                                ls.pdf = area_to_solid_angle(at.position, attrs.position, ls.dirWs, at.triangleFrame.n) / sum;
+                                ls.radiance = tex_sample_rgb(sc, sc.materials[ld.w].emissive, at_texcoord);
+                                ls.dirWs = normalize(sub(at_position, attrs.position));
+                                ls.pdf = area_to_solid_angle(at_position, attrs.position, ls.dirWs, at_n) / sum;
                                 if (ls.pdf > 0.0f) {
-                                    const f3 offL = offset_along_normal(at.position, at.triangleFrame.n);
+                                    const f3 offL = offset_along_normal(at_position, at_n);
                                     const f3 offS = offset_along_normal(attrs.position, face_forward(attrs.triangleFrame.n, ls.dirWs));
                                     sh1 = true;
                                     s1t = length(sub(offL, offS)); s1o = offS; s1d = normalize(sub(offL, offS));
@@ -370,6 +408,9 @@ void launch_raygen(hipStream_t s, int grid, const ShardView& sh, const CameraCon
 }
 void launch_shade(hipStream_t s, int grid, const SceneView& sc, const PipelineOpts& o, const PathState& cur, const HitBuf& hits, const PathState& nxt, const ShadowQueue& q, float4* lbuf, Counters* cnt) {
     hipLaunchKernelGGL(k_shade, dim3(grid), dim3(SHADE_BLOCK), 0, s, sc, o, cur, hits, nxt, q, lbuf, cnt);
+}
+void launch_light_tris(hipStream_t s, const SceneView& sc, uint32_t indexed_attributes, uint32_t n_instances, LightTri* out) {
+    hipLaunchKernelGGL(k_light_tris, dim3((sc.alias_count + 1 + 255) / 256), dim3(256), 0, s, sc, indexed_attributes, n_instances, out);
 }
 void launch_advance(hipStream_t s, Counters* cnt, int mode, uint32_t total, uint32_t masked) { hipLaunchKernelGGL(k_advance, dim3(1), dim3(1), 0, s, cnt, mode, total, masked); }
 void launch_film(hipStream_t s, int grid, const ShardView& sh, const PipelineOpts& o, const float4* lbuf, uint32_t s_count, uint32_t n_launches, int first_chunk, int last_chunk, uint32_t sample_count, float4* color, float4* film) {

@@ -51,6 +51,11 @@ struct alignas(16) MaterialRec { uint32_t normal, emissive, type, color, metalne
 // parameter (World.zig:44-228) — are then served by the descriptor load alone, one dependent load less per fetch
 struct alignas(16) TexDesc { uint32_t offset, w, h, pad; float4 first; };
 struct AliasEntry { uint32_t alias; float select; uint32_t instance, geometry, primitive; };  // light.hlsl:17-22,112-116 (20 B)
+// What MeshLights::sample (light.hlsl:130-158) needs of alias entry i, gathered once per scene: the object-space vertices and
+// texcoords of the emissive triangle and its material — one 64-B load per light sample instead of the chain
+// instance → geometry → mesh → indices → positions.  Entry [count] stands for the all-zero entry of an out-of-range index.
+struct alignas(16) LightTri { float p0x, p0y, p0z, p1x, p1y, p1z, p2x, p2y, p2z, t0x, t0y, t1x, t1y, t2x, t2y; uint32_t material; };
+static_assert(sizeof(LightTri) == 64, "LightTri must be 64 bytes");
 
 struct EnvView {
     const float4* rgb;        // S*S equal-area map
@@ -71,6 +76,7 @@ struct SceneView {
     const float4* texels;
     const AliasEntry* alias;          // entry 0 = header {count, sum}
     uint32_t alias_count; float alias_sum;   // copy of the header: kernel arguments instead of a dependent load per path
+    const LightTri* light_tris;       // alias_count + 1 records
     EnvView env;
     uint32_t tlas_root;               // MAX_UINT when the scene is empty
     uint32_t root_in_blas;            // 1: tlas_root is the root of the merged world BLAS (no TLAS level at all)
