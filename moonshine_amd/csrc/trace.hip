@@ -75,7 +75,8 @@ __device__ __forceinline__ bool tri_intersect(f3 o, const RayK& k, f3 v0, f3 v1,
     return !mixed && det != 0.0f && tt > 0.0f;
 }
 
-__device__ __forceinline__ float safe_inv(float d) { return absf(d) < 1e-30f ? (d < 0.0f ? -1e30f : 1e30f) : 1.0f / d; }
+// reciprocal direction for the box tests only (they carry a 1e-5 slack): v_rcp_f32, 1 ulp
+__device__ __forceinline__ float safe_inv(float d) { return absf(d) < 1e-30f ? (d < 0.0f ? -1e30f : 1e30f) : __builtin_amdgcn_rcpf(d); }
 
 struct Hit { uint32_t inst, tri; float t, u, v; };   // tri = slot of the hit triangle's record in SceneView::tris
 
@@ -221,13 +222,14 @@ __device__ __forceinline__ bool step_tri(Lane& L, const SceneView& sc, unsigned 
 }
 
 // TLAS leaf: enter the instance's BLAS in instance space (t is preserved: d is not renormalised).  The ray is
-// restored when the sentinel entry pushed here is popped.
+// restored when the sentinel entry pushed here is popped.  Returns the BLAS root (visited in the same iteration), or
+// MAX_UINT when there is nothing to enter.
 template <class Load>
-__device__ __forceinline__ void step_inst(Lane& L, const SceneView& sc, const StackRef& S, uint32_t item, uint32_t my, Load load) {
+__device__ __forceinline__ uint32_t step_inst(Lane& L, const SceneView& sc, const StackRef& S, uint32_t item, uint32_t my, Load load) {
     const uint32_t ii = sc.tlas_items[item];
     const InstanceRec* ir = sc.instances + ii;
     const uint32_t root = ir->blas_root, flags = ir->flags;
-    if (!(flags & INST_FLAG_VISIBLE) || root == MAX_UINT) return;
+    if (!(flags & INST_FLAG_VISIBLE) || root == MAX_UINT) return MAX_UINT;
     if (flags & INST_FLAG_IDENTITY) {
         lane_push(L, S, 0u, GRP_SENTINEL);   // identity transform: M·(o,1) = o and M·d = d exactly, the ray is left as is
     } else {
@@ -243,7 +245,7 @@ __device__ __forceinline__ void step_inst(Lane& L, const SceneView& sc, const St
         lane_push(L, S, 1u, GRP_SENTINEL);
     }
     L.in_blas = true; L.cur_inst = (flags & INST_FLAG_WORLD) ? WORLD_INSTANCE : ii;
-    L.g0 = root; L.g1 = GRP_NODE | 0x0101u;
+    return root;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -319,12 +321,13 @@ __device__ __forceinline__ void trace_wave_loop(const SceneView& sc, uint32_t n,
             else {
                 lane_pop(L, S);
                 if (__builtin_expect((L.g1 & GRP_KIND_MASK) == GRP_SENTINEL, 0)) {   // leaving an instance: back to the world-space ray
-                    if (has_t) L.sp++;   // ... but only once the triangles queued in instance space are done: un-pop
+                    if (has_t) { L.sp++; L.g1 = 0u; }   // ... but only once the triangles queued in instance space are done: un-pop
                     else {
                         if (L.g0 & 1u) { f3 o, d; float tmax; (void)load(my, o, d, tmax); lane_set_space(L, o, d); }
-                        L.in_blas = false;
+                        L.in_blas = false; L.g1 = 0u;
+                        if (L.sp == 0) { store(my, L); active = false; }
+                        else lane_pop(L, S);   // what lies under a sentinel is a TLAS-level group (two levels only), never another sentinel
                     }
-                    L.g1 = 0u;
                 }
             }
         }
@@ -354,9 +357,9 @@ __device__ __forceinline__ void trace_wave_loop(const SceneView& sc, uint32_t n,
         lap(2);
         if (do_n && want_n) {
             const uint32_t kind = L.g1 & GRP_KIND_MASK;
-            const uint32_t idx = group_take(L, S, lut);
-            if (__builtin_expect(kind == GRP_INST, 0)) step_inst(L, sc, S, idx, my, load);
-            else step_node<STATS>(L, sc, S, idx, nv);
+            uint32_t idx = group_take(L, S, lut);
+            if (__builtin_expect(kind == GRP_INST, 0)) idx = step_inst(L, sc, S, idx, my, load);   // then straight into the BLAS root
+            if (idx != MAX_UINT) step_node<STATS>(L, sc, S, idx, nv);
         }
         lap(3);
         if (STATS && do_n) cyc[6] += __popcll(__ballot(want_n));   // node-lane steps

@@ -5,7 +5,7 @@ import torch  # noqa
 from moonshine_amd import api, scenes
 w, h, spp = (int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3])) if len(sys.argv) > 3 else (480, 270, 4)
 c = api.Context()
-s, l = scenes.s1(c, extent=(w, h))
+s, l = (scenes.s2 if os.environ.get("SCENE") == "s2" else scenes.s1)(c, extent=(w, h))
 c.set_pipeline(samples_per_run=1, max_bounces=8, env_samples_per_bounce=1, mesh_samples_per_bounce=1)
 c.set_profiling(True, True)
 c.render(s, l, launches=spp, readback=False)
