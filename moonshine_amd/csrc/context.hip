@@ -18,14 +18,14 @@
 
 namespace msne {
 // kernels' host wrappers (trace.hip, integrator.hip, env.hip, bvh_build.hip)
-void launch_trace_closest(hipStream_t, int, bool, const SceneView&, const PathState&, const HitBuf&, Counters*, uint32_t*, uint32_t*, unsigned long long*, const uint32_t[4]);
-void launch_trace_shadow(hipStream_t, int, bool, const SceneView&, const ShadowQueue&, const PathState&, Counters*, uint32_t*, uint32_t*, unsigned long long*, const uint32_t[4]);
+void launch_trace_closest(hipStream_t, int, bool, const SceneView&, const PathState&, const HitBuf&, BounceCounters*, uint32_t*, uint32_t*, unsigned long long*, const uint32_t[4]);
+void launch_trace_shadow(hipStream_t, int, bool, const SceneView&, const ShadowQueue&, const PathState&, BounceCounters*, uint32_t*, uint32_t*, unsigned long long*, const uint32_t[4]);
 void launch_trace_probe(hipStream_t, int, const SceneView&, const float*, uint32_t, int, uint32_t*, uint32_t*, float*, uint32_t*, uint32_t*, const uint32_t[4]);
 size_t trace_spill_words(int grid);
 int trace_blocks_per_cu();
-void launch_raygen(hipStream_t, int, const ShardView&, const CameraConsts&, const PipelineOpts&, uint32_t, uint32_t, const PathState&, Counters*);
-void launch_shade(hipStream_t, int, const SceneView&, const PipelineOpts&, const PathState&, const HitBuf&, const PathState&, const ShadowQueue&, float4*, Counters*);
-void launch_advance(hipStream_t, Counters*, int, uint32_t, uint32_t);
+void launch_raygen(hipStream_t, int, const ShardView&, const CameraConsts&, const PipelineOpts&, uint32_t, uint32_t, const PathState&, BounceCounters*);
+void launch_shade(hipStream_t, int, const SceneView&, const PipelineOpts&, const PathState&, const HitBuf&, const PathState&, const ShadowQueue&, float4*, BounceCounters*);
+void launch_account(hipStream_t, const BounceCounters*, uint32_t, Totals*);
 void launch_light_tris(hipStream_t, const SceneView&, uint32_t, uint32_t, LightTri*);
 void launch_film(hipStream_t, int, const ShardView&, const PipelineOpts&, const float4*, uint32_t, uint32_t, int, int, uint32_t, float4*, float4*);
 void launch_unpack_film(hipStream_t, int, const ShardView&, const float4*, uint32_t, uint32_t, size_t, float4*);
@@ -128,7 +128,8 @@ struct HdMoonshine {
     struct Pipe {
         PathBuffers paths[2];
         DevBuf<uint32_t> hit_u, spill, spill2; DevBuf<float> shq_f;
-        DevBuf<Counters> counters;
+        DevBuf<BounceCounters> counters;   // one per bounce of the batch in flight (+1)
+        DevBuf<Totals> totals;
         hipStream_t s0 = nullptr, s1 = nullptr;   // s1: k_trace_shadow, overlapped with the next bounce's k_trace_closest
         size_t cap = 0;
     };
@@ -478,7 +479,9 @@ bool HdMoonshine::ensure_wavefront(size_t npaths, size_t slots, int npipes) {
             if (!pp.paths[0].ensure(c) || !pp.paths[1].ensure(c) || !pp.hit_u.alloc(4 * c) || !pp.shq_f.alloc(8 * 2 * c)) { fail("out of device memory (wavefront state)"); return false; }
             pp.cap = c;
         }
-        if (!pp.counters.p) { if (!pp.counters.alloc(1)) return false; if (hipMemsetAsync(pp.counters.p, 0, sizeof(Counters), stream) != hipSuccess) return false; }
+        const size_t nc = (size_t)opts.max_bounces + 5;   // bounces 0 .. max_bounces + 2, the entry k_shade of the last one appends to, and the probe's
+        if (pp.counters.n < nc && !pp.counters.alloc(nc)) return false;
+        if (!pp.totals.p) { if (!pp.totals.alloc(1)) return false; if (hipMemsetAsync(pp.totals.p, 0, sizeof(Totals), stream) != hipSuccess) return false; }
         if (!pp.spill.p && (!pp.spill.alloc(trace_spill_words(trace_grid)) || !pp.spill2.alloc(trace_spill_words(trace_grid)))) { fail("out of device memory (traversal spill)"); return false; }
     }
     if (slots > lbuf_cap) { if (!d_lbuf.alloc(slots)) { fail("out of device memory (sample buffer)"); lbuf_cap = 0; return false; } lbuf_cap = slots; }
@@ -559,35 +562,32 @@ bool HdMoonshine::render(uint32_t sensor, uint32_t lens, uint32_t launches, bool
         const HitBuf hits{ reinterpret_cast<uint4*>(pp.hit_u.p) };
         const ShadowQueue shq{ reinterpret_cast<float4*>(pp.shq_f.p), reinterpret_cast<float4*>(pp.shq_f.p + 4 * qc) };
         const PathState st[2] = { pp.paths[0].view(), pp.paths[1].view() };
-        Counters* cnt = pp.counters.p;
-        CHECK_HIP(this, hipMemsetAsync(cnt, 0, 32, pp.s0));   // queue counts + heads
+        BounceCounters* cnt = pp.counters.p;   // [b] = the queues of bounce b: nothing to rotate or reset between kernels
+        CHECK_HIP(this, hipMemsetAsync(cnt, 0, ((size_t)max_iter + 2) * sizeof(BounceCounters), pp.s0));
         launch_raygen(pp.s0, shade_grid, s->shard, cam, opts, first_sample, ns, st[0], cnt);
-        launch_advance(pp.s0, cnt, 1, ns * s->shard.pixels, ns * (s->shard.pixels - s->shard.valid_pixels));
         hipEvent_t shadow_done = nullptr;
         for (uint32_t b = 0; b < max_iter; b++) {
             const PathState& cur = st[b & 1]; const PathState& nxt = st[(b + 1) & 1];
-            timed2(0, pp.s0, [&] { launch_trace_closest(pp.s0, trace_grid, trace_stats, sv, cur, hits, cnt, pp.spill.p, d_overflow.p, d_trace_stats.p, tune); });
+            timed2(0, pp.s0, [&] { launch_trace_closest(pp.s0, trace_grid, trace_stats, sv, cur, hits, cnt + b, pp.spill.p, d_overflow.p, d_trace_stats.p, tune); });
             if (shadow_done) CHECK_HIP(this, hipStreamWaitEvent(pp.s0, shadow_done, 0));   // k_shade(b) consumes the results of k_trace_shadow(b-1)
-            launch_advance(pp.s0, cnt, 3, 0, 0);
-            timed2(2, pp.s0, [&] { launch_shade(pp.s0, shade_grid, sv, opts, cur, hits, nxt, shq, lbuf, cnt); });
-            launch_advance(pp.s0, cnt, 2, 0, 0);
+            timed2(2, pp.s0, [&] { launch_shade(pp.s0, shade_grid, sv, opts, cur, hits, nxt, shq, lbuf, cnt + b); });
             hipEvent_t shade_done = next_event();
             if (!shade_done) { fail("hipEventCreate failed"); return false; }
             CHECK_HIP(this, hipEventRecord(shade_done, pp.s0));
             CHECK_HIP(this, hipStreamWaitEvent(pp.s1, shade_done, 0));
-            timed2(1, pp.s1, [&] { launch_trace_shadow(pp.s1, trace_grid, trace_stats, sv, shq, nxt, cnt, pp.spill2.p, d_overflow.p, d_trace_stats.p, tune); });
+            timed2(1, pp.s1, [&] { launch_trace_shadow(pp.s1, trace_grid, trace_stats, sv, shq, nxt, cnt + b + 1, pp.spill2.p, d_overflow.p, d_trace_stats.p, tune); });
             shadow_done = next_event();
             if (!shadow_done) { fail("hipEventCreate failed"); return false; }
             CHECK_HIP(this, hipEventRecord(shadow_done, pp.s1));
             if (b >= 15 && (b & 3) == 3) {   // long tails (max_bounces = 1024 offline): poll the queue length every 4 bounces
-                uint32_t n_cur = 0;
-                CHECK_HIP(this, hipMemcpyAsync(&n_cur, &cnt->n_cur, 4, hipMemcpyDeviceToHost, pp.s0));
+                uint32_t n_next = 0;
+                CHECK_HIP(this, hipMemcpyAsync(&n_next, &cnt[b + 1].n_paths, 4, hipMemcpyDeviceToHost, pp.s0));
                 CHECK_HIP(this, hipStreamSynchronize(pp.s0));
-                if (n_cur == 0) break;
+                if (n_next == 0) break;
             }
         }
         if (shadow_done) CHECK_HIP(this, hipStreamWaitEvent(pp.s0, shadow_done, 0));
-        launch_advance(pp.s0, cnt, 3, 0, 0);
+        launch_account(pp.s0, cnt, max_iter, pp.totals.p);
         return true;
     };
     // fork the pipes after everything queued on the main stream so far, join them back before k_film
@@ -858,9 +858,9 @@ int MsneGetStats(const HdMoonshine* cc, MsneStats* out) {
     *out = c->stats;
     out->closest_rays = out->shadow_rays = out->samples = 0;
     for (auto& pp : c->pipes) {
-        if (!pp.counters.p) continue;
-        Counters h{};
-        if (hipMemcpy(&h, pp.counters.p, sizeof h, hipMemcpyDeviceToHost) != hipSuccess) return -1;
+        if (!pp.totals.p) continue;
+        Totals h{};
+        if (hipMemcpy(&h, pp.totals.p, sizeof h, hipMemcpyDeviceToHost) != hipSuccess) return -1;
         out->closest_rays += h.closest_rays; out->shadow_rays += h.shadow_rays; out->samples += h.samples;
     }
     return 0;
@@ -869,7 +869,7 @@ void MsneResetStats(HdMoonshine* c) {
     LOCK(c);
     if (!c->bind()) return;
     c->stats = MsneStats{};
-    for (auto& pp : c->pipes) if (pp.counters.p) (void)hipMemset(pp.counters.p, 0, sizeof(Counters));
+    for (auto& pp : c->pipes) if (pp.totals.p) (void)hipMemset(pp.totals.p, 0, sizeof(Totals));
     if (c->d_trace_stats.p) (void)hipMemset(c->d_trace_stats.p, 0, 160);
 }
 

@@ -2,7 +2,7 @@
 //   k_raygen  = raygen prologue: Rng::fromSeed, dispatchUV, Camera::generateRay       (main.hlsl:54-59,83-89; camera.hlsl:14-42)
 //   k_shade   = one iteration of PathTracingIntegrator::incomingRadiance              (integrator.hlsl:79-166) + the miss epilogue (:168-181)
 //   k_film    = storeColor                                                            (main.hlsl:43-51,94)
-//   k_advance = queue bookkeeping between bounces (no reference equivalent: the reference loops inside one thread)
+//   k_account = ray / sample statistics of a finished batch (no reference equivalent)
 // Light samples are generated in k_shade; their shadow rays are traced by k_trace_shadow, which zeroes the
 // pending contribution when occluded; the contribution is added to the path's radiance by the next k_shade
 // in the reference's order (env sample, then mesh sample — integrator.hlsl:139-151).
@@ -35,7 +35,8 @@ __device__ __forceinline__ bool shard_pixel(const ShardView& sh, uint32_t p, uin
 }
 
 __global__ __launch_bounds__(SHADE_BLOCK) void k_raygen(ShardView sh, CameraConsts cam, PipelineOpts opts, uint32_t sample_base, uint32_t s_count,
-                                                          PathState st, Counters* cnt) {
+                                                          PathState st, BounceCounters* cnt) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) { cnt->n_paths = s_count * sh.pixels; cnt->zombies = s_count * (sh.pixels - sh.valid_pixels); }   // bounce 0's queue
     // queue index = slot (no compaction, no atomics: one device-scope counter would cap this kernel at ~88 waves/us);
     // the few slots of edge tiles that fall outside the image are flagged and dropped by the first k_shade
     const uint32_t total = s_count * sh.pixels;
@@ -110,8 +111,8 @@ __device__ __forceinline__ f3 estimate_direct_mis(const Frame& frame, const LSam
 }
 
 __global__ __launch_bounds__(SHADE_BLOCK) void k_shade(SceneView sc, PipelineOpts opts, PathState cur, HitBuf hits, PathState nxt, ShadowQueue shq,
-                                                         float4* lbuf, Counters* cnt) {
-    const uint32_t n = cnt->n_cur;
+                                                         float4* lbuf, BounceCounters* cnt /* [0]: this bounce, [1]: the next */) {
+    const uint32_t n = cnt[0].n_paths;
     const uint32_t max_bounces = opts.max_bounces, env_n = opts.env_samples, mesh_n = opts.mesh_samples;
     __shared__ unsigned long long s_cnt[SHADE_BLOCK / 64];
     __shared__ unsigned long long s_base;
@@ -291,7 +292,7 @@ __global__ __launch_bounds__(SHADE_BLOCK) void k_shade(SceneView sc, PipelineOpt
                     const MSample sample = material_sample(material, woSs, sq);
                     if (sample.pdf == 0.0f) {
                         done = true;
-                        if (sh0 || sh1) { cont = true; flags |= PATH_FLAG_ZOMBIE; done = false; atomicAdd(&cnt->zombies_next, 1u); }   // finalize after its shadow rays resolve
+                        if (sh0 || sh1) { cont = true; flags |= PATH_FLAG_ZOMBIE; done = false; atomicAdd(&cnt[1].zombies, 1u); }   // finalize after its shadow rays resolve
                     } else {
                         lastPdf = sample.pdf;
                         rayD = frame_frame_to_world(shadingFrame, sample.dirFs);
@@ -316,7 +317,7 @@ __global__ __launch_bounds__(SHADE_BLOCK) void k_shade(SceneView sc, PipelineOpt
         if (threadIdx.x == 0) {
             unsigned long long tot = 0;
             for (int k = 0; k < SHADE_BLOCK / 64; k++) tot += s_cnt[k];
-            s_base = tot ? atomicAdd(reinterpret_cast<unsigned long long*>(&cnt->n_next), tot) : 0ull;
+            s_base = tot ? atomicAdd(reinterpret_cast<unsigned long long*>(&cnt[1].n_paths), tot) : 0ull;
         }
         __syncthreads();
         unsigned long long base = s_base;
@@ -338,24 +339,12 @@ __global__ __launch_bounds__(SHADE_BLOCK) void k_shade(SceneView sc, PipelineOpt
     }
 }
 
-// queue bookkeeping between the kernels of a bounce
-// mode 1: after k_raygen (slots [0,total) filled, `masked` of them outside the image)
-// mode 2: after k_shade(b)  — rotate the path queue: what k_shade appended becomes the queue of k_trace_closest(b+1)
-// mode 3: before k_shade(b) — k_trace_shadow(b-1) is done: account its rays, free the shadow queue
-// (2 and 3 are separate so that k_trace_shadow(b) can overlap k_trace_closest(b+1) on a second stream)
-__global__ void k_advance(Counters* cnt, int mode, uint32_t total, uint32_t masked) {
+// statistics of a finished batch: rays traced and camera paths started, from its per-bounce counters
+__global__ void k_account(const BounceCounters* c, uint32_t n_bounces, Totals* t) {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
-    if (mode == 1) {
-        cnt->n_cur = total; cnt->samples += total - masked; cnt->zombies_cur = masked; cnt->zombies_next = 0;
-        cnt->n_next = 0; cnt->n_shadow = 0; cnt->head_closest = 0; cnt->head_shadow = 0;
-    } else if (mode == 2) {
-        cnt->closest_rays += cnt->n_cur - cnt->zombies_cur;
-        cnt->zombies_cur = cnt->zombies_next; cnt->zombies_next = 0;
-        cnt->n_cur = cnt->n_next; cnt->n_next = 0; cnt->head_closest = 0;
-    } else {
-        cnt->shadow_rays += cnt->n_shadow;
-        cnt->n_shadow = 0; cnt->head_shadow = 0;
-    }
+    unsigned long long closest = 0, shadow = 0;
+    for (uint32_t b = 0; b <= n_bounces; b++) { closest += c[b].n_paths - c[b].zombies; shadow += c[b].n_shadow_in; }
+    t->closest_rays += closest; t->shadow_rays += shadow; t->samples += c[0].n_paths - c[0].zombies;
 }
 
 // storeColor main.hlsl:43-51 over the `s_count` samples of this chunk (summed in sample order, main.hlsl:83-92)
@@ -403,16 +392,16 @@ __global__ __launch_bounds__(SHADE_BLOCK) void k_unpack_film(ShardView sh, const
 }
 
 // ---------------- host launch wrappers ----------------
-void launch_raygen(hipStream_t s, int grid, const ShardView& sh, const CameraConsts& cam, const PipelineOpts& o, uint32_t sample_base, uint32_t s_count, const PathState& st, Counters* cnt) {
+void launch_raygen(hipStream_t s, int grid, const ShardView& sh, const CameraConsts& cam, const PipelineOpts& o, uint32_t sample_base, uint32_t s_count, const PathState& st, BounceCounters* cnt) {
     hipLaunchKernelGGL(k_raygen, dim3(grid), dim3(SHADE_BLOCK), 0, s, sh, cam, o, sample_base, s_count, st, cnt);
 }
-void launch_shade(hipStream_t s, int grid, const SceneView& sc, const PipelineOpts& o, const PathState& cur, const HitBuf& hits, const PathState& nxt, const ShadowQueue& q, float4* lbuf, Counters* cnt) {
+void launch_shade(hipStream_t s, int grid, const SceneView& sc, const PipelineOpts& o, const PathState& cur, const HitBuf& hits, const PathState& nxt, const ShadowQueue& q, float4* lbuf, BounceCounters* cnt) {
     hipLaunchKernelGGL(k_shade, dim3(grid), dim3(SHADE_BLOCK), 0, s, sc, o, cur, hits, nxt, q, lbuf, cnt);
 }
 void launch_light_tris(hipStream_t s, const SceneView& sc, uint32_t indexed_attributes, uint32_t n_instances, LightTri* out) {
     hipLaunchKernelGGL(k_light_tris, dim3((sc.alias_count + 1 + 255) / 256), dim3(256), 0, s, sc, indexed_attributes, n_instances, out);
 }
-void launch_advance(hipStream_t s, Counters* cnt, int mode, uint32_t total, uint32_t masked) { hipLaunchKernelGGL(k_advance, dim3(1), dim3(1), 0, s, cnt, mode, total, masked); }
+void launch_account(hipStream_t s, const BounceCounters* c, uint32_t n_bounces, Totals* t) { hipLaunchKernelGGL(k_account, dim3(1), dim3(1), 0, s, c, n_bounces, t); }
 void launch_film(hipStream_t s, int grid, const ShardView& sh, const PipelineOpts& o, const float4* lbuf, uint32_t s_count, uint32_t n_launches, int first_chunk, int last_chunk, uint32_t sample_count, float4* color, float4* film) {
     hipLaunchKernelGGL(k_film, dim3(grid), dim3(SHADE_BLOCK), 0, s, sh, o, lbuf, s_count, n_launches, first_chunk, last_chunk, sample_count, color, film);
 }

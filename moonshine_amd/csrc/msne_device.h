@@ -114,13 +114,18 @@ struct ShadowQueue {
     float4* d;   // direction xyz | w = target bits: (next-state index << 1) | which (0 env, 1 mesh)
 };
 
-// device-side counters; one instance per context
-struct Counters {
-    uint32_t n_next, n_shadow;                          // appended to with ONE 64-bit atomic per workgroup (low = n_next, high = n_shadow)
-    uint32_t n_cur, zombies_cur;                        // zombies: queue entries that only wait to be finalized (no ray)
-    uint32_t head_closest, head_shadow, zombies_next, pad2;
-    unsigned long long closest_rays, shadow_rays, samples, pad3;
+// Queue counters of ONE bounce of a batch.  A batch owns an array of them indexed by bounce, zeroed when it starts, so
+// nothing has to be rotated or reset between the kernels of a bounce (no bookkeeping launches in the bounce loop):
+// k_trace_closest(b) and k_shade(b) consume [b]; k_shade(b) appends to [b + 1]; k_trace_shadow(b) consumes [b + 1].n_shadow_in.
+struct alignas(8) BounceCounters {
+    uint32_t n_paths, n_shadow_in;       // path-queue entries of this bounce | shadow rays made by the previous bounce's k_shade
+                                         // (adjacent: ONE 64-bit atomic per workgroup appends to both)
+    uint32_t zombies;                    // of n_paths: entries that only wait to be finalised (no ray)
+    uint32_t head_closest, head_shadow;  // dequeue heads of k_trace_closest(b) and k_trace_shadow(b - 1)
+    uint32_t pad[3];
 };
+static_assert(sizeof(BounceCounters) == 32, "BounceCounters must be 32 bytes");
+struct Totals { unsigned long long closest_rays, shadow_rays, samples, pad; };   // since the last MsneResetStats
 
 struct PipelineOpts {   // pipeline.zig:319-327
     uint32_t samples_per_run, max_bounces, env_samples, mesh_samples;

@@ -378,10 +378,10 @@ __device__ __forceinline__ void trace_wave_loop(const SceneView& sc, uint32_t n,
     order_table_init(lds_lut)
 
 template <bool STATS>
-__global__ __launch_bounds__(TRACE_BLOCK, TRACE_WPS) void k_trace_closest(SceneView sc, PathState st, HitBuf hits, Counters* cnt,
+__global__ __launch_bounds__(TRACE_BLOCK, TRACE_WPS) void k_trace_closest(SceneView sc, PathState st, HitBuf hits, BounceCounters* cnt,
                                                                 uint32_t* spill, uint32_t* overflow, unsigned long long* stat_out, TraceTune tune) {
     TRACE_LDS_DECL;
-    const uint32_t n = cnt->n_cur;
+    const uint32_t n = cnt->n_paths;
     unsigned long long nv = 0, nt = 0;
     trace_wave_loop<false, STATS>(sc, n, &cnt->head_closest, lds_stack, lds_lut, spill, overflow, tune,
         [&](uint32_t i, f3& o, f3& d, float& tmax) -> bool {
@@ -398,10 +398,10 @@ __global__ __launch_bounds__(TRACE_BLOCK, TRACE_WPS) void k_trace_closest(SceneV
 }
 
 template <bool STATS>
-__global__ __launch_bounds__(TRACE_BLOCK, TRACE_WPS) void k_trace_shadow(SceneView sc, ShadowQueue q, PathState next, Counters* cnt,
+__global__ __launch_bounds__(TRACE_BLOCK, TRACE_WPS) void k_trace_shadow(SceneView sc, ShadowQueue q, PathState next, BounceCounters* cnt,
                                                                uint32_t* spill, uint32_t* overflow, unsigned long long* stat_out, TraceTune tune) {
     TRACE_LDS_DECL;
-    const uint32_t n = cnt->n_shadow;
+    const uint32_t n = cnt->n_shadow_in;
     unsigned long long nv = 0, nt = 0;
     trace_wave_loop<true, STATS>(sc, n, &cnt->head_shadow, lds_stack, lds_lut, spill, overflow, tune,
         [&](uint32_t i, f3& o, f3& d, float& tmax) -> bool {
@@ -442,13 +442,13 @@ __global__ __launch_bounds__(TRACE_BLOCK, TRACE_WPS) void k_trace_probe(SceneVie
 }
 
 // ---------------- host launch wrappers ----------------
-void launch_trace_closest(hipStream_t s, int grid, bool stats, const SceneView& sc, const PathState& st, const HitBuf& hits, Counters* cnt,
+void launch_trace_closest(hipStream_t s, int grid, bool stats, const SceneView& sc, const PathState& st, const HitBuf& hits, BounceCounters* cnt,
                           uint32_t* spill, uint32_t* overflow, unsigned long long* stat_out, const uint32_t tune4[4]) {
     const TraceTune tune{ tune4[0], tune4[1], tune4[2], tune4[3] };
     if (stats) hipLaunchKernelGGL(k_trace_closest<true>, dim3(grid), dim3(TRACE_BLOCK), 0, s, sc, st, hits, cnt, spill, overflow, stat_out, tune);
     else hipLaunchKernelGGL(k_trace_closest<false>, dim3(grid), dim3(TRACE_BLOCK), 0, s, sc, st, hits, cnt, spill, overflow, stat_out, tune);
 }
-void launch_trace_shadow(hipStream_t s, int grid, bool stats, const SceneView& sc, const ShadowQueue& q, const PathState& next, Counters* cnt,
+void launch_trace_shadow(hipStream_t s, int grid, bool stats, const SceneView& sc, const ShadowQueue& q, const PathState& next, BounceCounters* cnt,
                          uint32_t* spill, uint32_t* overflow, unsigned long long* stat_out, const uint32_t tune4[4]) {
     const TraceTune tune{ tune4[0], tune4[1], tune4[2], tune4[3] };
     if (stats) hipLaunchKernelGGL(k_trace_shadow<true>, dim3(grid), dim3(TRACE_BLOCK), 0, s, sc, q, next, cnt, spill, overflow, stat_out, tune);
