@@ -18,9 +18,9 @@
 
 namespace msne {
 // kernels' host wrappers (trace.hip, integrator.hip, env.hip, bvh_build.hip)
-void launch_trace_closest(hipStream_t, int, bool, const SceneView&, const PathState&, const HitBuf&, BounceCounters*, uint32_t*, uint32_t*, unsigned long long*, const uint32_t[4]);
-void launch_trace_shadow(hipStream_t, int, bool, const SceneView&, const ShadowQueue&, const PathState&, BounceCounters*, uint32_t*, uint32_t*, unsigned long long*, const uint32_t[4]);
-void launch_trace_probe(hipStream_t, int, const SceneView&, const float*, uint32_t, int, uint32_t*, uint32_t*, float*, uint32_t*, uint32_t*, const uint32_t[4]);
+void launch_trace_closest(hipStream_t, int, bool, const SceneView&, const PathState&, const HitBuf&, BounceCounters*, uint32_t*, uint32_t*, unsigned long long*, uint32_t);
+void launch_trace_shadow(hipStream_t, int, bool, const SceneView&, const ShadowQueue&, const PathState&, BounceCounters*, uint32_t*, uint32_t*, unsigned long long*, uint32_t);
+void launch_trace_probe(hipStream_t, int, const SceneView&, const float*, uint32_t, int, uint32_t*, uint32_t*, float*, uint32_t*, uint32_t*, uint32_t);
 size_t trace_spill_words(int grid);
 int trace_blocks_per_cu();
 void launch_raygen(hipStream_t, int, const ShardView&, const CameraConsts&, const PipelineOpts&, uint32_t, uint32_t, const PathState&, BounceCounters*);
@@ -141,7 +141,7 @@ struct HdMoonshine {
     size_t lbuf_cap = 0;
     DevBuf<uint32_t> d_overflow; DevBuf<unsigned long long> d_trace_stats;
     int trace_grid = 1024, shade_grid = 2048;
-    uint32_t tune[4] = { 16, 16, 32, 12 };  // traversal: lane-refill threshold, phase-vote thresholds (node lanes, triangle lanes, blocked lanes); $MSNE_TUNE=a,b,c,d
+    uint32_t refill = 16;              // traversal: idle lanes (of 64) at which a wave refills from the ray queue; $MSNE_REFILL
     size_t max_inflight = 160u << 20;  // most paths traced concurrently (276 B of wavefront state each, allocated on demand); $MSNE_MAX_INFLIGHT
     // statistics
     MsneStats stats{};
@@ -568,14 +568,14 @@ bool HdMoonshine::render(uint32_t sensor, uint32_t lens, uint32_t launches, bool
         hipEvent_t shadow_done = nullptr;
         for (uint32_t b = 0; b < max_iter; b++) {
             const PathState& cur = st[b & 1]; const PathState& nxt = st[(b + 1) & 1];
-            timed2(0, pp.s0, [&] { launch_trace_closest(pp.s0, trace_grid, trace_stats, sv, cur, hits, cnt + b, pp.spill.p, d_overflow.p, d_trace_stats.p, tune); });
+            timed2(0, pp.s0, [&] { launch_trace_closest(pp.s0, trace_grid, trace_stats, sv, cur, hits, cnt + b, pp.spill.p, d_overflow.p, d_trace_stats.p, refill); });
             if (shadow_done) CHECK_HIP(this, hipStreamWaitEvent(pp.s0, shadow_done, 0));   // k_shade(b) consumes the results of k_trace_shadow(b-1)
             timed2(2, pp.s0, [&] { launch_shade(pp.s0, shade_grid, sv, opts, cur, hits, nxt, shq, lbuf, cnt + b); });
             hipEvent_t shade_done = next_event();
             if (!shade_done) { fail("hipEventCreate failed"); return false; }
             CHECK_HIP(this, hipEventRecord(shade_done, pp.s0));
             CHECK_HIP(this, hipStreamWaitEvent(pp.s1, shade_done, 0));
-            timed2(1, pp.s1, [&] { launch_trace_shadow(pp.s1, trace_grid, trace_stats, sv, shq, nxt, cnt + b + 1, pp.spill2.p, d_overflow.p, d_trace_stats.p, tune); });
+            timed2(1, pp.s1, [&] { launch_trace_shadow(pp.s1, trace_grid, trace_stats, sv, shq, nxt, cnt + b + 1, pp.spill2.p, d_overflow.p, d_trace_stats.p, refill); });
             shadow_done = next_event();
             if (!shadow_done) { fail("hipEventCreate failed"); return false; }
             CHECK_HIP(this, hipEventRecord(shadow_done, pp.s1));
@@ -680,7 +680,7 @@ HdMoonshine* MsneCreate(const MsneConfig* cfg_in) {
     if (const char* e = getenv("MSNE_MAX_INFLIGHT")) c->max_inflight = (size_t)atoll(e);
     if (const char* e = getenv("MSNE_PIPES")) c->n_pipes = std::max(1, std::min((int)HdMoonshine::MAX_PIPES, atoi(e)));
     if (const char* e = getenv("MSNE_SINGLE_PIPE_PATHS")) c->single_pipe_paths = (size_t)atoll(e);
-    if (const char* e = getenv("MSNE_TUNE")) { unsigned a, b, d, f; if (sscanf(e, "%u,%u,%u,%u", &a, &b, &d, &f) == 4) { c->tune[0] = a; c->tune[1] = b; c->tune[2] = d; c->tune[3] = f; } }
+    if (const char* e = getenv("MSNE_REFILL")) c->refill = (uint32_t)std::max(1, std::min(64, atoi(e)));
     if (const char* e = getenv("MSNE_TRACE_BLOCKS_PER_CU")) c->trace_grid = prop.multiProcessorCount * atoi(e);
     c->opts = PipelineOpts{ 1, 1024, 0, 0, 0, 0, 0 };                 // hydra.zig:97-105
     const float white[4] = { 1.0f, 1.0f, 1.0f, 1.0f };
@@ -892,7 +892,7 @@ int MsneTraceRays(HdMoonshine* c, const float* rays, uint32_t n, int any_hit, ui
     if (!dr.alloc(7 * (size_t)n) || !di.alloc(4 * (size_t)n) || !dt.alloc(3 * (size_t)n)) { c->fail("out of device memory (probe)"); return -1; }
     if (hipMemcpyAsync(dr.p, rays, 28 * (size_t)n, hipMemcpyHostToDevice, c->stream) != hipSuccess) return -1;
     if (hipMemsetAsync(&c->pipes[0].counters.p->head_closest, 0, 4, c->stream) != hipSuccess) return -1;
-    launch_trace_probe(c->stream, c->trace_grid, c->scene_view(), dr.p, n, any_hit, &c->pipes[0].counters.p->head_closest, di.p, dt.p, c->pipes[0].spill.p, c->d_overflow.p, c->tune);
+    launch_trace_probe(c->stream, c->trace_grid, c->scene_view(), dr.p, n, any_hit, &c->pipes[0].counters.p->head_closest, di.p, dt.p, c->pipes[0].spill.p, c->d_overflow.p, c->refill);
     if (hipMemcpyAsync(out_ids, di.p, 16 * (size_t)n, hipMemcpyDeviceToHost, c->stream) != hipSuccess) return -1;
     if (hipMemcpyAsync(out_tuv, dt.p, 12 * (size_t)n, hipMemcpyDeviceToHost, c->stream) != hipSuccess) return -1;
     if (hipStreamSynchronize(c->stream) != hipSuccess) { c->fail("probe failed"); return -1; }

@@ -3,8 +3,8 @@
 // written by closesthit/miss/shadowmiss in main.hlsl:102-118) over the driver-built TLAS/BLAS
 // (engine/hrtsystem/Accel.zig:94-184,484).
 //
-// Design (gfx950).  The kernels are VALU-issue bound (rocprofv3: SQ_ACTIVE_INST_VALU ≈ 100 % of SIMD time,
-// HBM traffic far below peak), so everything here minimises vector instructions per node visit:
+// Design (gfx950).  The kernels are VALU-issue bound (rocprofv3: SQ_ACTIVE_INST_VALU ≈ 90 % of SIMD time,
+// HBM traffic far below peak), so everything here minimises vector instructions per ray and keeps lanes busy:
 //  * persistent waves: a wave reserves a private chunk of the compacted ray queue with one atomicAdd (its first
 //    chunk is static), and every LANE refills itself from that chunk when its ray terminates;
 //  * the per-lane stack (LDS, [entry][word][thread] → conflict-free) holds child GROUPS, not children: one
@@ -13,7 +13,11 @@
 //  * the builder places a node's children in octant order (slot bit k set = child on the + side of axis k), so
 //    the visit order is a 2-KB LDS table lookup lut[ray octant][hit bits] instead of a distance sort;
 //  * near/far planes are chosen by ray sign once per node (12 v_cndmask), not by min/max per child;
-//  * leaf triangles are decoded lazily, one triangle per iteration, so lanes stay in step whatever the leaf sizes.
+//  * every leaf holds one triangle; the hit leaves of a node form a triangle group {item base, hit bits | leaf mask}, two
+//    of which can wait per lane: node traversal runs ahead of the triangle tests (one per iteration), so both bodies
+//    run with more lanes; a node visited with a not yet shortened ray costs a few extra visits, never a wrong result;
+//  * entering / leaving an instance costs no extra iteration (the BLAS root is visited in the iteration that enters,
+//    the TLAS group below the sentinel is popped in the iteration that leaves).
 // Box tests use fmaf and a relative slack (they only gate which triangles are tested); the triangle test is
 // the watertight Woop–Benthin–Wald test evaluated op-for-op like the test oracle, and equal-t ties resolve
 // to the smallest (instance, geometry, primitive), so results do not depend on BVH shape or visit order.
@@ -31,7 +35,6 @@ constexpr int TRACE_BLOCK = 256;
 constexpr int STACK_LDS = TRACE_STACK_LDS;   // group entries per lane kept in LDS (2 words each); 6 x (24 KB + 2 KB table) fit the CU's 160 KB
 constexpr int STACK_SPILL = 128 - STACK_LDS; // further entries per lane in HBM (2 words each)
 constexpr uint32_t GRP_NODE = 0u, GRP_INST = 1u << 16, GRP_SENTINEL = 2u << 16, GRP_KIND_MASK = 3u << 16;
-struct TraceTune { uint32_t refill, t_node, t_tri, t_inst; };   // refill: idle lanes of 64 that trigger a refill from the ray queue (the others: unused)
 
 struct RayK { int kx, ky, kz; float Sx, Sy, Sz; };
 
@@ -300,7 +303,7 @@ __device__ __forceinline__ void order_table_init(uint8_t* lut) {
 // `store(i, lane)` receives the finished lane.
 template <bool ANY_HIT, bool STATS, class Load, class Store>
 __device__ __forceinline__ void trace_wave_loop(const SceneView& sc, uint32_t n, uint32_t* head, uint32_t* lds_stack, const uint8_t* lut, uint32_t* spill, uint32_t* overflow,
-                                                TraceTune tune, Load load, Store store, unsigned long long& nv, unsigned long long& nt, unsigned long long* prof) {
+                                                uint32_t refill /* idle lanes of 64 that trigger a refill from the ray queue */, Load load, Store store, unsigned long long& nv, unsigned long long& nt, unsigned long long* prof) {
     const uint32_t lane = threadIdx.x & 63u;
     const unsigned long long lt = lane == 0 ? 0ull : (~0ull >> (64 - lane));
     const uint32_t gtid = blockIdx.x * TRACE_BLOCK + threadIdx.x;
@@ -335,7 +338,7 @@ __device__ __forceinline__ void trace_wave_loop(const SceneView& sc, uint32_t n,
         // (b) idle lanes take new rays from the wave's private chunk
         const unsigned long long act = __ballot(active);
         const uint32_t nidle = 64u - (uint32_t)__popcll(act);   // blocks are 4 full waves
-        if (!wq.exhausted && nidle >= tune.refill) {
+        if (!wq.exhausted && nidle >= refill) {
             uint32_t base;
             const uint32_t got = wq.take(nidle, base);
             const uint32_t r = (uint32_t)__popcll(~act & lt);
@@ -379,11 +382,11 @@ __device__ __forceinline__ void trace_wave_loop(const SceneView& sc, uint32_t n,
 
 template <bool STATS>
 __global__ __launch_bounds__(TRACE_BLOCK, TRACE_WPS) void k_trace_closest(SceneView sc, PathState st, HitBuf hits, BounceCounters* cnt,
-                                                                uint32_t* spill, uint32_t* overflow, unsigned long long* stat_out, TraceTune tune) {
+                                                                uint32_t* spill, uint32_t* overflow, unsigned long long* stat_out, uint32_t refill) {
     TRACE_LDS_DECL;
     const uint32_t n = cnt->n_paths;
     unsigned long long nv = 0, nt = 0;
-    trace_wave_loop<false, STATS>(sc, n, &cnt->head_closest, lds_stack, lds_lut, spill, overflow, tune,
+    trace_wave_loop<false, STATS>(sc, n, &cnt->head_closest, lds_stack, lds_lut, spill, overflow, refill,
         [&](uint32_t i, f3& o, f3& d, float& tmax) -> bool {
             const float4 ro = st.ro[i];
             if (f2u(ro.w) & PATH_FLAG_ZOMBIE) return false;
@@ -399,11 +402,11 @@ __global__ __launch_bounds__(TRACE_BLOCK, TRACE_WPS) void k_trace_closest(SceneV
 
 template <bool STATS>
 __global__ __launch_bounds__(TRACE_BLOCK, TRACE_WPS) void k_trace_shadow(SceneView sc, ShadowQueue q, PathState next, BounceCounters* cnt,
-                                                               uint32_t* spill, uint32_t* overflow, unsigned long long* stat_out, TraceTune tune) {
+                                                               uint32_t* spill, uint32_t* overflow, unsigned long long* stat_out, uint32_t refill) {
     TRACE_LDS_DECL;
     const uint32_t n = cnt->n_shadow_in;
     unsigned long long nv = 0, nt = 0;
-    trace_wave_loop<true, STATS>(sc, n, &cnt->head_shadow, lds_stack, lds_lut, spill, overflow, tune,
+    trace_wave_loop<true, STATS>(sc, n, &cnt->head_shadow, lds_stack, lds_lut, spill, overflow, refill,
         [&](uint32_t i, f3& o, f3& d, float& tmax) -> bool {
             const float4 qo = q.o[i], qd = q.d[i];
             o = F3(qo.x, qo.y, qo.z); d = F3(qd.x, qd.y, qd.z); tmax = qo.w;
@@ -423,10 +426,10 @@ __global__ __launch_bounds__(TRACE_BLOCK, TRACE_WPS) void k_trace_shadow(SceneVi
 template <bool ANY_HIT>
 __global__ __launch_bounds__(TRACE_BLOCK, TRACE_WPS) void k_trace_probe(SceneView sc, const float* rays /*7 per ray: o,d,tmax*/, uint32_t n, uint32_t* head,
                                                               uint32_t* out_ids /*4 per ray: hit,inst,geo,prim*/, float* out_tuv /*3 per ray*/,
-                                                              uint32_t* spill, uint32_t* overflow, TraceTune tune) {
+                                                              uint32_t* spill, uint32_t* overflow, uint32_t refill) {
     TRACE_LDS_DECL;
     unsigned long long nv = 0, nt = 0;
-    trace_wave_loop<ANY_HIT, false>(sc, n, head, lds_stack, lds_lut, spill, overflow, tune,
+    trace_wave_loop<ANY_HIT, false>(sc, n, head, lds_stack, lds_lut, spill, overflow, refill,
         [&](uint32_t i, f3& o, f3& d, float& tmax) -> bool {
             const float* r = rays + 7 * (size_t)i;
             o = F3(r[0], r[1], r[2]); d = F3(r[3], r[4], r[5]); tmax = r[6];
@@ -443,22 +446,19 @@ __global__ __launch_bounds__(TRACE_BLOCK, TRACE_WPS) void k_trace_probe(SceneVie
 
 // ---------------- host launch wrappers ----------------
 void launch_trace_closest(hipStream_t s, int grid, bool stats, const SceneView& sc, const PathState& st, const HitBuf& hits, BounceCounters* cnt,
-                          uint32_t* spill, uint32_t* overflow, unsigned long long* stat_out, const uint32_t tune4[4]) {
-    const TraceTune tune{ tune4[0], tune4[1], tune4[2], tune4[3] };
-    if (stats) hipLaunchKernelGGL(k_trace_closest<true>, dim3(grid), dim3(TRACE_BLOCK), 0, s, sc, st, hits, cnt, spill, overflow, stat_out, tune);
-    else hipLaunchKernelGGL(k_trace_closest<false>, dim3(grid), dim3(TRACE_BLOCK), 0, s, sc, st, hits, cnt, spill, overflow, stat_out, tune);
+                          uint32_t* spill, uint32_t* overflow, unsigned long long* stat_out, uint32_t refill) {
+    if (stats) hipLaunchKernelGGL(k_trace_closest<true>, dim3(grid), dim3(TRACE_BLOCK), 0, s, sc, st, hits, cnt, spill, overflow, stat_out, refill);
+    else hipLaunchKernelGGL(k_trace_closest<false>, dim3(grid), dim3(TRACE_BLOCK), 0, s, sc, st, hits, cnt, spill, overflow, stat_out, refill);
 }
 void launch_trace_shadow(hipStream_t s, int grid, bool stats, const SceneView& sc, const ShadowQueue& q, const PathState& next, BounceCounters* cnt,
-                         uint32_t* spill, uint32_t* overflow, unsigned long long* stat_out, const uint32_t tune4[4]) {
-    const TraceTune tune{ tune4[0], tune4[1], tune4[2], tune4[3] };
-    if (stats) hipLaunchKernelGGL(k_trace_shadow<true>, dim3(grid), dim3(TRACE_BLOCK), 0, s, sc, q, next, cnt, spill, overflow, stat_out, tune);
-    else hipLaunchKernelGGL(k_trace_shadow<false>, dim3(grid), dim3(TRACE_BLOCK), 0, s, sc, q, next, cnt, spill, overflow, stat_out, tune);
+                         uint32_t* spill, uint32_t* overflow, unsigned long long* stat_out, uint32_t refill) {
+    if (stats) hipLaunchKernelGGL(k_trace_shadow<true>, dim3(grid), dim3(TRACE_BLOCK), 0, s, sc, q, next, cnt, spill, overflow, stat_out, refill);
+    else hipLaunchKernelGGL(k_trace_shadow<false>, dim3(grid), dim3(TRACE_BLOCK), 0, s, sc, q, next, cnt, spill, overflow, stat_out, refill);
 }
 void launch_trace_probe(hipStream_t s, int grid, const SceneView& sc, const float* rays, uint32_t n, int any_hit, uint32_t* head, uint32_t* out_ids, float* out_tuv,
-                        uint32_t* spill, uint32_t* overflow, const uint32_t tune4[4]) {
-    const TraceTune tune{ tune4[0], tune4[1], tune4[2], tune4[3] };
-    if (any_hit) hipLaunchKernelGGL(k_trace_probe<true>, dim3(grid), dim3(TRACE_BLOCK), 0, s, sc, rays, n, head, out_ids, out_tuv, spill, overflow, tune);
-    else hipLaunchKernelGGL(k_trace_probe<false>, dim3(grid), dim3(TRACE_BLOCK), 0, s, sc, rays, n, head, out_ids, out_tuv, spill, overflow, tune);
+                        uint32_t* spill, uint32_t* overflow, uint32_t refill) {
+    if (any_hit) hipLaunchKernelGGL(k_trace_probe<true>, dim3(grid), dim3(TRACE_BLOCK), 0, s, sc, rays, n, head, out_ids, out_tuv, spill, overflow, refill);
+    else hipLaunchKernelGGL(k_trace_probe<false>, dim3(grid), dim3(TRACE_BLOCK), 0, s, sc, rays, n, head, out_ids, out_tuv, spill, overflow, refill);
 }
 int trace_blocks_per_cu() { return TRACE_WPS; }
 size_t trace_spill_words(int grid) { return (size_t)grid * TRACE_BLOCK * STACK_SPILL * 2; }
