@@ -205,6 +205,12 @@ void* MsneGetPackedFilmDevicePtr(const HdMoonshine*, SensorHandle);            /
  * when this is called (the library's streams are non-blocking: synchronise the stream that filled it first). */
 int MsneUnpackGatheredFilm(HdMoonshine*, SensorHandle, const void* gathered_device_ptr, uint32_t shard_count);
 
+/* ObjectPicker.getClickedObject (ObjectPicker.zig:89-128) = the raygen of shaders/hrtsystem/input.hlsl:24-69: ONE closest-hit
+ * ray through `normalized_coords` (0..1 across the sensor, y down: uv = (x, 1 - y)), lens sample (0,0), lens used as given
+ * (the shader zeroes the aperture of a copy it then does not use).  instance_index = -1 on a miss. */
+typedef struct MsneClickData { int32_t instance_index; uint32_t geometry_index, primitive_index; F32x2 barycentrics; } MsneClickData;
+int MsnePick(HdMoonshine*, SensorHandle, LensHandle, F32x2 normalized_coords, MsneClickData* out);
+
 int MsneGetStats(const HdMoonshine*, MsneStats*);
 void MsneResetStats(HdMoonshine*);
 const char* MsneGetLastError(const HdMoonshine*);   /* NULL ctx → last creation error */
@@ -216,7 +222,7 @@ typedef struct MsneGlbInfo { uint32_t meshes, materials, instances, textures, tr
 int MsneLoadGlb(HdMoonshine*, const char* glb_path, MsneGlbInfo* info_out);
 /* Rgba2D.load + BackgroundManager.addBackground (Scene.zig:49-55): equirectangular EXR → environment */
 int MsneSetBackgroundExr(HdMoonshine*, const char* exr_path);
-/* Rgba2D.save (exr.zig:137-206): the sensor's host buffer as a 3-channel (B,G,R) FLOAT scanline EXR; alpha is dropped */
+/* Rgba2D.save (exr.zig:137-206): the sensor's host buffer as a 3-channel (B,G,R) FLOAT scanline EXR, ZIP blocks of 16 lines (tinyexr's header defaults); alpha is dropped */
 int MsneSaveSensorExr(HdMoonshine*, SensorHandle, Extent2D, const char* exr_path);
 /* the EXR codec itself.  Load: call with rgba_out == NULL to get the extent, then again with a buffer of w*h*4 floats. */
 int MsneExrLoad(const char* exr_path, float* rgba_out, Extent2D* extent_inout);

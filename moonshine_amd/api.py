@@ -64,6 +64,10 @@ class MsneConfig(C.Structure):
     _fields_ = [("device", C.c_int32), ("tile_size", C.c_uint32), ("shard_index", C.c_uint32), ("shard_count", C.c_uint32)]
 
 
+class MsneClickData(C.Structure):   # input.hlsl:24-29
+    _fields_ = [("instance_index", C.c_int32), ("geometry_index", C.c_uint32), ("primitive_index", C.c_uint32), ("barycentrics", F32x2)]
+
+
 class MsneStats(C.Structure):
     _fields_ = [("closest_rays", C.c_uint64), ("shadow_rays", C.c_uint64), ("samples", C.c_uint64), ("launches", C.c_uint64),
                 ("trace_closest_ms", C.c_double), ("trace_shadow_ms", C.c_double), ("shade_ms", C.c_double), ("render_ms", C.c_double),
@@ -127,6 +131,7 @@ SYMBOLS = [
     ("MsneSetProfiling", None, [_vp, C.c_int, C.c_int]),
     ("MsneGetTraversalCounters", C.c_int, [_vp, C.POINTER(C.c_uint64)]),
     ("MsneTraceRays", C.c_int, [_vp, _vp, _u32, C.c_int, _vp, _vp]),
+    ("MsnePick", C.c_int, [_vp, _u32, _u32, F32x2, _vp]),
     ("MsneGetEnvSize", _u32, [_vp]),
     ("MsneReadEnv", C.c_int, [_vp, _vp, _vp]),
     ("MsneGetAliasTable", _u32, [_vp, _vp, _u32]),
@@ -372,6 +377,15 @@ class Context:
                 "shadow_node_visits": int(out[2]), "shadow_tri_tests": int(out[3]),
                 "closest_profile": {n: int(out[4 + i]) for i, n in enumerate(names)},
                 "shadow_profile": {n: int(out[12 + i]) for i, n in enumerate(names)}}
+
+    def pick(self, sensor, lens, x, y):
+        """ObjectPicker.getClickedObject: (instance, geometry, primitive, (u, v)) under normalized sensor coordinates, or None."""
+        cd = MsneClickData()
+        if self.L.MsnePick(self.h, sensor, lens, F32x2(x, y), C.byref(cd)) != 0:
+            self._err("MsnePick")
+        if cd.instance_index < 0:
+            return None
+        return cd.instance_index, cd.geometry_index, cd.primitive_index, (cd.barycentrics.x, cd.barycentrics.y)
 
     def trace_rays(self, rays, any_hit=False):
         r = _f32(rays, (-1, 7))

@@ -194,3 +194,53 @@ def exr_bytes(rgba, channels="RGB", pixel_type="float", compression="none"):
         offs.append(off + len(body))
         body += struct.pack("<ii", y0, len(data)) + data
     return hdr + b"".join(struct.pack("<Q", o) for o in offs) + bytes(body)
+
+
+def exr_decode(data):
+    """Scanline OpenEXR bytes -> (H, W, 4) float32 (missing channels: RGB 0, A 1).  NONE / ZIPS / ZIP, half / float.
+    Pure Python + zlib, written from the file-layout document: the independent check of the C++ writer, and the reader of
+    tools/exrdiff.py (runs without the library)."""
+    assert struct.unpack_from("<I", data, 0)[0] == 20000630, "not an OpenEXR file"
+    pos = 8
+    attrs = {}
+    while data[pos] != 0:
+        e = data.index(b"\0", pos); name = data[pos:e].decode(); pos = e + 1
+        e = data.index(b"\0", pos); typ = data[pos:e].decode(); pos = e + 1
+        n = struct.unpack_from("<I", data, pos)[0]; pos += 4
+        attrs[name] = (typ, data[pos:pos + n]); pos += n
+    pos += 1
+    chans, c, p = [], attrs["channels"][1], 0
+    while c[p] != 0:
+        e = c.index(b"\0", p); nm = c[p:e].decode(); p = e + 1
+        ptype = struct.unpack_from("<i", c, p)[0]; p += 16
+        chans.append((nm, ptype))
+    comp = attrs["compression"][1][0]
+    assert comp in (0, 2, 3), "compression %d not supported by this decoder" % comp
+    x0, y0, x1, y1 = struct.unpack("<iiii", attrs["dataWindow"][1])
+    w, h = x1 - x0 + 1, y1 - y0 + 1
+    lines = 16 if comp == 3 else 1
+    nblocks = (h + lines - 1) // lines
+    offs = struct.unpack_from("<%dQ" % nblocks, data, pos)
+    out = np.zeros((h, w, 4), np.float32); out[..., 3] = 1.0
+    col = {"R": 0, "G": 1, "B": 2, "A": 3}
+    bpp = {1: 2, 2: 4}
+    line_bytes = sum(bpp[t] for _, t in chans) * w
+    for o in offs:
+        by, n = struct.unpack_from("<ii", data, o)
+        rows = min(lines, y1 + 1 - by)
+        raw = data[o + 8:o + 8 + n]
+        if comp and n < rows * line_bytes:
+            d = np.frombuffer(zlib.decompress(raw), np.uint8).astype(np.int32)
+            t = d.copy()
+            for i in range(1, len(t)):                      # undo the delta predictor
+                t[i] = (t[i - 1] + d[i] - 128) & 255
+            half = (len(t) + 1) // 2
+            b = np.empty(len(t), np.uint8); b[0::2] = t[:half]; b[1::2] = t[half:]
+            raw = b.tobytes()
+        p = 0
+        for r in range(rows):
+            for nm, t in chans:
+                v = np.frombuffer(raw, np.float16 if t == 1 else np.float32, w, p).astype(np.float32); p += bpp[t] * w
+                if nm in col:
+                    out[by - y0 + r, :, col[nm]] = v
+    return out

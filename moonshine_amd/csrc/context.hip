@@ -898,6 +898,24 @@ int MsneTraceRays(HdMoonshine* c, const float* rays, uint32_t n, int any_hit, ui
     if (hipStreamSynchronize(c->stream) != hipSuccess) { c->fail("probe failed"); return -1; }
     return 0;
 }
+int MsnePick(HdMoonshine* c, SensorHandle sensor, LensHandle lens, F32x2 nc, MsneClickData* out) {
+    if (!c || !out) return -1;
+    f3 O, D;
+    {
+        LOCK(c);
+        if (sensor >= c->sensors.size() || lens >= c->lenses.size()) { c->fail("pick: bad sensor or lens handle"); return -1; }
+        const SensorH* s = c->sensors[sensor];
+        const CameraConsts cam = make_camera(c->lenses[lens], s->extent.width, s->extent.height);
+        float v = nc.y; v -= 1.0f; v *= -1.0f;                       // input.hlsl:46-48
+        camera_generate_ray(cam, F2(nc.x, v), F2(0.0f, 0.0f), O, D);
+    }
+    const float ray[7] = { O.x, O.y, O.z, D.x, D.y, D.z, INFINITY_F };
+    uint32_t ids[4] = { 0, 0, 0, 0 }; float tuv[3] = { 0, 0, 0 };
+    if (MsneTraceRays(c, ray, 1, 0, ids, tuv) != 0) return -1;
+    out->instance_index = ids[0] ? (int32_t)ids[1] : -1; out->geometry_index = ids[0] ? ids[2] : 0u; out->primitive_index = ids[0] ? ids[3] : 0u;
+    out->barycentrics = F32x2{ ids[0] ? tuv[1] : 0.0f, ids[0] ? tuv[2] : 0.0f };
+    return 0;
+}
 uint32_t MsneGetEnvSize(const HdMoonshine* c) { return c->env.size; }
 int MsneReadEnv(HdMoonshine* c, float* rgb_out /*S*S*4*/, float* lum_out /*whole pyramid*/) {
     LOCK(c);

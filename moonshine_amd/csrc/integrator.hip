@@ -52,11 +52,8 @@ __global__ __launch_bounds__(SHADE_BLOCK) void k_raygen(ShardView sh, CameraCons
         f2 uv = F2(((float)x + center.x) / (float)sh.width, ((float)y + center.y) / (float)sh.height);
         if (opts.flip_image) uv.y = 1.0f - uv.y;
         f2 r2; r2.x = rng_float(rng); r2.y = rng_float(rng);
-        const f2 sr = square_to_uniform_disk_concentric(r2);                        // camera.hlsl:31-40
-        const f2 rd = F2(cam.aperture * sr.x / 2.0f, cam.aperture * sr.y / 2.0f);
-        const f3 defocus = add(scale(cam.u, rd.x), scale(cam.v, rd.y));
-        const f3 O = add(cam.origin, defocus);
-        const f3 D = normalize(sub(sub(add(add(cam.llc, scale(cam.horizontal, uv.x)), scale(cam.vertical, uv.y)), defocus), cam.origin));
+        f3 O, D;
+        camera_generate_ray(cam, uv, r2, O, D);
         st.ro[i] = make_float4(O.x, O.y, O.z, u2f(0u)); st.rd[i] = make_float4(D.x, D.y, D.z, 0.0f);
         st.tx[i] = 1.0f; st.ty[i] = 1.0f; st.tz[i] = 1.0f;
         st.lx[i] = 0.0f; st.ly[i] = 0.0f; st.lz[i] = 0.0f;

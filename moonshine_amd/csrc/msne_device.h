@@ -138,6 +138,15 @@ struct CameraConsts {
     float aperture;
 };
 
+// Camera::generateRay (camera.hlsl:14-42) from the precomputed constants; shared by k_raygen and MsnePick
+MSNE_HD void camera_generate_ray(const CameraConsts& cam, f2 uv, f2 rand, f3& O, f3& D) {
+    const f2 sr = square_to_uniform_disk_concentric(rand);                        // camera.hlsl:31-40
+    const f2 rd = F2(cam.aperture * sr.x / 2.0f, cam.aperture * sr.y / 2.0f);
+    const f3 defocus = add(scale(cam.u, rd.x), scale(cam.v, rd.y));
+    O = add(cam.origin, defocus);
+    D = normalize(sub(sub(add(add(cam.llc, scale(cam.horizontal, uv.x)), scale(cam.vertical, uv.y)), defocus), cam.origin));
+}
+
 // which pixels this context owns: tile t of the image -> shard t mod shard_count
 struct ShardView {
     uint32_t width, height, tile_size, tiles_x, tiles_y;

@@ -3,7 +3,7 @@
 // the published OpenEXR 2 file layout).
 //   load: RGBA f32, like tinyexr's LoadEXRFromMemory (exr.zig:208-229): channels R,G,B,(A) by name, HALF or FLOAT
 //         or UINT pixels, compression NONE / RLE / ZIPS / ZIP, single-part scanline files, any line order.
-//   save: three FLOAT channels in header order B,G,R, scanline, uncompressed (exr.zig:137-206; alpha is dropped).
+//   save: three FLOAT channels in header order B,G,R, scanline, ZIP (exr.zig:137-206 with tinyexr's header defaults; alpha is dropped).
 #include "host.h"
 #include <zlib.h>
 #include <cstdio>
@@ -156,22 +156,35 @@ bool exr_save_rgb(const std::string& path, const float* rgba, uint32_t w, uint32
     std::vector<uint8_t> o;
     put<uint32_t>(o, 20000630u); put<uint32_t>(o, 2u);
     { std::vector<uint8_t> v; for (const char* n : { "B", "G", "R" }) { put_str(v, n); put<int32_t>(v, 2); put<uint8_t>(v, 0); put<uint8_t>(v, 0); put<uint8_t>(v, 0); put<uint8_t>(v, 0); put<int32_t>(v, 1); put<int32_t>(v, 1); } put<uint8_t>(v, 0); put_attr(o, "channels", "chlist", v); }
-    { std::vector<uint8_t> v; put<uint8_t>(v, 0); put_attr(o, "compression", "compression", v); }
+    { std::vector<uint8_t> v; put<uint8_t>(v, 3); put_attr(o, "compression", "compression", v); }   // ZIP
     { std::vector<uint8_t> v; put<int32_t>(v, 0); put<int32_t>(v, 0); put<int32_t>(v, (int32_t)w - 1); put<int32_t>(v, (int32_t)h - 1); put_attr(o, "dataWindow", "box2i", v); put_attr(o, "displayWindow", "box2i", v); }
     { std::vector<uint8_t> v; put<uint8_t>(v, 0); put_attr(o, "lineOrder", "lineOrder", v); }
     { std::vector<uint8_t> v; put<float>(v, 1.0f); put_attr(o, "pixelAspectRatio", "float", v); }
     { std::vector<uint8_t> v; put<float>(v, 0.0f); put<float>(v, 0.0f); put_attr(o, "screenWindowCenter", "v2f", v); }
     { std::vector<uint8_t> v; put<float>(v, 1.0f); put_attr(o, "screenWindowWidth", "float", v); }
     put<uint8_t>(o, 0);
+    // ZIP blocks of 16 scanlines, as tinyexr's InitEXRHeader default does for Rgba2D.save: per line the channels B, G, R;
+    // bytes split into even/odd halves, delta-predicted, deflated; a block that does not shrink is stored raw
     const size_t line_bytes = (size_t)w * 12, table = o.size();
-    o.resize(table + (size_t)h * 8);
-    for (uint32_t y = 0; y < h; y++) {
+    const uint32_t nblocks = (h + 15u) / 16u;
+    o.resize(table + (size_t)nblocks * 8);
+    std::vector<uint8_t> raw, tmp, z;
+    for (uint32_t b = 0; b < nblocks; b++) {
+        const uint32_t y0 = b * 16u, y1 = std::min(h, y0 + 16u);
+        raw.resize((size_t)(y1 - y0) * line_bytes);
+        for (uint32_t y = y0; y < y1; y++)
+            for (int c = 0; c < 3; c++) for (uint32_t x = 0; x < w; x++)
+                memcpy(&raw[(size_t)(y - y0) * line_bytes + ((size_t)c * w + x) * 4], &rgba[((size_t)y * w + x) * 4 + (2 - c)], 4);   // B, G, R
+        tmp.resize(raw.size());
+        { const size_t half = (raw.size() + 1) / 2; size_t a = 0, bq = half; for (size_t i = 0; i < raw.size(); i++) { if (i & 1) tmp[bq++] = raw[i]; else tmp[a++] = raw[i]; } }
+        { int prev = tmp.empty() ? 0 : tmp[0]; for (size_t i = 1; i < tmp.size(); i++) { const int cur = tmp[i]; tmp[i] = (uint8_t)(cur - prev + 128 + 256); prev = cur; } }
+        uLongf zn = compressBound((uLong)tmp.size());
+        z.resize(zn);
+        const bool packed = compress(z.data(), &zn, tmp.data(), (uLong)tmp.size()) == Z_OK && zn < raw.size();
         const uint64_t off = o.size();
-        memcpy(&o[table + (size_t)y * 8], &off, 8);
-        put<int32_t>(o, (int32_t)y); put<int32_t>(o, (int32_t)line_bytes);
-        const size_t base = o.size();
-        o.resize(base + line_bytes);
-        for (int c = 0; c < 3; c++) for (uint32_t x = 0; x < w; x++) memcpy(&o[base + ((size_t)c * w + x) * 4], &rgba[((size_t)y * w + x) * 4 + (2 - c)], 4);   // B, G, R
+        memcpy(&o[table + (size_t)b * 8], &off, 8);
+        put<int32_t>(o, (int32_t)y0); put<int32_t>(o, (int32_t)(packed ? zn : raw.size()));
+        if (packed) o.insert(o.end(), z.begin(), z.begin() + zn); else o.insert(o.end(), raw.begin(), raw.end());
     }
     FILE* f = fopen(path.c_str(), "wb");
     if (!f) { err = "cannot write " + path; return false; }

@@ -107,6 +107,31 @@ def test_trace_rays_instanced(orc, gpu_api):
     _check_rays(oc, gc, rays[:1500])
 
 
+def test_object_pick_matches_oracle(orc, gpu_api):
+    """ObjectPicker (ObjectPicker.zig:89-128, input.hlsl:24-69): one closest-hit ray through normalized sensor coordinates,
+    y flipped, lens sample (0,0) on the lens AS GIVEN (second lens: a real aperture, so the ray starts on the lens rim)."""
+    oc, so, lo, gc, sg, lg = both(orc, gpu_api, scenes.s1, extent=(96, 54), grid=3, order=3)
+    f = np.array([14.0, 14.0, -8.0]); f /= np.linalg.norm(f)
+    args = [scenes._lens((-14, -14, 9), tuple(f.astype(np.float32)), (0, 0, 1), 0.6),
+            scenes._lens((-14, -14, 9), tuple(f.astype(np.float32)), (0, 0, 1), 0.6, aperture=0.3, focus=20.0)]
+    handles = [(lo, lg), (oc.create_lens(oc.make_lens(**args[1])), gc.create_lens(gc.make_lens(**args[1])))]
+    hits = 0
+    for kw, (_, lens_g) in zip(args, handles):
+        olens = oc.make_lens(**kw)
+        for y in np.linspace(0.02, 0.98, 9):
+            for x in np.linspace(0.02, 0.98, 9):
+                got = gc.pick(sg, lens_g, float(np.float32(x)), float(np.float32(y)))
+                yy = np.float32(np.float32(np.float32(y) - np.float32(1.0)) * np.float32(-1.0))          # input.hlsl:46-48
+                r = orc.generate_ray(olens, 96, 54, float(np.float32(x)), float(yy), 0.0, 0.0)
+                hit, oid, otuv = oc.trace_closest(r[:3], r[3:6], 1e12)
+                assert (got is not None) == hit, (x, y)
+                if hit:
+                    hits += 1
+                    assert got[:3] == tuple(int(v) for v in oid), (x, y, got, oid)
+                    assert np.array_equal(np.array(got[3], np.float32).view(np.uint32), otuv[1:3].view(np.uint32)), (x, y)
+    assert hits > 40
+
+
 def test_empty_scene(orc, gpu_api):
     gc = gpu_api.Context(); oc = orc.Context()
     for c in (gc, oc):

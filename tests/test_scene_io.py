@@ -3,6 +3,8 @@ The importer is exercised against the oracle through tests/shim (no GPU needed);
 library in tests/test_gpu_io.py."""
 import math
 import os
+import subprocess
+import sys
 
 import numpy as np
 import pytest
@@ -40,6 +42,26 @@ def test_exr_writer_layout_and_roundtrip(tmp_path):
     assert b"A\0\x02" not in raw[i:i + 80]                                                                 # alpha dropped (exr.zig:158-172)
     got = api.exr_load(p)
     assert np.array_equal(bits(got[..., :3]), bits(img[..., :3])) and np.all(got[..., 3] == 1.0)
+    # ZIP blocks of 16 lines like the reference's writer (tinyexr header defaults), checked by the independent Python decoder
+    j = raw.index(b"compression\0compression\0")
+    assert raw[j + 28] == 3
+    big = rs.normal(size=(37, 21, 4)).astype(np.float32); big[5:30, 3:9] = 0.25      # compressible + a partial last block
+    api.exr_save(p, big)
+    dec = assets.exr_decode(open(p, "rb").read())
+    assert np.array_equal(bits(dec[..., :3]), bits(big[..., :3])) and np.all(dec[..., 3] == 1.0)
+    assert os.path.getsize(p) < 37 * 21 * 12 + 400
+
+
+def test_exrdiff_tool(tmp_path):
+    rs = np.random.default_rng(2)
+    a = rs.random((8, 8, 4)).astype(np.float32); b = a.copy(); b[3, 4, 1] += 1e-3
+    pa, pb = str(tmp_path / "a.exr"), str(tmp_path / "b.exr")
+    open(pa, "wb").write(assets.exr_bytes(a, "RGB", "float", "zip")); open(pb, "wb").write(assets.exr_bytes(b, "RGB", "half", "zips"))
+    tool = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "exrdiff.py")
+    r = subprocess.run([sys.executable, tool, pa, pa], capture_output=True, text=True)
+    assert r.returncode == 0 and "relative L2 0.000e+00" in r.stdout
+    r = subprocess.run([sys.executable, tool, pa, pb], capture_output=True, text=True)
+    assert r.returncode == 1 and "x=4, y=3" in r.stdout
 
 
 def test_exr_rejects_garbage(tmp_path):
