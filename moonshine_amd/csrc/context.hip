@@ -19,12 +19,12 @@
 namespace msne {
 // kernels' host wrappers (trace.hip, integrator.hip, env.hip, bvh_build.hip)
 void launch_trace_closest(hipStream_t, int, bool, const SceneView&, const PathState&, const HitBuf&, BounceCounters*, uint32_t*, uint32_t*, unsigned long long*, uint32_t);
-void launch_trace_shadow(hipStream_t, int, bool, const SceneView&, const ShadowQueue&, const PathState&, BounceCounters*, uint32_t*, uint32_t*, unsigned long long*, uint32_t);
+void launch_trace_shadow(hipStream_t, int, bool, const SceneView&, const ShadowQueue&, BounceCounters*, uint32_t*, uint32_t*, unsigned long long*, uint32_t);
 void launch_trace_probe(hipStream_t, int, const SceneView&, const float*, uint32_t, int, uint32_t*, uint32_t*, float*, uint32_t*, uint32_t*, uint32_t);
 size_t trace_spill_words(int grid);
 int trace_blocks_per_cu();
 void launch_raygen(hipStream_t, int, const ShardView&, const CameraConsts&, const PipelineOpts&, uint32_t, uint32_t, const PathState&, BounceCounters*);
-void launch_shade(hipStream_t, int, const SceneView&, const PipelineOpts&, const PathState&, const HitBuf&, const PathState&, const ShadowQueue&, float4*, BounceCounters*);
+void launch_shade(hipStream_t, int, const SceneView&, const PipelineOpts&, const PathState&, const HitBuf&, const PathState&, const ShadowQueue&, const float4*, float4*, BounceCounters*);
 void launch_account(hipStream_t, const BounceCounters*, uint32_t, Totals*);
 void launch_light_tris(hipStream_t, const SceneView&, uint32_t, uint32_t, LightTri*);
 void launch_film(hipStream_t, int, const ShardView&, const PipelineOpts&, const float4*, uint32_t, uint32_t, int, int, uint32_t, float4*, float4*);
@@ -71,20 +71,19 @@ struct SensorH {
 };
 
 struct PathBuffers {
-    DevBuf<float> f;      // ro, rd (float4 each) + 13 float arrays
-    DevBuf<uint32_t> u;   // rng, slot
+    DevBuf<float> f;      // ro, rd (float4 each) + 7 float arrays
+    DevBuf<uint32_t> u;   // rng, slot, pq
     size_t cap = 0;
     PathState view() const {
         PathState s; float* b = f.p; size_t c = cap;
         s.ro = reinterpret_cast<float4*>(b); s.rd = reinterpret_cast<float4*>(b + 4 * c);
         b += 8 * c;
         s.tx = b + 0 * c; s.ty = b + 1 * c; s.tz = b + 2 * c; s.lx = b + 3 * c; s.ly = b + 4 * c; s.lz = b + 5 * c;
-        s.p0x = b + 6 * c; s.p0y = b + 7 * c; s.p0z = b + 8 * c; s.p1x = b + 9 * c; s.p1y = b + 10 * c; s.p1z = b + 11 * c;
-        s.last_pdf = b + 12 * c;
-        s.rng = u.p; s.slot = u.p + c;
+        s.last_pdf = b + 6 * c;
+        s.rng = u.p; s.slot = u.p + c; s.pq = u.p + 2 * c;
         return s;
     }
-    bool ensure(size_t c) { if (c <= cap) return true; cap = 0; if (!f.alloc(21 * c) || !u.alloc(2 * c)) return false; cap = c; return true; }
+    bool ensure(size_t c) { if (c <= cap) return true; cap = 0; if (!f.alloc(15 * c) || !u.alloc(3 * c)) return false; cap = c; return true; }
 };
 
 }  // namespace
@@ -127,7 +126,7 @@ struct HdMoonshine {
     // (a few long rays, most CUs idle) the others' bulk work fills the machine.
     struct Pipe {
         PathBuffers paths[2];
-        DevBuf<uint32_t> hit_u, spill, spill2; DevBuf<float> shq_f;
+        DevBuf<uint32_t> hit_u, spill, spill2; DevBuf<float> shq_f; uint32_t shq_samples = 0;   // shadow queue: o, d, c x 2, each samples * cap float4
         DevBuf<BounceCounters> counters;   // one per bounce of the batch in flight (+1)
         DevBuf<Totals> totals;
         hipStream_t s0 = nullptr, s1 = nullptr;   // s1: k_trace_shadow, overlapped with the next bounce's k_trace_closest
@@ -142,7 +141,7 @@ struct HdMoonshine {
     DevBuf<uint32_t> d_overflow; DevBuf<unsigned long long> d_trace_stats;
     int trace_grid = 1024, shade_grid = 2048;
     uint32_t refill = 16;              // traversal: idle lanes (of 64) at which a wave refills from the ray queue; $MSNE_REFILL
-    size_t max_inflight = 160u << 20;  // most paths traced concurrently (276 B of wavefront state each, allocated on demand); $MSNE_MAX_INFLIGHT
+    size_t max_inflight = 160u << 20;  // most paths traced concurrently (288 B of wavefront state each at one env + one mesh light sample, allocated on demand); $MSNE_MAX_INFLIGHT
     // statistics
     MsneStats stats{};
     bool profile = false, trace_stats = false;
@@ -476,8 +475,13 @@ bool HdMoonshine::ensure_wavefront(size_t npaths, size_t slots, int npipes) {
         if (npaths > pp.cap) {
             const size_t c = (npaths + 255) & ~(size_t)255;
             pp.cap = 0;
-            if (!pp.paths[0].ensure(c) || !pp.paths[1].ensure(c) || !pp.hit_u.alloc(4 * c) || !pp.shq_f.alloc(8 * 2 * c)) { fail("out of device memory (wavefront state)"); return false; }
-            pp.cap = c;
+            if (!pp.paths[0].ensure(c) || !pp.paths[1].ensure(c) || !pp.hit_u.alloc(4 * c)) { fail("out of device memory (wavefront state)"); return false; }
+            pp.cap = c; pp.shq_samples = 0;
+        }
+        const uint32_t ns = std::max(1u, opts.env_samples + opts.mesh_samples);   // shadow-queue entries per path
+        if (ns > pp.shq_samples) {
+            if (!pp.shq_f.alloc(4 * 4 * (size_t)ns * pp.cap)) { pp.shq_samples = 0; fail("out of device memory (shadow queue)"); return false; }
+            pp.shq_samples = ns;
         }
         const size_t nc = (size_t)opts.max_bounces + 5;   // bounces 0 .. max_bounces + 2, the entry k_shade of the last one appends to, and the probe's
         if (pp.counters.n < nc && !pp.counters.alloc(nc)) return false;
@@ -558,9 +562,10 @@ bool HdMoonshine::render(uint32_t sensor, uint32_t lens, uint32_t launches, bool
     // go to lbuf[0 .. ns*P).  Two streams per pipe: k_trace_closest / k_shade / bookkeeping on s0, k_trace_shadow on s1 —
     // the shadow rays of bounce b are only needed by k_shade(b+1), so k_trace_shadow(b) overlaps k_trace_closest(b+1).
     auto trace_pass = [&](Pipe& pp, uint32_t first_sample, uint32_t ns, float4* lbuf) -> bool {
-        const size_t cap = pp.cap, qc = 2 * cap;
+        const size_t qc = (size_t)pp.shq_samples * pp.cap;   // shadow-queue capacity: o, d, then the two contribution buffers (by bounce parity)
         const HitBuf hits{ reinterpret_cast<uint4*>(pp.hit_u.p) };
-        const ShadowQueue shq{ reinterpret_cast<float4*>(pp.shq_f.p), reinterpret_cast<float4*>(pp.shq_f.p + 4 * qc) };
+        float4* const shq_f4 = reinterpret_cast<float4*>(pp.shq_f.p);
+        float4* const contrib[2] = { shq_f4 + 2 * qc, shq_f4 + 3 * qc };
         const PathState st[2] = { pp.paths[0].view(), pp.paths[1].view() };
         BounceCounters* cnt = pp.counters.p;   // [b] = the queues of bounce b: nothing to rotate or reset between kernels
         CHECK_HIP(this, hipMemsetAsync(cnt, 0, ((size_t)max_iter + 2) * sizeof(BounceCounters), pp.s0));
@@ -570,12 +575,13 @@ bool HdMoonshine::render(uint32_t sensor, uint32_t lens, uint32_t launches, bool
             const PathState& cur = st[b & 1]; const PathState& nxt = st[(b + 1) & 1];
             timed2(0, pp.s0, [&] { launch_trace_closest(pp.s0, trace_grid, trace_stats, sv, cur, hits, cnt + b, pp.spill.p, d_overflow.p, d_trace_stats.p, refill); });
             if (shadow_done) CHECK_HIP(this, hipStreamWaitEvent(pp.s0, shadow_done, 0));   // k_shade(b) consumes the results of k_trace_shadow(b-1)
-            timed2(2, pp.s0, [&] { launch_shade(pp.s0, shade_grid, sv, opts, cur, hits, nxt, shq, lbuf, cnt + b); });
+            const ShadowQueue shq{ shq_f4, shq_f4 + qc, contrib[b & 1] };
+            timed2(2, pp.s0, [&] { launch_shade(pp.s0, shade_grid, sv, opts, cur, hits, nxt, shq, contrib[(b + 1) & 1], lbuf, cnt + b); });
             hipEvent_t shade_done = next_event();
             if (!shade_done) { fail("hipEventCreate failed"); return false; }
             CHECK_HIP(this, hipEventRecord(shade_done, pp.s0));
             CHECK_HIP(this, hipStreamWaitEvent(pp.s1, shade_done, 0));
-            timed2(1, pp.s1, [&] { launch_trace_shadow(pp.s1, trace_grid, trace_stats, sv, shq, nxt, cnt + b + 1, pp.spill2.p, d_overflow.p, d_trace_stats.p, refill); });
+            timed2(1, pp.s1, [&] { launch_trace_shadow(pp.s1, trace_grid, trace_stats, sv, shq, cnt + b + 1, pp.spill2.p, d_overflow.p, d_trace_stats.p, std::max(1u, refill / 2)); });   // the shadow queue has unused entries (light samples with pdf 0): refill sooner
             shadow_done = next_event();
             if (!shadow_done) { fail("hipEventCreate failed"); return false; }
             CHECK_HIP(this, hipEventRecord(shadow_done, pp.s1));
@@ -770,7 +776,7 @@ void HdMoonshineSetInstanceTransform(HdMoonshine* c, InstanceHandle h, Mat3x4 t)
 int MsneSetPipeline(HdMoonshine* c, const MsnePipelineOpts* o) {
     LOCK(c);
     if (!o || o->samples_per_run == 0) { c->fail("pipeline: samples_per_run must be >= 1"); return -1; }
-    if (o->env_samples_per_bounce > 1 || o->mesh_samples_per_bounce > 1) { c->fail("pipeline: more than one env/mesh light sample per bounce is not supported by the wavefront integrator yet"); return -2; }
+    if (o->env_samples_per_bounce > 64 || o->mesh_samples_per_bounce > 64) { c->fail("pipeline: at most 64 env and 64 mesh light samples per bounce"); return -2; }
     if (o->max_bounces > 65000) { c->fail("pipeline: max_bounces too large"); return -1; }
     c->opts = PipelineOpts{ o->samples_per_run, o->max_bounces, o->env_samples_per_bounce, o->mesh_samples_per_bounce, o->flip_image, o->indexed_attributes, o->two_component_normal_texture };
     c->clear_all_sensors();                                   // hydra.zig:365-372

@@ -3,14 +3,14 @@
 //   k_shade   = one iteration of PathTracingIntegrator::incomingRadiance              (integrator.hlsl:79-166) + the miss epilogue (:168-181)
 //   k_film    = storeColor                                                            (main.hlsl:43-51,94)
 //   k_account = ray / sample statistics of a finished batch (no reference equivalent)
-// Light samples are generated in k_shade; their shadow rays are traced by k_trace_shadow, which zeroes the
-// pending contribution when occluded; the contribution is added to the path's radiance by the next k_shade
-// in the reference's order (env sample, then mesh sample — integrator.hlsl:139-151).
+// Light samples are generated in k_shade and stored, as if unoccluded, next to their shadow rays in the shadow queue;
+// k_trace_shadow zeroes the contribution of an occluded ray; the next k_shade adds a path's contributions to its radiance
+// in the reference's order (env samples, then mesh samples — integrator.hlsl:139-151).  Any number of samples per bounce.
 #include "shade.h"
 
 namespace msne {
 
-constexpr int SHADE_BLOCK = 256;   // k_shade is left at its natural 153 VGPRs (3 waves/SIMD): capping it at 128 / 96 spills and is 15 % / 80 % slower
+constexpr int SHADE_BLOCK = 256;   // k_shade is held at 168 VGPRs (3 waves/SIMD; 172 unconstrained = 2 waves, 25 % slower); 128 (4 waves) spills 61 registers and is 15 % slower
 
 __device__ __forceinline__ uint32_t wave_append(uint32_t* counter, bool pred) {
     const unsigned long long m = __ballot(pred);
@@ -57,7 +57,6 @@ __global__ __launch_bounds__(SHADE_BLOCK) void k_raygen(ShardView sh, CameraCons
         st.ro[i] = make_float4(O.x, O.y, O.z, u2f(0u)); st.rd[i] = make_float4(D.x, D.y, D.z, 0.0f);
         st.tx[i] = 1.0f; st.ty[i] = 1.0f; st.tz[i] = 1.0f;
         st.lx[i] = 0.0f; st.ly[i] = 0.0f; st.lz[i] = 0.0f;
-        st.p0x[i] = 0.0f; st.p0y[i] = 0.0f; st.p0z[i] = 0.0f; st.p1x[i] = 0.0f; st.p1y[i] = 0.0f; st.p1z[i] = 0.0f;
         st.last_pdf[i] = 0.0f; st.rng[i] = rng; st.slot[i] = slot;
     }
 }
@@ -107,12 +106,16 @@ __device__ __forceinline__ f3 estimate_direct_mis(const Frame& frame, const LSam
     return F3(0.0f, 0.0f, 0.0f);
 }
 
-__global__ __launch_bounds__(SHADE_BLOCK) void k_shade(SceneView sc, PipelineOpts opts, PathState cur, HitBuf hits, PathState nxt, ShadowQueue shq,
+__global__ __launch_bounds__(SHADE_BLOCK, 3) void k_shade(SceneView sc, PipelineOpts opts, PathState cur, HitBuf hits, PathState nxt, ShadowQueue shq,
+                                                         const float4* c_prev /* light-sample contributions of the previous bounce */,
                                                          float4* lbuf, BounceCounters* cnt /* [0]: this bounce, [1]: the next */) {
     const uint32_t n = cnt[0].n_paths;
     const uint32_t max_bounces = opts.max_bounces, env_n = opts.env_samples, mesh_n = opts.mesh_samples;
+    const bool have_lights = !(sc.alias_count == 0 || sc.alias_sum == 0.0f);                  // MeshLights::sample returns pdf 0 without them (light.hlsl:131)
+    const uint32_t n_nee = env_n + (have_lights ? mesh_n : 0u);                               // shadow-queue entries per path that samples lights
     __shared__ unsigned long long s_cnt[SHADE_BLOCK / 64];
     __shared__ unsigned long long s_base;
+    __shared__ uint32_t s_stride;
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     const unsigned long long lt = lane == 0 ? 0ull : (~0ull >> (64 - lane));
     const uint32_t n_pad = (n + (SHADE_BLOCK - 1u)) & ~(SHADE_BLOCK - 1u);   // trip count uniform per workgroup (it synchronises below)
@@ -129,7 +132,7 @@ __global__ __launch_bounds__(SHADE_BLOCK) void k_shade(SceneView sc, PipelineOpt
             const uint32_t i0 = base_i + threadIdx.x;
             if (i0 < n) {
                 const uint32_t fl = f2u(cur.ro[i0].w);
-                if (!(fl & PATH_FLAG_MASKED)) {
+                if (!(fl & (PATH_FLAG_MASKED | PATH_FLAG_DEAD))) {
                     if (fl & PATH_FLAG_ZOMBIE) cat = 0u;
                     else {
                         const uint4 hr = hits.rec[i0];
@@ -167,23 +170,28 @@ __global__ __launch_bounds__(SHADE_BLOCK) void k_shade(SceneView sc, PipelineOpt
         const bool live = threadIdx.x < s_cat[NCAT * (SHADE_BLOCK / 64)];
         const uint32_t src = live ? s_perm[threadIdx.x] : 0u;   // the thread that classified this path
         const uint32_t i = live ? base_i + src : n_pad;
-        float4 ro4 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-        if (live) ro4 = cur.ro[i];
-        bool cont = false, sh0 = false, sh1 = false;
-        // state carried to the next bounce
-        f3 rayO = F3(0, 0, 0), rayD = F3(0, 0, 1), throughput = F3(0, 0, 0), L = F3(0, 0, 0), c0 = F3(0, 0, 0), c1 = F3(0, 0, 0);
-        f3 s0o = F3(0, 0, 0), s0d = F3(0, 0, 0), s1o = F3(0, 0, 0), s1d = F3(0, 0, 0);
-        float s0t = 0.0f, s1t = 0.0f, lastPdf = 0.0f;
-        uint32_t rng = 0, slot = 0, flags = 0;
+        // ---- phase A: what the hit means for the path (pending light samples, miss epilogue, emission, termination) ----
+        bool alive = false, nee = false, delta = false;
+        f3 rayO = F3(0, 0, 0), rayD = F3(0, 0, 1), throughput = F3(0, 0, 0), L = F3(0, 0, 0), woSs = F3(0, 0, 1);
+        float lastPdf = 0.0f;
+        uint32_t rng = 0, slot = 0, flags = 0, bounceCount = 0;
+        Attrs attrs; Frame shadingFrame; Mat material;
+        attrs.position = F3(0, 0, 0); attrs.triangleFrame.n = F3(0, 0, 1); shadingFrame.n = F3(0, 0, 1); shadingFrame.s = F3(1, 0, 0); shadingFrame.t = F3(0, 1, 0);
+        material.type = MAT_LAMBERT; material.color = F3(0, 0, 0); material.metalness = 0.0f; material.alpha = 0.0f; material.ior = 1.0f;
         if (live) {
+            const float4 ro4 = cur.ro[i];
             { const float4 rd4 = cur.rd[i]; rayO = F3(ro4.x, ro4.y, ro4.z); rayD = F3(rd4.x, rd4.y, rd4.z); }
             throughput = F3(cur.tx[i], cur.ty[i], cur.tz[i]);
             L = F3(cur.lx[i], cur.ly[i], cur.lz[i]);
             lastPdf = cur.last_pdf[i]; rng = cur.rng[i]; slot = cur.slot[i]; flags = f2u(ro4.w);
-            // light samples of the previous bounce, in the reference's order (env, then mesh)
-            L = add(L, F3(cur.p0x[i], cur.p0y[i], cur.p0z[i]));
-            L = add(L, F3(cur.p1x[i], cur.p1y[i], cur.p1z[i]));
-            const uint32_t bounceCount = flags & 0xFFFFu;
+            // light samples of the previous bounce, in the reference's order (env samples, then mesh samples): each was stored
+            // unoccluded next to its shadow ray and zeroed by k_trace_shadow if the ray was blocked
+            if (flags & PATH_FLAG_NEE) {
+                const uint32_t pq = cur.pq[i];
+                const uint32_t ps = (flags >> PATH_STRIDE_SHIFT) & 0x1ffu;
+                for (uint32_t k = 0; k < n_nee; k++) { const float4 c = c_prev[pq + k * ps]; L = add(L, F3(c.x, c.y, c.z)); }
+            }
+            bounceCount = flags & 0xFFFFu;
             const bool isLastMaterialDelta = (flags & PATH_FLAG_DELTA) != 0;
             bool done = (flags & PATH_FLAG_ZOMBIE) != 0;
             const uint4 hrec = s_hit[src];
@@ -202,21 +210,20 @@ __global__ __launch_bounds__(SHADE_BLOCK) void k_shade(SceneView sc, PipelineOpt
                 const uint32_t htri = hrec.y;
                 const uint4 pg = s_geo[src];
                 GeometryRec geometry; geometry.mesh = pg.x; geometry.material = pg.y; geometry.sampled = pg.z;
-                const Attrs attrs = mesh_attributes_world(sc, opts.indexed_attributes != 0, hinst, 0u, 0u, F2(u2f(hrec.z), u2f(hrec.w)), geometry, htri, true);
+                attrs = mesh_attributes_world(sc, opts.indexed_attributes != 0, hinst, 0u, 0u, F2(u2f(hrec.z), u2f(hrec.w)), geometry, htri, true);
                 MaterialRec mrec;
                 { const uint4 m0 = s_mat[0][src], m1 = s_mat[1][src];
                   mrec.normal = m0.x; mrec.emissive = m0.y; mrec.type = m0.z; mrec.color = m0.w; mrec.metalness = m1.x; mrec.roughness = m1.y; mrec.ior = u2f(m1.z); mrec.pad = m1.w; }
                 const Frame textureFrame = get_texture_frame(sc, mrec, opts.two_component_normal_texture != 0, attrs.texcoord, attrs.frame);
                 const f3 emissiveLight = tex_sample_rgb(sc, mrec.emissive, attrs.texcoord);
-                const Mat material = material_load(sc, mrec, attrs.texcoord);
+                material = material_load(sc, mrec, attrs.texcoord);
 
                 const f3 woWs = neg(rayD);
                 const bool frontfacing = dot(attrs.triangleFrame.n, woWs) > 0.0f;
-                Frame shadingFrame;
                 if ((frontfacing && dot(woWs, textureFrame.n) > 0.0f) || (!frontfacing && -dot(woWs, textureFrame.n) > 0.0f)) shadingFrame = textureFrame;
                 else if ((frontfacing && dot(woWs, attrs.frame.n) > 0.0f) || (!frontfacing && -dot(woWs, attrs.frame.n) > 0.0f)) shadingFrame = attrs.frame;
                 else shadingFrame = attrs.triangleFrame;
-                const f3 woSs = frame_world_to_frame(shadingFrame, woWs);
+                woSs = frame_world_to_frame(shadingFrame, woWs);
 
                 // emission, integrator.hlsl:108-124
                 const bool geo_sampled = (geometry.sampled & GEO_SAMPLED) != 0;
@@ -234,105 +241,112 @@ __global__ __launch_bounds__(SHADE_BLOCK) void k_shade(SceneView sc, PipelineOpt
                     if (rng_float(rng) > pSurvive) done = true;
                     else throughput = divs(throughput, pSurvive);
                 }
-                if (!done) {
-                    const bool isCurrentMaterialDelta = material_is_delta(material);
-                    if (!isCurrentMaterialDelta) {
-                        if (env_n) {   // integrator.hlsl:141-144 (one sample; MsneSetPipeline rejects > 1)
-                            f2 rand; rand.x = rng_float(rng); rand.y = rng_float(rng);
-                            const LSample ls = env_sample_unoccluded(sc.env, rand);
-                            if (ls.pdf > 0.0f) {
-                                sh0 = true;
-                                s0o = offset_along_normal(attrs.position, face_forward(attrs.triangleFrame.n, ls.dirWs)); s0d = ls.dirWs; s0t = INFINITY_F;
-                                const f3 e = estimate_direct_mis(shadingFrame, ls, material, woSs, env_n);
-                                c0 = divs(mul(throughput, e), (float)env_n);
-                            }
-                        }
-                        if (mesh_n) {  // integrator.hlsl:147-150 + MeshLights::sample light.hlsl:130-158
-                            f2 rand; rand.x = rng_float(rng); rand.y = rng_float(rng);
-                            const uint32_t entryCount = sc.alias_count;
-                            const float sum = sc.alias_sum;
-                            if (!(entryCount == 0 || sum == 0.0f)) {
-                                const float scaled = rand.x * (float)entryCount;
-                                uint32_t idx = (uint32_t)scaled;
-                                rand.x = scaled - floor_(scaled);
-                                AliasEntry en = alias_load(sc, entryCount, 1 + idx);
-                                if (!coin_flip_remap(en.select, rand.x)) { idx = en.alias; en = alias_load(sc, entryCount, 1 + idx); }
-                                const f2 bary = square_to_triangle(rand);
-                                // MeshAttributes::lookupAndInterpolate(...).inWorld(...) (world.hlsl:114-176) from the light's gathered record
-                                // (position, texcoord and triangle normal are all the light sample uses; same operations, same order)
-                                const uint4* lp = reinterpret_cast<const uint4*>(sc.light_tris + (idx < entryCount ? idx : entryCount));
-                                const uint4 la = lp[0], lb = lp[1], lc = lp[2], ld = lp[3];
-                                const InstanceRec* linst = sc.instances + en.instance;
-                                const m34 ltoWorld = linst->transform, ltoMesh = linst->world_to_instance;
-                                const f3 lp0 = F3(u2f(la.x), u2f(la.y), u2f(la.z)), lp1 = F3(u2f(la.w), u2f(lb.x), u2f(lb.y)), lp2 = F3(u2f(lb.z), u2f(lb.w), u2f(lc.x));
-                                const f3 lbary = F3(1.0f - bary.x - bary.y, bary.x, bary.y);
-                                const f3 at_position = m34_mul_point(ltoWorld, interp3(lbary, lp0, lp1, lp2));
-                                const f2 at_texcoord = interp2(lbary, F2(u2f(lc.y), u2f(lc.z)), F2(u2f(lc.w), u2f(ld.x)), F2(u2f(ld.y), u2f(ld.z)));
-                                const f3 at_n = normalize(m34_mul_transposed(ltoMesh, normalize(cross(sub(lp0, lp2), sub(lp1, lp2)))));
-                                LSample ls;
-                                ls.radiance = tex_sample_rgb(sc, sc.materials[ld.w].emissive, at_texcoord);
-                                ls.dirWs = normalize(sub(at_position, attrs.position));
-                                ls.pdf = area_to_solid_angle(at_position, attrs.position, ls.dirWs, at_n) / sum;
-                                if (ls.pdf > 0.0f) {
-                                    const f3 offL = offset_along_normal(at_position, at_n);
-                                    const f3 offS = offset_along_normal(attrs.position, face_forward(attrs.triangleFrame.n, ls.dirWs));
-                                    sh1 = true;
-                                    s1t = length(sub(offL, offS)); s1o = offS; s1d = normalize(sub(offL, offS));
-                                    const f3 e = estimate_direct_mis(shadingFrame, ls, material, woSs, mesh_n);
-                                    c1 = divs(mul(throughput, e), (float)mesh_n);
-                                }
-                            }
-                        }
-                    }
-                    // next direction, integrator.hlsl:153-165
-                    f2 sq; sq.x = rng_float(rng); sq.y = rng_float(rng);
-                    const MSample sample = material_sample(material, woSs, sq);
-                    if (sample.pdf == 0.0f) {
-                        done = true;
-                        if (sh0 || sh1) { cont = true; flags |= PATH_FLAG_ZOMBIE; done = false; atomicAdd(&cnt[1].zombies, 1u); }   // finalize after its shadow rays resolve
-                    } else {
-                        lastPdf = sample.pdf;
-                        rayD = frame_frame_to_world(shadingFrame, sample.dirFs);
-                        rayO = offset_along_normal(attrs.position, face_forward(attrs.triangleFrame.n, rayD));
-                        const f3 f = material_eval(material, sample.dirFs, woSs);
-                        const float ac = absf(sample.dirFs.z);
-                        throughput = mul(throughput, F3(f.x * ac / sample.pdf, f.y * ac / sample.pdf, f.z * ac / sample.pdf));
-                        flags = ((bounceCount + 1u) & 0xFFFFu) | (isCurrentMaterialDelta ? PATH_FLAG_DELTA : 0u);
-                        cont = true;
-                    }
-                }
+                if (!done) { alive = true; delta = material_is_delta(material); nee = !delta && n_nee != 0u; }
             }
             if (done) lbuf[slot] = make_float4(L.x, L.y, L.z, 0.0f);
         }
-        // ---- compaction: surviving paths and their shadow rays.  One 64-bit atomic per WORKGROUP reserves both
-        // ranges (low word: next-path queue, high word: shadow queue) — per-wave atomics on one counter cap the
-        // kernel at ~88 waves/us (MI355X_MICROARCH.md "dequeue") ----
-        const unsigned long long mc = __ballot(cont), m0 = __ballot(sh0), m1 = __ballot(sh1);
-        const uint32_t wc = (uint32_t)__popcll(mc), w0 = (uint32_t)__popcll(m0), w1 = (uint32_t)__popcll(m1);
-        if (lane == 0) s_cnt[wave] = (unsigned long long)wc | ((unsigned long long)(w0 + w1) << 32);
+        // ---- phase B: queue slots.  One 64-bit atomic per WORKGROUP reserves both ranges (low word: one next-path entry per
+        // surviving path, high word: n_nee shadow-ray entries per path that samples lights) — per-wave atomics on one counter
+        // cap the kernel at ~88 waves/us (MI355X_MICROARCH.md "dequeue").  Reserving before the samples exist means they are
+        // written straight to the queue instead of waiting in registers; a sample with pdf 0 leaves an unused entry. ----
+        const unsigned long long ma = __ballot(alive), mn = __ballot(nee);
+        if (lane == 0) s_cnt[wave] = (unsigned long long)__popcll(ma) | ((unsigned long long)__popcll(mn) << 32);
         __syncthreads();
         if (threadIdx.x == 0) {
             unsigned long long tot = 0;
             for (int k = 0; k < SHADE_BLOCK / 64; k++) tot += s_cnt[k];
-            s_base = tot ? atomicAdd(reinterpret_cast<unsigned long long*>(&cnt[1].n_paths), tot) : 0ull;
+            const uint32_t np = (uint32_t)(tot >> 32);   // paths of this workgroup that sample lights: sample k of all of them is stored together
+            s_stride = np;                               // (keeps env rays with env rays and light rays with light rays in the shadow queue)
+            s_base = tot ? atomicAdd(reinterpret_cast<unsigned long long*>(&cnt[1].n_paths), (tot & 0xffffffffull) | ((unsigned long long)(np * n_nee) << 32)) : 0ull;
         }
         __syncthreads();
         unsigned long long base = s_base;
+        const uint32_t stride = s_stride;
         for (uint32_t k = 0; k < wave; k++) base += s_cnt[k];
-        __syncthreads();   // s_cnt / s_base are rewritten by the next iteration
-        const uint32_t j = (uint32_t)base + (uint32_t)__popcll(mc & lt);
-        const uint32_t qb = (uint32_t)(base >> 32);
-        if (cont) {
-            nxt.ro[j] = make_float4(rayO.x, rayO.y, rayO.z, u2f(flags)); nxt.rd[j] = make_float4(rayD.x, rayD.y, rayD.z, 0.0f);
-            nxt.tx[j] = throughput.x; nxt.ty[j] = throughput.y; nxt.tz[j] = throughput.z;
-            nxt.lx[j] = L.x; nxt.ly[j] = L.y; nxt.lz[j] = L.z;
-            nxt.p0x[j] = c0.x; nxt.p0y[j] = c0.y; nxt.p0z[j] = c0.z; nxt.p1x[j] = c1.x; nxt.p1y[j] = c1.y; nxt.p1z[j] = c1.z;
-            nxt.last_pdf[j] = lastPdf; nxt.rng[j] = rng; nxt.slot[j] = slot;
+        __syncthreads();   // s_cnt / s_base / s_stride are rewritten by the next iteration
+        const uint32_t j = (uint32_t)base + (uint32_t)__popcll(ma & lt);
+        const uint32_t q = (uint32_t)(base >> 32) + (uint32_t)__popcll(mn & lt);   // sample k of this path: entry q + k * stride
+        // ---- phase C: light samples (integrator.hlsl:137-151) and the next direction (:153-165) ----
+        if (alive) {
+            uint32_t valid = 0;
+            if (!delta) {   // the random numbers of every sample are drawn whether or not it gets a queue entry
+                for (uint32_t k = 0; k < env_n; k++) {   // integrator.hlsl:141-144
+                    f2 rand; rand.x = rng_float(rng); rand.y = rng_float(rng);
+                    const LSample ls = env_sample_unoccluded(sc.env, rand);
+                    const uint32_t e_ = q + k * stride;
+                    if (ls.pdf > 0.0f) {
+                        const f3 so = offset_along_normal(attrs.position, face_forward(attrs.triangleFrame.n, ls.dirWs));
+                        const f3 e = estimate_direct_mis(shadingFrame, ls, material, woSs, env_n);
+                        const f3 cc = divs(mul(throughput, e), (float)env_n);
+                        shq.o[e_] = make_float4(so.x, so.y, so.z, INFINITY_F); shq.d[e_] = make_float4(ls.dirWs.x, ls.dirWs.y, ls.dirWs.z, 0.0f);
+                        shq.c[e_] = make_float4(cc.x, cc.y, cc.z, 0.0f);
+                        valid++;
+                    } else { shq.o[e_] = make_float4(0.0f, 0.0f, 0.0f, -1.0f); shq.c[e_] = make_float4(0.0f, 0.0f, 0.0f, 0.0f); }
+                }
+                for (uint32_t k = 0; k < mesh_n; k++) {  // integrator.hlsl:147-150 + MeshLights::sample light.hlsl:130-158
+                    f2 rand; rand.x = rng_float(rng); rand.y = rng_float(rng);
+                    const uint32_t e_ = q + (env_n + k) * stride;
+                    if (!have_lights) continue;
+                    bool ok = false;
+                    const uint32_t entryCount = sc.alias_count;
+                    const float sum = sc.alias_sum;
+                    {
+                        const float scaled = rand.x * (float)entryCount;
+                        uint32_t idx = (uint32_t)scaled;
+                        rand.x = scaled - floor_(scaled);
+                        AliasEntry en = alias_load(sc, entryCount, 1 + idx);
+                        if (!coin_flip_remap(en.select, rand.x)) { idx = en.alias; en = alias_load(sc, entryCount, 1 + idx); }
+                        const f2 bary = square_to_triangle(rand);
+                        // MeshAttributes::lookupAndInterpolate(...).inWorld(...) (world.hlsl:114-176) from the light's gathered record
+                        // (position, texcoord and triangle normal are all the light sample uses; same operations, same order)
+                        const uint4* lp = reinterpret_cast<const uint4*>(sc.light_tris + (idx < entryCount ? idx : entryCount));
+                        const uint4 la = lp[0], lb = lp[1], lc = lp[2], ld = lp[3];
+                        const InstanceRec* linst = sc.instances + en.instance;
+                        const m34 ltoWorld = linst->transform, ltoMesh = linst->world_to_instance;
+                        const f3 lp0 = F3(u2f(la.x), u2f(la.y), u2f(la.z)), lp1 = F3(u2f(la.w), u2f(lb.x), u2f(lb.y)), lp2 = F3(u2f(lb.z), u2f(lb.w), u2f(lc.x));
+                        const f3 lbary = F3(1.0f - bary.x - bary.y, bary.x, bary.y);
+                        const f3 at_position = m34_mul_point(ltoWorld, interp3(lbary, lp0, lp1, lp2));
+                        const f2 at_texcoord = interp2(lbary, F2(u2f(lc.y), u2f(lc.z)), F2(u2f(lc.w), u2f(ld.x)), F2(u2f(ld.y), u2f(ld.z)));
+                        const f3 at_n = normalize(m34_mul_transposed(ltoMesh, normalize(cross(sub(lp0, lp2), sub(lp1, lp2)))));
+                        LSample ls;
+                        ls.radiance = tex_sample_rgb(sc, sc.materials[ld.w].emissive, at_texcoord);
+                        ls.dirWs = normalize(sub(at_position, attrs.position));
+                        ls.pdf = area_to_solid_angle(at_position, attrs.position, ls.dirWs, at_n) / sum;
+                        if (ls.pdf > 0.0f) {
+                            const f3 offL = offset_along_normal(at_position, at_n);
+                            const f3 offS = offset_along_normal(attrs.position, face_forward(attrs.triangleFrame.n, ls.dirWs));
+                            const float st_ = length(sub(offL, offS)); const f3 sd = normalize(sub(offL, offS));
+                            const f3 e = estimate_direct_mis(shadingFrame, ls, material, woSs, mesh_n);
+                            const f3 cc = divs(mul(throughput, e), (float)mesh_n);
+                            shq.o[e_] = make_float4(offS.x, offS.y, offS.z, st_); shq.d[e_] = make_float4(sd.x, sd.y, sd.z, 0.0f);
+                            shq.c[e_] = make_float4(cc.x, cc.y, cc.z, 0.0f);
+                            ok = true; valid++;
+                        }
+                    }
+                    if (!ok) { shq.o[e_] = make_float4(0.0f, 0.0f, 0.0f, -1.0f); shq.c[e_] = make_float4(0.0f, 0.0f, 0.0f, 0.0f); }
+                }
+            }
+            // next direction, integrator.hlsl:153-165
+            f2 sq; sq.x = rng_float(rng); sq.y = rng_float(rng);
+            const MSample sample = material_sample(material, woSs, sq);
+            if (sample.pdf == 0.0f) {
+                // the path ends here; with light samples in flight it is finalised one pass later (after their shadow rays)
+                atomicAdd(&cnt[1].zombies, 1u);
+                if (valid) { nxt.ro[j] = make_float4(0.0f, 0.0f, 0.0f, u2f(PATH_FLAG_ZOMBIE | PATH_FLAG_NEE | (stride << PATH_STRIDE_SHIFT))); nxt.lx[j] = L.x; nxt.ly[j] = L.y; nxt.lz[j] = L.z; nxt.pq[j] = q; nxt.slot[j] = slot; }
+                else { nxt.ro[j] = make_float4(0.0f, 0.0f, 0.0f, u2f(PATH_FLAG_ZOMBIE | PATH_FLAG_DEAD)); lbuf[slot] = make_float4(L.x, L.y, L.z, 0.0f); }
+            } else {
+                const f3 nd = frame_frame_to_world(shadingFrame, sample.dirFs);
+                const f3 no = offset_along_normal(attrs.position, face_forward(attrs.triangleFrame.n, nd));
+                const f3 f = material_eval(material, sample.dirFs, woSs);
+                const float ac = absf(sample.dirFs.z);
+                const f3 tp = mul(throughput, F3(f.x * ac / sample.pdf, f.y * ac / sample.pdf, f.z * ac / sample.pdf));
+                const uint32_t nf = ((bounceCount + 1u) & 0xFFFFu) | (delta ? PATH_FLAG_DELTA : 0u) | (nee ? (PATH_FLAG_NEE | (stride << PATH_STRIDE_SHIFT)) : 0u);
+                nxt.ro[j] = make_float4(no.x, no.y, no.z, u2f(nf)); nxt.rd[j] = make_float4(nd.x, nd.y, nd.z, 0.0f);
+                nxt.tx[j] = tp.x; nxt.ty[j] = tp.y; nxt.tz[j] = tp.z;
+                nxt.lx[j] = L.x; nxt.ly[j] = L.y; nxt.lz[j] = L.z;
+                nxt.last_pdf[j] = sample.pdf; nxt.rng[j] = rng; nxt.slot[j] = slot; nxt.pq[j] = q;
+            }
         }
-        const uint32_t q0 = qb + (uint32_t)__popcll(m0 & lt);
-        if (sh0) { shq.o[q0] = make_float4(s0o.x, s0o.y, s0o.z, s0t); shq.d[q0] = make_float4(s0d.x, s0d.y, s0d.z, u2f(j << 1)); }
-        const uint32_t q1 = qb + w0 + (uint32_t)__popcll(m1 & lt);
-        if (sh1) { shq.o[q1] = make_float4(s1o.x, s1o.y, s1o.z, s1t); shq.d[q1] = make_float4(s1d.x, s1d.y, s1d.z, u2f((j << 1) | 1u)); }
     }
 }
 
@@ -340,7 +354,7 @@ __global__ __launch_bounds__(SHADE_BLOCK) void k_shade(SceneView sc, PipelineOpt
 __global__ void k_account(const BounceCounters* c, uint32_t n_bounces, Totals* t) {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
     unsigned long long closest = 0, shadow = 0;
-    for (uint32_t b = 0; b <= n_bounces; b++) { closest += c[b].n_paths - c[b].zombies; shadow += c[b].n_shadow_in; }
+    for (uint32_t b = 0; b <= n_bounces; b++) { closest += c[b].n_paths - c[b].zombies; shadow += c[b].n_shadow_traced; }
     t->closest_rays += closest; t->shadow_rays += shadow; t->samples += c[0].n_paths - c[0].zombies;
 }
 
@@ -392,8 +406,8 @@ __global__ __launch_bounds__(SHADE_BLOCK) void k_unpack_film(ShardView sh, const
 void launch_raygen(hipStream_t s, int grid, const ShardView& sh, const CameraConsts& cam, const PipelineOpts& o, uint32_t sample_base, uint32_t s_count, const PathState& st, BounceCounters* cnt) {
     hipLaunchKernelGGL(k_raygen, dim3(grid), dim3(SHADE_BLOCK), 0, s, sh, cam, o, sample_base, s_count, st, cnt);
 }
-void launch_shade(hipStream_t s, int grid, const SceneView& sc, const PipelineOpts& o, const PathState& cur, const HitBuf& hits, const PathState& nxt, const ShadowQueue& q, float4* lbuf, BounceCounters* cnt) {
-    hipLaunchKernelGGL(k_shade, dim3(grid), dim3(SHADE_BLOCK), 0, s, sc, o, cur, hits, nxt, q, lbuf, cnt);
+void launch_shade(hipStream_t s, int grid, const SceneView& sc, const PipelineOpts& o, const PathState& cur, const HitBuf& hits, const PathState& nxt, const ShadowQueue& q, const float4* c_prev, float4* lbuf, BounceCounters* cnt) {
+    hipLaunchKernelGGL(k_shade, dim3(grid), dim3(SHADE_BLOCK), 0, s, sc, o, cur, hits, nxt, q, c_prev, lbuf, cnt);
 }
 void launch_light_tris(hipStream_t s, const SceneView& sc, uint32_t indexed_attributes, uint32_t n_instances, LightTri* out) {
     hipLaunchKernelGGL(k_light_tris, dim3((sc.alias_count + 1 + 255) / 256), dim3(256), 0, s, sc, indexed_attributes, n_instances, out);

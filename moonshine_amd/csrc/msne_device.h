@@ -93,25 +93,32 @@ struct PathState {
     float4* rd;                          // ray direction xyz | w unused
     float* tx; float* ty; float* tz;     // throughput
     float* lx; float* ly; float* lz;     // accumulated radiance
-    float* p0x; float* p0y; float* p0z;  // pending env-NEE contribution (zeroed by k_trace_shadow if occluded)
-    float* p1x; float* p1y; float* p1z;  // pending mesh-NEE contribution
     float* last_pdf;
     uint32_t* rng;
     uint32_t* slot;                      // sample slot: s_local * pixels + pixel_local
-    // flags (in ro.w): bits 0..15 bounce count, bit 16 last material delta, bit 17 zombie (finalize only), bit 18 masked
+    uint32_t* pq;                        // first of the path's light-sample entries in the shadow queue (PATH_FLAG_NEE)
+    // flags (in ro.w): bits 0..15 bounce count, bit 16 last material delta, bit 17 no ray (finalise only), bit 18 masked,
+    // bit 19 light samples pending (env_samples + mesh_samples entries from pq, PATH_STRIDE apart), bit 20 dead
 };
 constexpr uint32_t PATH_FLAG_DELTA = 1u << 16;
-constexpr uint32_t PATH_FLAG_ZOMBIE = 1u << 17;
-constexpr uint32_t PATH_FLAG_MASKED = 1u << 18;   // slot of a pixel outside the image (edge tiles): dropped by the first k_shade
-constexpr int PATH_STATE_WORDS = 23;
+constexpr uint32_t PATH_FLAG_ZOMBIE = 1u << 17;   // no ray to trace: the entry only waits for k_shade (to add its light samples and finalise) or is dead / masked
+constexpr uint32_t PATH_FLAG_MASKED = 1u << 18;   // slot of a pixel outside the image (edge tiles): ignored by k_shade
+constexpr uint32_t PATH_FLAG_NEE = 1u << 19;
+constexpr uint32_t PATH_STRIDE_SHIFT = 21;        // bits 21..29: distance between a path's consecutive light-sample entries (the light-sampling paths of its workgroup)
+constexpr uint32_t PATH_FLAG_DEAD = 1u << 20;     // ended in k_shade after its queue entry was reserved: ignored by k_shade
+constexpr int PATH_STATE_WORDS = 18;
 
 // rec = {instance, triangle slot in SceneView::tris, u bits, v bits}: ONE 16-B store per finished ray; k_shade reads the
 // 48-B triangle record (vertices + geometry + primitive) instead of chasing instance → geometry → mesh → indices → positions
 struct HitBuf { uint4* rec; };
 
+// One entry per light sample of a path: the shadow ray and the sample's unoccluded contribution.  A workgroup of k_shade
+// stores sample k of all its paths together (entry = first + k * stride), env samples before mesh samples.
+// `c` is double-buffered by bounce parity (k_shade(b+1) reads bounce b's while writing its own).
 struct ShadowQueue {
-    float4* o;   // origin xyz | w = tmax
-    float4* d;   // direction xyz | w = target bits: (next-state index << 1) | which (0 env, 1 mesh)
+    float4* o;   // origin xyz | w = tmax (< 0: unused entry — the sample had pdf 0)
+    float4* d;   // direction xyz
+    float4* c;   // contribution rgb (zeroed by k_trace_shadow when the ray is occluded)
 };
 
 // Queue counters of ONE bounce of a batch.  A batch owns an array of them indexed by bounce, zeroed when it starts, so
@@ -122,7 +129,8 @@ struct alignas(8) BounceCounters {
                                          // (adjacent: ONE 64-bit atomic per workgroup appends to both)
     uint32_t zombies;                    // of n_paths: entries that only wait to be finalised (no ray)
     uint32_t head_closest, head_shadow;  // dequeue heads of k_trace_closest(b) and k_trace_shadow(b - 1)
-    uint32_t pad[3];
+    uint32_t n_shadow_traced;            // of n_shadow_in: entries that held a ray (a light sample with pdf 0 leaves its entry unused), counted by k_trace_shadow
+    uint32_t pad[2];
 };
 static_assert(sizeof(BounceCounters) == 32, "BounceCounters must be 32 bytes");
 struct Totals { unsigned long long closest_rays, shadow_rays, samples, pad; };   // since the last MsneResetStats

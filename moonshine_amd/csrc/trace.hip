@@ -303,14 +303,15 @@ __device__ __forceinline__ void order_table_init(uint8_t* lut) {
 // `store(i, lane)` receives the finished lane.
 template <bool ANY_HIT, bool STATS, class Load, class Store>
 __device__ __forceinline__ void trace_wave_loop(const SceneView& sc, uint32_t n, uint32_t* head, uint32_t* lds_stack, const uint8_t* lut, uint32_t* spill, uint32_t* overflow,
-                                                uint32_t refill /* idle lanes of 64 that trigger a refill from the ray queue */, Load load, Store store, unsigned long long& nv, unsigned long long& nt, unsigned long long* prof) {
+                                                uint32_t refill /* idle lanes of 64 that trigger a refill from the ray queue */, Load load, Store store, unsigned long long& nv, unsigned long long& nt, unsigned long long* prof,
+                                                uint32_t* rays_traced = nullptr /* += queue entries that held a ray */) {
     const uint32_t lane = threadIdx.x & 63u;
     const unsigned long long lt = lane == 0 ? 0ull : (~0ull >> (64 - lane));
     const uint32_t gtid = blockIdx.x * TRACE_BLOCK + threadIdx.x;
     StackRef S{ lds_stack, spill + gtid, gridDim.x * TRACE_BLOCK, overflow };
     WaveQueue wq(n, head);
     Lane L; L.sp = 0; L.g1 = 0; L.ta1 = 0; L.tb1 = 0;
-    bool active = false; uint32_t my = 0;
+    bool active = false; uint32_t my = 0, n_rays = 0;
     // STATS builds: wave-cycle profile of the loop sections (s_memtime), accumulated per wave
     unsigned long long cyc[8] = { 0, 0, 0, 0, 0, 0, 0, 0 }, tprev = 0;
     auto lap = [&](int k) { if (STATS) { const unsigned long long t = __builtin_readcyclecounter(); cyc[k] += t - tprev; tprev = t; } };
@@ -345,7 +346,7 @@ __device__ __forceinline__ void trace_wave_loop(const SceneView& sc, uint32_t n,
             if (!active && r < got) {
                 my = base + r;
                 f3 o, d; float tmax;
-                if (load(my, o, d, tmax)) { active = lane_begin(L, sc, o, d, tmax); if (!active) store(my, L); }
+                if (load(my, o, d, tmax)) { n_rays++; active = lane_begin(L, sc, o, d, tmax); if (!active) store(my, L); }
                 else { L.best.inst = MAX_UINT; L.best.tri = 0; L.best.u = 0.0f; L.best.v = 0.0f; L.best.t = 0.0f; store(my, L); }
             }
         }
@@ -373,6 +374,10 @@ __device__ __forceinline__ void trace_wave_loop(const SceneView& sc, uint32_t n,
         if (STATS) cyc[5] += __popcll(__ballot(active));   // active lanes at the end of the iteration
     }
     if (STATS && (threadIdx.x & 63u) == 0) for (int k = 0; k < 8; k++) atomicAdd(&prof[k], cyc[k]);
+    if (rays_traced) {   // one atomic per wave
+        for (int o = 32; o >= 1; o >>= 1) n_rays += __shfl_xor(n_rays, o);
+        if ((threadIdx.x & 63u) == 0 && n_rays) atomicAdd(rays_traced, n_rays);
+    }
 }
 
 #define TRACE_LDS_DECL \
@@ -401,7 +406,7 @@ __global__ __launch_bounds__(TRACE_BLOCK, TRACE_WPS) void k_trace_closest(SceneV
 }
 
 template <bool STATS>
-__global__ __launch_bounds__(TRACE_BLOCK, TRACE_WPS) void k_trace_shadow(SceneView sc, ShadowQueue q, PathState next, BounceCounters* cnt,
+__global__ __launch_bounds__(TRACE_BLOCK, TRACE_WPS) void k_trace_shadow(SceneView sc, ShadowQueue q, BounceCounters* cnt,
                                                                uint32_t* spill, uint32_t* overflow, unsigned long long* stat_out, uint32_t refill) {
     TRACE_LDS_DECL;
     const uint32_t n = cnt->n_shadow_in;
@@ -409,16 +414,14 @@ __global__ __launch_bounds__(TRACE_BLOCK, TRACE_WPS) void k_trace_shadow(SceneVi
     trace_wave_loop<true, STATS>(sc, n, &cnt->head_shadow, lds_stack, lds_lut, spill, overflow, refill,
         [&](uint32_t i, f3& o, f3& d, float& tmax) -> bool {
             const float4 qo = q.o[i], qd = q.d[i];
+            if (qo.w < 0.0f) return false;   // unused entry
             o = F3(qo.x, qo.y, qo.z); d = F3(qd.x, qd.y, qd.z); tmax = qo.w;
             return true;
         },
         [&](uint32_t i, const Lane& L) {
-            if (L.best.inst != MAX_UINT) {   // ShadowIntersection::hit → lightSample.pdf = 0 (light.hlsl:75-77,154-156): the pending contribution vanishes
-                const uint32_t tg = f2u(q.d[i].w), j = tg >> 1;
-                if (tg & 1u) { next.p1x[j] = 0.0f; next.p1y[j] = 0.0f; next.p1z[j] = 0.0f; }
-                else { next.p0x[j] = 0.0f; next.p0y[j] = 0.0f; next.p0z[j] = 0.0f; }
-            }
-        }, nv, nt, stat_out + 12);
+            // ShadowIntersection::hit → lightSample.pdf = 0 (light.hlsl:75-77,154-156): the sample's contribution vanishes
+            if (L.best.inst != MAX_UINT) q.c[i] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        }, nv, nt, stat_out + 12, &cnt->n_shadow_traced);
     if (STATS) { atomicAdd(&stat_out[2], nv); atomicAdd(&stat_out[3], nt); }
 }
 
@@ -450,10 +453,10 @@ void launch_trace_closest(hipStream_t s, int grid, bool stats, const SceneView& 
     if (stats) hipLaunchKernelGGL(k_trace_closest<true>, dim3(grid), dim3(TRACE_BLOCK), 0, s, sc, st, hits, cnt, spill, overflow, stat_out, refill);
     else hipLaunchKernelGGL(k_trace_closest<false>, dim3(grid), dim3(TRACE_BLOCK), 0, s, sc, st, hits, cnt, spill, overflow, stat_out, refill);
 }
-void launch_trace_shadow(hipStream_t s, int grid, bool stats, const SceneView& sc, const ShadowQueue& q, const PathState& next, BounceCounters* cnt,
+void launch_trace_shadow(hipStream_t s, int grid, bool stats, const SceneView& sc, const ShadowQueue& q, BounceCounters* cnt,
                          uint32_t* spill, uint32_t* overflow, unsigned long long* stat_out, uint32_t refill) {
-    if (stats) hipLaunchKernelGGL(k_trace_shadow<true>, dim3(grid), dim3(TRACE_BLOCK), 0, s, sc, q, next, cnt, spill, overflow, stat_out, refill);
-    else hipLaunchKernelGGL(k_trace_shadow<false>, dim3(grid), dim3(TRACE_BLOCK), 0, s, sc, q, next, cnt, spill, overflow, stat_out, refill);
+    if (stats) hipLaunchKernelGGL(k_trace_shadow<true>, dim3(grid), dim3(TRACE_BLOCK), 0, s, sc, q, cnt, spill, overflow, stat_out, refill);
+    else hipLaunchKernelGGL(k_trace_shadow<false>, dim3(grid), dim3(TRACE_BLOCK), 0, s, sc, q, cnt, spill, overflow, stat_out, refill);
 }
 void launch_trace_probe(hipStream_t s, int grid, const SceneView& sc, const float* rays, uint32_t n, int any_hit, uint32_t* head, uint32_t* out_ids, float* out_tuv,
                         uint32_t* spill, uint32_t* overflow, uint32_t refill) {
