@@ -262,7 +262,7 @@ struct WaveQueue {
     bool exhausted;
     __device__ WaveQueue(uint32_t n_, uint32_t* head_) : n(n_), head(head_), exhausted(false) {
         const uint32_t nwaves = gridDim.x * (TRACE_BLOCK / 64);
-        uint32_t c = (n / (nwaves * 4u) + 63u) & ~63u;
+        uint32_t c = (n / (nwaves * 4u) + 63u) & ~63u;   // (16-ray chunks for short queues were measured: more, emptier waves — slower)
         chunk = c < 64u ? 64u : (c > 512u ? 512u : c);
         nwaves_chunk = nwaves * chunk;
         const uint32_t wave = blockIdx.x * (TRACE_BLOCK / 64) + (threadIdx.x >> 6);
