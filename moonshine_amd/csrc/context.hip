@@ -71,19 +71,15 @@ struct SensorH {
 };
 
 struct PathBuffers {
-    DevBuf<float> f;      // ro, rd (float4 each) + 7 float arrays
-    DevBuf<uint32_t> u;   // rng, slot, pq
+    DevBuf<float> f;      // ro, rd, tp, lr (float4 each) + sq (uint2)
     size_t cap = 0;
     PathState view() const {
         PathState s; float* b = f.p; size_t c = cap;
-        s.ro = reinterpret_cast<float4*>(b); s.rd = reinterpret_cast<float4*>(b + 4 * c);
-        b += 8 * c;
-        s.tx = b + 0 * c; s.ty = b + 1 * c; s.tz = b + 2 * c; s.lx = b + 3 * c; s.ly = b + 4 * c; s.lz = b + 5 * c;
-        s.last_pdf = b + 6 * c;
-        s.rng = u.p; s.slot = u.p + c; s.pq = u.p + 2 * c;
+        s.ro = reinterpret_cast<float4*>(b); s.rd = reinterpret_cast<float4*>(b + 4 * c); s.tp = reinterpret_cast<float4*>(b + 8 * c);
+        s.lr = reinterpret_cast<float4*>(b + 12 * c); s.sq = reinterpret_cast<uint2*>(b + 16 * c);
         return s;
     }
-    bool ensure(size_t c) { if (c <= cap) return true; cap = 0; if (!f.alloc(15 * c) || !u.alloc(3 * c)) return false; cap = c; return true; }
+    bool ensure(size_t c) { if (c <= cap) return true; cap = 0; if (!f.alloc(18 * c)) return false; cap = c; return true; }
 };
 
 }  // namespace

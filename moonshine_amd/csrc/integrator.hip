@@ -43,7 +43,7 @@ __global__ __launch_bounds__(SHADE_BLOCK) void k_raygen(ShardView sh, CameraCons
     for (uint32_t slot = blockIdx.x * SHADE_BLOCK + threadIdx.x; slot < total; slot += gridDim.x * SHADE_BLOCK) {
         uint32_t x = 0, y = 0;
         const uint32_t i = slot;
-        if (!shard_pixel(sh, slot % sh.pixels, x, y)) { st.ro[i] = make_float4(0.0f, 0.0f, 0.0f, u2f(PATH_FLAG_ZOMBIE | PATH_FLAG_MASKED)); st.slot[i] = slot; continue; }
+        if (!shard_pixel(sh, slot % sh.pixels, x, y)) { st.ro[i] = make_float4(0.0f, 0.0f, 0.0f, u2f(PATH_FLAG_ZOMBIE | PATH_FLAG_MASKED)); continue; }
         const uint32_t s_local = slot / sh.pixels;
         uint32_t rng = rng_seed(sample_base + s_local, x, y);                       // main.hlsl:85
         f2 r1; r1.x = rng_float(rng); r1.y = rng_float(rng);
@@ -55,9 +55,7 @@ __global__ __launch_bounds__(SHADE_BLOCK) void k_raygen(ShardView sh, CameraCons
         f3 O, D;
         camera_generate_ray(cam, uv, r2, O, D);
         st.ro[i] = make_float4(O.x, O.y, O.z, u2f(0u)); st.rd[i] = make_float4(D.x, D.y, D.z, 0.0f);
-        st.tx[i] = 1.0f; st.ty[i] = 1.0f; st.tz[i] = 1.0f;
-        st.lx[i] = 0.0f; st.ly[i] = 0.0f; st.lz[i] = 0.0f;
-        st.last_pdf[i] = 0.0f; st.rng[i] = rng; st.slot[i] = slot;
+        st.tp[i] = make_float4(1.0f, 1.0f, 1.0f, 0.0f); st.lr[i] = make_float4(0.0f, 0.0f, 0.0f, u2f(rng)); st.sq[i] = make_uint2(slot, 0u);
     }
 }
 
@@ -181,13 +179,13 @@ __global__ __launch_bounds__(SHADE_BLOCK, 3) void k_shade(SceneView sc, Pipeline
         if (live) {
             const float4 ro4 = cur.ro[i];
             { const float4 rd4 = cur.rd[i]; rayO = F3(ro4.x, ro4.y, ro4.z); rayD = F3(rd4.x, rd4.y, rd4.z); }
-            throughput = F3(cur.tx[i], cur.ty[i], cur.tz[i]);
-            L = F3(cur.lx[i], cur.ly[i], cur.lz[i]);
-            lastPdf = cur.last_pdf[i]; rng = cur.rng[i]; slot = cur.slot[i]; flags = f2u(ro4.w);
+            const float4 tp4 = cur.tp[i], lr4 = cur.lr[i]; const uint2 sq2 = cur.sq[i];
+            throughput = F3(tp4.x, tp4.y, tp4.z); L = F3(lr4.x, lr4.y, lr4.z);
+            lastPdf = tp4.w; rng = f2u(lr4.w); slot = sq2.x; flags = f2u(ro4.w);
             // light samples of the previous bounce, in the reference's order (env samples, then mesh samples): each was stored
             // unoccluded next to its shadow ray and zeroed by k_trace_shadow if the ray was blocked
             if (flags & PATH_FLAG_NEE) {
-                const uint32_t pq = cur.pq[i];
+                const uint32_t pq = sq2.y;
                 const uint32_t ps = (flags >> PATH_STRIDE_SHIFT) & 0x1ffu;
                 for (uint32_t k = 0; k < n_nee; k++) { const float4 c = c_prev[pq + k * ps]; L = add(L, F3(c.x, c.y, c.z)); }
             }
@@ -332,7 +330,7 @@ __global__ __launch_bounds__(SHADE_BLOCK, 3) void k_shade(SceneView sc, Pipeline
             if (sample.pdf == 0.0f) {
                 // the path ends here; with light samples in flight it is finalised one pass later (after their shadow rays)
                 atomicAdd(&cnt[1].zombies, 1u);
-                if (valid) { nxt.ro[j] = make_float4(0.0f, 0.0f, 0.0f, u2f(PATH_FLAG_ZOMBIE | PATH_FLAG_NEE | (stride << PATH_STRIDE_SHIFT))); nxt.lx[j] = L.x; nxt.ly[j] = L.y; nxt.lz[j] = L.z; nxt.pq[j] = q; nxt.slot[j] = slot; }
+                if (valid) { nxt.ro[j] = make_float4(0.0f, 0.0f, 0.0f, u2f(PATH_FLAG_ZOMBIE | PATH_FLAG_NEE | (stride << PATH_STRIDE_SHIFT))); nxt.lr[j] = make_float4(L.x, L.y, L.z, 0.0f); nxt.sq[j] = make_uint2(slot, q); }
                 else { nxt.ro[j] = make_float4(0.0f, 0.0f, 0.0f, u2f(PATH_FLAG_ZOMBIE | PATH_FLAG_DEAD)); lbuf[slot] = make_float4(L.x, L.y, L.z, 0.0f); }
             } else {
                 const f3 nd = frame_frame_to_world(shadingFrame, sample.dirFs);
@@ -342,9 +340,7 @@ __global__ __launch_bounds__(SHADE_BLOCK, 3) void k_shade(SceneView sc, Pipeline
                 const f3 tp = mul(throughput, F3(f.x * ac / sample.pdf, f.y * ac / sample.pdf, f.z * ac / sample.pdf));
                 const uint32_t nf = ((bounceCount + 1u) & 0xFFFFu) | (delta ? PATH_FLAG_DELTA : 0u) | (nee ? (PATH_FLAG_NEE | (stride << PATH_STRIDE_SHIFT)) : 0u);
                 nxt.ro[j] = make_float4(no.x, no.y, no.z, u2f(nf)); nxt.rd[j] = make_float4(nd.x, nd.y, nd.z, 0.0f);
-                nxt.tx[j] = tp.x; nxt.ty[j] = tp.y; nxt.tz[j] = tp.z;
-                nxt.lx[j] = L.x; nxt.ly[j] = L.y; nxt.lz[j] = L.z;
-                nxt.last_pdf[j] = sample.pdf; nxt.rng[j] = rng; nxt.slot[j] = slot; nxt.pq[j] = q;
+                nxt.tp[j] = make_float4(tp.x, tp.y, tp.z, sample.pdf); nxt.lr[j] = make_float4(L.x, L.y, L.z, u2f(rng)); nxt.sq[j] = make_uint2(slot, q);
             }
         }
     }

@@ -87,18 +87,16 @@ struct SceneView {
 constexpr uint32_t WORLD_INSTANCE = 0xFFFFFFFEu;
 constexpr uint32_t INST_FLAG_VISIBLE = 1u, INST_FLAG_IDENTITY = 2u, INST_FLAG_WORLD = 4u;
 
-// ---- wavefront state (SoA, one slot per in-flight path; two sets ping-pong between bounces) ----
+// ---- wavefront state (one slot per in-flight path; two sets ping-pong between bounces).  Arrays of 16-B records: a wave
+// moves each with one coalesced instruction (five loads per path in k_shade instead of twelve 4-B ones) ----
 struct PathState {
-    float4* ro;                          // ray origin xyz | w = flags (bit pattern): the trace kernels fetch a ray with 2 x 16-B loads
-    float4* rd;                          // ray direction xyz | w unused
-    float* tx; float* ty; float* tz;     // throughput
-    float* lx; float* ly; float* lz;     // accumulated radiance
-    float* last_pdf;
-    uint32_t* rng;
-    uint32_t* slot;                      // sample slot: s_local * pixels + pixel_local
-    uint32_t* pq;                        // first of the path's light-sample entries in the shadow queue (PATH_FLAG_NEE)
+    float4* ro;     // ray origin xyz | w = flags (bit pattern): the trace kernels fetch a ray with 2 x 16-B loads
+    float4* rd;     // ray direction xyz | w unused
+    float4* tp;     // throughput rgb | w = pdf of the last BSDF sample
+    float4* lr;     // accumulated radiance rgb | w = rng state (bit pattern)
+    uint2* sq;      // x = sample slot (s_local * pixels + pixel_local), y = first of the path's light-sample entries in the shadow queue
     // flags (in ro.w): bits 0..15 bounce count, bit 16 last material delta, bit 17 no ray (finalise only), bit 18 masked,
-    // bit 19 light samples pending (env_samples + mesh_samples entries from pq, PATH_STRIDE apart), bit 20 dead
+    // bit 19 light samples pending (env_samples + mesh_samples entries from sq.y, PATH_STRIDE apart), bit 20 dead
 };
 constexpr uint32_t PATH_FLAG_DELTA = 1u << 16;
 constexpr uint32_t PATH_FLAG_ZOMBIE = 1u << 17;   // no ray to trace: the entry only waits for k_shade (to add its light samples and finalise) or is dead / masked
