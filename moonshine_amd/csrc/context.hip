@@ -893,6 +893,7 @@ int MsneTraceRays(HdMoonshine* c, const float* rays, uint32_t n, int any_hit, ui
     DevBuf<float> dr; DevBuf<uint32_t> di; DevBuf<float> dt;
     if (!dr.alloc(7 * (size_t)n) || !di.alloc(4 * (size_t)n) || !dt.alloc(3 * (size_t)n)) { c->fail("out of device memory (probe)"); return -1; }
     if (hipMemcpyAsync(dr.p, rays, 28 * (size_t)n, hipMemcpyHostToDevice, c->stream) != hipSuccess) return -1;
+    if (hipMemsetAsync(di.p, 0, 16 * (size_t)n, c->stream) != hipSuccess || hipMemsetAsync(dt.p, 0, 12 * (size_t)n, c->stream) != hipSuccess) return -1;
     if (hipMemsetAsync(&c->pipes[0].counters.p->head_closest, 0, 4, c->stream) != hipSuccess) return -1;
     launch_trace_probe(c->stream, c->trace_grid, c->scene_view(), dr.p, n, any_hit, &c->pipes[0].counters.p->head_closest, di.p, dt.p, c->pipes[0].spill.p, c->d_overflow.p, c->refill);
     if (hipMemcpyAsync(out_ids, di.p, 16 * (size_t)n, hipMemcpyDeviceToHost, c->stream) != hipSuccess) return -1;

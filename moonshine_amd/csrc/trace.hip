@@ -93,7 +93,7 @@ struct Lane {
     uint32_t tb0, tb1; // a second pending triangle group: node traversal runs ahead of the triangle tests by up to two nodes
     uint32_t octbase;  // ray octant << 8 (row of the order table)
     uint32_t cur_inst;
-    int sp;
+    int sp, sb;        // stack entries live in rows [sb, sp): sb moves up when the bottom entry is handed to an idle lane (any-hit tails)
     bool in_blas;
 };
 
@@ -123,7 +123,7 @@ __device__ __forceinline__ void lane_set_space(Lane& L, f3 o, f3 d) {
 __device__ __forceinline__ bool lane_begin(Lane& L, const SceneView& sc, f3 o, f3 d, float tmax) {
     lane_set_space(L, o, d);
     L.best.inst = MAX_UINT; L.best.tri = 0; L.best.t = tmax; L.best.u = 0.0f; L.best.v = 0.0f;
-    L.sp = 0; L.in_blas = sc.root_in_blas != 0u; L.cur_inst = WORLD_INSTANCE;   // only used when the root IS the world BLAS
+    L.sp = 0; L.sb = 0; L.in_blas = sc.root_in_blas != 0u; L.cur_inst = WORLD_INSTANCE;   // only used when the root IS the world BLAS
     L.g0 = sc.tlas_root; L.g1 = sc.tlas_root != MAX_UINT ? (GRP_NODE | 0x0101u) : 0u;   // a group of one: the root itself
     L.ta0 = 0; L.ta1 = 0; L.tb0 = 0; L.tb1 = 0;
     return sc.tlas_root != MAX_UINT;
@@ -287,6 +287,17 @@ struct WaveQueue {
     }
 };
 
+// lane index of the r-th set bit of a 64-lane mask (r < popcount)
+__device__ __forceinline__ uint32_t nth_set_bit(unsigned long long mask, uint32_t r) {
+    uint32_t m = (uint32_t)mask, base = 0, c = (uint32_t)__popc(m);
+    if (r >= c) { r -= c; m = (uint32_t)(mask >> 32); base = 32; }
+    c = (uint32_t)__popc(m & 0xffffu); if (r >= c) { r -= c; m >>= 16; base += 16; } m &= 0xffffu;
+    c = (uint32_t)__popc(m & 0xffu);   if (r >= c) { r -= c; m >>= 8;  base += 8; }  m &= 0xffu;
+    c = (uint32_t)__popc(m & 0xfu);    if (r >= c) { r -= c; m >>= 4;  base += 4; }  m &= 0xfu;
+    c = (uint32_t)__popc(m & 0x3u);    if (r >= c) { r -= c; m >>= 2;  base += 2; }  m &= 0x3u;
+    return base + ((r >= (m & 1u)) ? 1u : 0u);
+}
+
 // visit-order table: lut[octant << 8 | hit bits] = the hit slot s with the smallest (s ^ octant) — slot == octant is the
 // child the ray enters first, slot == ~octant the one it reaches last (the builder places children in octant order)
 __device__ __forceinline__ void order_table_init(uint8_t* lut) {
@@ -310,7 +321,7 @@ __device__ __forceinline__ void trace_wave_loop(const SceneView& sc, uint32_t n,
     const uint32_t gtid = blockIdx.x * TRACE_BLOCK + threadIdx.x;
     StackRef S{ lds_stack, spill + gtid, gridDim.x * TRACE_BLOCK, overflow };
     WaveQueue wq(n, head);
-    Lane L; L.sp = 0; L.g1 = 0; L.ta1 = 0; L.tb1 = 0;
+    Lane L; L.sp = 0; L.sb = 0; L.g1 = 0; L.ta1 = 0; L.tb1 = 0;
     bool active = false; uint32_t my = 0, n_rays = 0;
     // STATS builds: wave-cycle profile of the loop sections (s_memtime), accumulated per wave
     unsigned long long cyc[8] = { 0, 0, 0, 0, 0, 0, 0, 0 }, tprev = 0;
@@ -321,7 +332,7 @@ __device__ __forceinline__ void trace_wave_loop(const SceneView& sc, uint32_t n,
         // (a) lanes without a child group pop one; a lane with nothing left at all is finished
         if (active && !(L.g1 & 0xffu)) {
             const bool has_t = (L.ta1 & 0xffu) != 0u;
-            if (L.sp == 0) { if (!has_t) { store(my, L); active = false; } }
+            if (L.sp == L.sb) { if (!has_t) { store(my, L); active = false; } }
             else {
                 lane_pop(L, S);
                 if (__builtin_expect((L.g1 & GRP_KIND_MASK) == GRP_SENTINEL, 0)) {   // leaving an instance: back to the world-space ray
@@ -329,7 +340,7 @@ __device__ __forceinline__ void trace_wave_loop(const SceneView& sc, uint32_t n,
                     else {
                         if (L.g0 & 1u) { f3 o, d; float tmax; (void)load(my, o, d, tmax); lane_set_space(L, o, d); }
                         L.in_blas = false; L.g1 = 0u;
-                        if (L.sp == 0) { store(my, L); active = false; }
+                        if (L.sp == L.sb) { store(my, L); active = false; }
                         else lane_pop(L, S);   // what lies under a sentinel is a TLAS-level group (two levels only), never another sentinel
                     }
                 }
@@ -350,6 +361,43 @@ __device__ __forceinline__ void trace_wave_loop(const SceneView& sc, uint32_t n,
                 else { L.best.inst = MAX_UINT; L.best.tri = 0; L.best.u = 0.0f; L.best.v = 0.0f; L.best.t = 0.0f; store(my, L); }
             }
         }
+        // (b') any-hit tails: a launch ends with a few very long rays (S1 shadow rays: mean 16 iterations, max 330) run by a
+        // few lanes at memory latency.  Once the queue is empty, a busy lane hands the BOTTOM entry of its stack — the
+        // largest unvisited subtree — to an idle lane of its wave, which searches it as an independent any-hit ray for the
+        // same queue entry: occlusion is an OR, so the pieces never have to be merged.
+        if (ANY_HIT && wq.exhausted) {
+            const unsigned long long busy = __ballot(active);
+            const bool give = active && L.sp > L.sb && (sc.root_in_blas != 0u || !L.in_blas);   // only entries that live in world space
+            const unsigned long long donors = __ballot(give), idle = ~busy;
+            const uint32_t nthief = (uint32_t)__popcll(idle), ndon = (uint32_t)__popcll(donors);
+            if (ndon != 0u && nthief >= 8u) {
+                const uint32_t npair = nthief < ndon ? nthief : ndon;
+                const uint32_t rth = (uint32_t)__popcll(idle & lt), rdn = (uint32_t)__popcll(donors & lt);
+                const uint32_t dl = nth_set_bit(donors, rth < npair ? rth : 0u);   // the donor this lane would take from
+                const float ox = __shfl(L.o.x, dl), oy = __shfl(L.o.y, dl), oz = __shfl(L.o.z, dl);
+                const float ix = __shfl(L.id.x, dl), iy = __shfl(L.id.y, dl), iz = __shfl(L.id.z, dl);
+                const int kx = __shfl(L.rk.kx, dl), ky = __shfl(L.rk.ky, dl), kz = __shfl(L.rk.kz, dl);
+                const float sx = __shfl(L.rk.Sx, dl), sy = __shfl(L.rk.Sy, dl), sz = __shfl(L.rk.Sz, dl);
+                const float bt = __shfl(L.best.t, dl);
+                const uint32_t ob = __shfl(L.octbase, dl), ci = __shfl(L.cur_inst, dl), dmy = __shfl(my, dl);
+                const int dib = __shfl((int)L.in_blas, dl), dsb = __shfl(L.sb, dl);
+                if (!active && rth < npair) {
+                    const uint32_t col = threadIdx.x - lane + dl;   // the donor's stack column
+                    if (dsb < STACK_LDS) { L.g0 = S.lds[(2 * dsb) * TRACE_BLOCK + col]; L.g1 = S.lds[(2 * dsb + 1) * TRACE_BLOCK + col]; }
+                    else {
+                        const uint32_t* dsp = S.spill - lane + dl;
+                        L.g0 = dsp[(size_t)(2 * (dsb - STACK_LDS)) * S.spill_stride]; L.g1 = dsp[(size_t)(2 * (dsb - STACK_LDS) + 1) * S.spill_stride];
+                    }
+                    L.o = F3(ox, oy, oz); L.id = F3(ix, iy, iz);
+                    L.rk.kx = kx; L.rk.ky = ky; L.rk.kz = kz; L.rk.Sx = sx; L.rk.Sy = sy; L.rk.Sz = sz;
+                    L.best.inst = MAX_UINT; L.best.tri = 0; L.best.t = bt; L.best.u = 0.0f; L.best.v = 0.0f;
+                    L.octbase = ob; L.cur_inst = ci; L.in_blas = dib != 0; my = dmy;
+                    L.sp = 0; L.sb = 0; L.ta1 = 0; L.tb1 = 0;
+                    active = true;
+                }
+                if (give && rdn < npair) L.sb++;
+            }
+        }
         lap(1);
         if (!__ballot(active)) { if (wq.exhausted) break; continue; }
         // (c) both bodies run whenever any lane has work for them (vote thresholds were swept: within noise).  Node traversal
@@ -368,7 +416,7 @@ __device__ __forceinline__ void trace_wave_loop(const SceneView& sc, uint32_t n,
         lap(3);
         if (STATS && do_n) cyc[6] += __popcll(__ballot(want_n));   // node-lane steps
         if (do_t && want_t) {
-            if (step_tri<ANY_HIT, STATS>(L, sc, nt)) { L.sp = 0; L.g1 = 0; L.ta1 = 0; L.tb1 = 0; store(my, L); active = false; }
+            if (step_tri<ANY_HIT, STATS>(L, sc, nt)) { L.sp = 0; L.sb = 0; L.g1 = 0; L.ta1 = 0; L.tb1 = 0; store(my, L); active = false; }
         }
         lap(4);
         if (STATS) cyc[5] += __popcll(__ballot(active));   // active lanes at the end of the iteration
@@ -440,8 +488,12 @@ __global__ __launch_bounds__(TRACE_BLOCK, TRACE_WPS) void k_trace_probe(SceneVie
         },
         [&](uint32_t i, const Lane& L) {
             const bool hit = L.best.inst != MAX_UINT;
+            if (ANY_HIT) {   // the pieces of a shared any-hit ray report separately: only occlusion is written (the buffers start zeroed)
+                if (hit) { out_ids[4 * i] = 1u; out_ids[4 * i + 1] = L.best.inst; }
+                return;
+            }
             uint32_t geo = 0, prim = 0;
-            if (hit && !ANY_HIT) { geo = sc.tris[L.best.tri].geo; prim = sc.tris[L.best.tri].prim; }
+            if (hit) { geo = sc.tris[L.best.tri].geo; prim = sc.tris[L.best.tri].prim; }
             out_ids[4 * i] = hit ? 1u : 0u; out_ids[4 * i + 1] = L.best.inst; out_ids[4 * i + 2] = geo; out_ids[4 * i + 3] = prim;
             out_tuv[3 * i] = L.best.t; out_tuv[3 * i + 1] = L.best.u; out_tuv[3 * i + 2] = L.best.v;
         }, nv, nt, nullptr);
