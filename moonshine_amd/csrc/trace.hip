@@ -93,7 +93,8 @@ struct Lane {
     uint32_t tb0, tb1; // a second pending triangle group: node traversal runs ahead of the triangle tests by up to two nodes
     uint32_t octbase;  // ray octant << 8 (row of the order table)
     uint32_t cur_inst;
-    int sp, sb;        // stack entries live in rows [sb, sp): sb moves up when the bottom entry is handed to an idle lane (any-hit tails)
+    int sp, sb;        // stack entries live in rows [sb, sp): sb moves up when the bottom entry is handed to an idle lane (launch tails)
+    uint32_t own;      // closest-hit tails: bits 0..5 = the lane that owns this ray (itself unless this lane searches a handed-over piece), bits 8.. = pieces still out
     bool in_blas;
 };
 
@@ -321,7 +322,7 @@ __device__ __forceinline__ void trace_wave_loop(const SceneView& sc, uint32_t n,
     const uint32_t gtid = blockIdx.x * TRACE_BLOCK + threadIdx.x;
     StackRef S{ lds_stack, spill + gtid, gridDim.x * TRACE_BLOCK, overflow };
     WaveQueue wq(n, head);
-    Lane L; L.sp = 0; L.sb = 0; L.g1 = 0; L.ta1 = 0; L.tb1 = 0;
+    Lane L; L.sp = 0; L.sb = 0; L.g1 = 0; L.ta1 = 0; L.tb1 = 0; L.own = lane;
     bool active = false; uint32_t my = 0, n_rays = 0;
     // STATS builds: wave-cycle profile of the loop sections (s_memtime), accumulated per wave
     unsigned long long cyc[8] = { 0, 0, 0, 0, 0, 0, 0, 0 }, tprev = 0;
@@ -330,21 +331,46 @@ __device__ __forceinline__ void trace_wave_loop(const SceneView& sc, uint32_t n,
     for (;;) {
         if (STATS) cyc[7] += 1;   // iterations
         // (a) lanes without a child group pop one; a lane with nothing left at all is finished
+        bool piece_done = false;   // closest-hit tails: this lane finished a handed-over piece of another lane's ray
         if (active && !(L.g1 & 0xffu)) {
             const bool has_t = (L.ta1 & 0xffu) != 0u;
-            if (L.sp == L.sb) { if (!has_t) { store(my, L); active = false; } }
-            else {
+            if (L.sp == L.sb) {
+                if (!has_t) {
+                    if (ANY_HIT || L.own == lane) { store(my, L); active = false; }   // (an owner with pieces out — own >> 8 != 0 — waits for them)
+                    else if ((L.own & 63u) != lane) piece_done = true;
+                }
+            } else {
                 lane_pop(L, S);
                 if (__builtin_expect((L.g1 & GRP_KIND_MASK) == GRP_SENTINEL, 0)) {   // leaving an instance: back to the world-space ray
                     if (has_t) { L.sp++; L.g1 = 0u; }   // ... but only once the triangles queued in instance space are done: un-pop
                     else {
                         if (L.g0 & 1u) { f3 o, d; float tmax; (void)load(my, o, d, tmax); lane_set_space(L, o, d); }
                         L.in_blas = false; L.g1 = 0u;
-                        if (L.sp == L.sb) { store(my, L); active = false; }
+                        if (L.sp == L.sb) { if (ANY_HIT || L.own == lane) { store(my, L); active = false; } }   // (sentinels only exist on owners' own stacks below sb... see (b'))
                         else lane_pop(L, S);   // what lies under a sentinel is a TLAS-level group (two levels only), never another sentinel
                     }
                 }
             }
+        }
+        if (!ANY_HIT) {   // finished pieces report to the lane that owns the ray: its best hit absorbs theirs (all in one wave: no atomics)
+            unsigned long long fm = __ballot(piece_done);
+            while (fm) {
+                const int f = __builtin_ctzll(fm); fm &= fm - 1ull;
+                const uint32_t o_ = (uint32_t)__builtin_amdgcn_readlane((int)L.own, f) & 63u;
+                const uint32_t c_inst = (uint32_t)__builtin_amdgcn_readlane((int)L.best.inst, f), c_tri = (uint32_t)__builtin_amdgcn_readlane((int)L.best.tri, f);
+                const float c_t = u2f((uint32_t)__builtin_amdgcn_readlane((int)f2u(L.best.t), f)), c_u = u2f((uint32_t)__builtin_amdgcn_readlane((int)f2u(L.best.u), f)), c_v = u2f((uint32_t)__builtin_amdgcn_readlane((int)f2u(L.best.v), f));
+                if (lane == o_) {
+                    L.own -= 1u << 8;
+                    bool closer = c_inst != MAX_UINT && c_t < L.best.t;
+                    if (c_inst != MAX_UINT && c_t == L.best.t && L.best.inst != MAX_UINT) {   // exact tie: smallest (instance, geometry, primitive) wins
+                        const TriRec* a = sc.tris + c_tri; const TriRec* b = sc.tris + L.best.tri;
+                        closer = c_inst < L.best.inst || (c_inst == L.best.inst && (a->geo < b->geo || (a->geo == b->geo && a->prim < b->prim)));
+                    }
+                    L.best.t = closer ? c_t : L.best.t; L.best.u = closer ? c_u : L.best.u; L.best.v = closer ? c_v : L.best.v;
+                    L.best.inst = closer ? c_inst : L.best.inst; L.best.tri = closer ? c_tri : L.best.tri;
+                }
+            }
+            if (piece_done) active = false;
         }
         lap(0);
         // (b) idle lanes take new rays from the wave's private chunk
@@ -357,15 +383,16 @@ __device__ __forceinline__ void trace_wave_loop(const SceneView& sc, uint32_t n,
             if (!active && r < got) {
                 my = base + r;
                 f3 o, d; float tmax;
-                if (load(my, o, d, tmax)) { n_rays++; active = lane_begin(L, sc, o, d, tmax); if (!active) store(my, L); }
+                if (load(my, o, d, tmax)) { n_rays++; L.own = lane; active = lane_begin(L, sc, o, d, tmax); if (!active) store(my, L); }
                 else { L.best.inst = MAX_UINT; L.best.tri = 0; L.best.u = 0.0f; L.best.v = 0.0f; L.best.t = 0.0f; store(my, L); }
             }
         }
-        // (b') any-hit tails: a launch ends with a few very long rays (S1 shadow rays: mean 16 iterations, max 330) run by a
-        // few lanes at memory latency.  Once the queue is empty, a busy lane hands the BOTTOM entry of its stack — the
-        // largest unvisited subtree — to an idle lane of its wave, which searches it as an independent any-hit ray for the
-        // same queue entry: occlusion is an OR, so the pieces never have to be merged.
-        if (ANY_HIT && wq.exhausted) {
+        // (b') launch tails: a launch ends with a few very long rays (S1: mean 16-20 iterations, max 185 closest / 330 shadow)
+        // run by a few lanes at memory latency.  Once the queue is empty, a busy lane hands the BOTTOM entry of its stack —
+        // the largest unvisited subtree — to an idle lane of its wave, which searches it as a ray of its own for the same
+        // queue entry.  Any-hit: occlusion is an OR, the pieces never meet again.  Closest-hit: a finished piece reports
+        // to the lane that owns the ray (see (a)); the owner stores the hit when no piece is out.
+        if (wq.exhausted) {
             const unsigned long long busy = __ballot(active);
             const bool give = active && L.sp > L.sb && (sc.root_in_blas != 0u || !L.in_blas);   // only entries that live in world space
             const unsigned long long donors = __ballot(give), idle = ~busy;
@@ -381,7 +408,9 @@ __device__ __forceinline__ void trace_wave_loop(const SceneView& sc, uint32_t n,
                 const float bt = __shfl(L.best.t, dl);
                 const uint32_t ob = __shfl(L.octbase, dl), ci = __shfl(L.cur_inst, dl), dmy = __shfl(my, dl);
                 const int dib = __shfl((int)L.in_blas, dl), dsb = __shfl(L.sb, dl);
-                if (!active && rth < npair) {
+                const uint32_t downer = (uint32_t)__shfl((int)L.own, dl) & 63u;   // the donor may itself be searching a piece
+                const bool thief = !active && rth < npair;
+                if (thief) {
                     const uint32_t col = threadIdx.x - lane + dl;   // the donor's stack column
                     if (dsb < STACK_LDS) { L.g0 = S.lds[(2 * dsb) * TRACE_BLOCK + col]; L.g1 = S.lds[(2 * dsb + 1) * TRACE_BLOCK + col]; }
                     else {
@@ -392,10 +421,18 @@ __device__ __forceinline__ void trace_wave_loop(const SceneView& sc, uint32_t n,
                     L.rk.kx = kx; L.rk.ky = ky; L.rk.kz = kz; L.rk.Sx = sx; L.rk.Sy = sy; L.rk.Sz = sz;
                     L.best.inst = MAX_UINT; L.best.tri = 0; L.best.t = bt; L.best.u = 0.0f; L.best.v = 0.0f;
                     L.octbase = ob; L.cur_inst = ci; L.in_blas = dib != 0; my = dmy;
-                    L.sp = 0; L.sb = 0; L.ta1 = 0; L.tb1 = 0;
+                    L.sp = 0; L.sb = 0; L.ta1 = 0; L.tb1 = 0; L.own = downer;
                     active = true;
                 }
                 if (give && rdn < npair) L.sb++;
+                if (!ANY_HIT) {   // one more piece out for every owner that was taken from
+                    unsigned long long tm = __ballot(thief);
+                    while (tm) {
+                        const int tl = __builtin_ctzll(tm); tm &= tm - 1ull;
+                        const uint32_t o_ = (uint32_t)__builtin_amdgcn_readlane((int)L.own, tl) & 63u;
+                        if (lane == o_) L.own += 1u << 8;
+                    }
+                }
             }
         }
         lap(1);
