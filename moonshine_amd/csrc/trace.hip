@@ -256,7 +256,7 @@ __device__ __forceinline__ uint32_t step_inst(Lane& L, const SceneView& sc, cons
 // Persistent-wave dequeue.  One device-scope atomic word saturates at ~88 dequeues/us on MI355X
 // (MI355X_MICROARCH.md "dequeue"), so (1) every wave's FIRST chunk is static (wave w takes chunk w: an
 // empty or short queue costs no atomics at all), (2) later chunks come from one atomicAdd per wave on the
-// queue head, and (3) a chunk is 64..512 rays that the wave's lanes consume one by one as they go idle.
+// queue head, and (3) a chunk is 64..256 rays that the wave's lanes consume one by one as they go idle.
 struct WaveQueue {
     uint32_t n, chunk, pos, end, nwaves_chunk;
     uint32_t* head;
@@ -264,7 +264,7 @@ struct WaveQueue {
     __device__ WaveQueue(uint32_t n_, uint32_t* head_) : n(n_), head(head_), exhausted(false) {
         const uint32_t nwaves = gridDim.x * (TRACE_BLOCK / 64);
         uint32_t c = (n / (nwaves * 4u) + 63u) & ~63u;   // (16-ray chunks for short queues were measured: more, emptier waves — slower)
-        chunk = c < 64u ? 64u : (c > 512u ? 512u : c);
+        chunk = c < 64u ? 64u : (c > 256u ? 256u : c);   // 256: a launch ends when its last wave ends, one chunk (~0.2 ms) after the first
         nwaves_chunk = nwaves * chunk;
         const uint32_t wave = blockIdx.x * (TRACE_BLOCK / 64) + (threadIdx.x >> 6);
         pos = wave * chunk; end = pos + chunk;
