@@ -138,6 +138,7 @@ __global__ __launch_bounds__(64) void k_radix_scatter(const uint32_t* keys, cons
 constexpr uint32_t REF_LEAF = 0x80000000u;
 struct BinTree {
     uint32_t* left; uint32_t* right;         // child refs of internal node i (bit 31 = leaf: index into the sorted primitives)
+    uint32_t* count;                         // primitives under internal node i
     Box* box;                                // internal node boxes
 };
 
@@ -234,6 +235,7 @@ __global__ __launch_bounds__(PLOC_BLOCK) void k_ploc_merge(const uint32_t* cref,
         const uint32_t rj = cref[j]; const Box bj = cbox[j];
         for (int k = 0; k < 3; k++) { b.lo[k] = fminf(b.lo[k], bj.lo[k]); b.hi[k] = fmaxf(b.hi[k], bj.hi[k]); }
         t.left[id] = ref; t.right[id] = rj; t.box[id] = b;
+        t.count[id] = ((ref & REF_LEAF) ? 1u : t.count[ref]) + ((rj & REF_LEAF) ? 1u : t.count[rj]);
         ref = id;
     }
     oref[pos] = ref; obox[pos] = b;
@@ -259,9 +261,17 @@ __global__ void k_collapse(const CollapseWork* work, uint32_t nwork, CollapseWor
     auto ref_box = [&](uint32_t r) -> Box { return (r & REF_LEAF) ? leaf_boxes[r & ~REF_LEAF] : t.box[r]; };
     if (bin & REF_LEAF) ch[nch++] = bin;
     else { ch[nch++] = t.left[bin]; ch[nch++] = t.right[bin]; }
-    while (nch < 8) {   // open the internal child with the largest surface area until the node is full
-        int best = -1; float ba = -1.0f;
-        for (int i = 0; i < nch; i++) if (!(ch[i] & REF_LEAF)) { Box b = ref_box(ch[i]); float ar = box_area(b); if (ar > ba) { ba = ar; best = i; } }
+    // A node visit costs the same whatever the number of children (8 slots are tested), so nodes should be full: a child
+    // subtree small enough to be absorbed completely (its primitives fit the free slots) is opened first, smallest first —
+    // that removes a node for nothing; otherwise the internal child with the largest surface area is opened
+    // (without the first rule 44 % of the nodes of S1 had two children, 4.1 on average).
+    while (nch < 8) {
+        int best = -1; float ba = -1.0f; uint32_t bsz = MAX_UINT;
+        for (int i = 0; i < nch; i++) if (!(ch[i] & REF_LEAF)) {
+            const uint32_t sz = t.count[ch[i]];
+            if (sz - 1u <= (uint32_t)(8 - nch)) { if (sz < bsz) { bsz = sz; best = i; } }
+            else if (bsz == MAX_UINT) { Box b = ref_box(ch[i]); float ar = box_area(b); if (ar > ba) { ba = ar; best = i; } }
+        }
         if (best < 0) break;
         const uint32_t c = ch[best];
         ch[best] = t.left[c]; ch[nch++] = t.right[c];
@@ -366,14 +376,14 @@ struct BuildScratch {
     uint32_t cap = 0;
     Box *boxes = nullptr, *sorted = nullptr, *ibox = nullptr;
     uint32_t *keys = nullptr, *keys2 = nullptr, *idx = nullptr, *idx2 = nullptr, *ghist = nullptr, *bounds = nullptr;
-    uint32_t *left = nullptr, *right = nullptr;
+    uint32_t *left = nullptr, *right = nullptr, *count = nullptr;
     CollapseWork *wa = nullptr, *wb = nullptr;
     uint32_t* next_count = nullptr;
     Box *cba = nullptr, *cbb = nullptr;                                       // PLOC cluster boxes (ping-pong)
     uint32_t *cra = nullptr, *crb = nullptr, *nn = nullptr, *pflags = nullptr, *bsum = nullptr, *totals = nullptr;
     uint2* bbase = nullptr;
     void release() {
-        void* p[] = { boxes, sorted, ibox, keys, keys2, idx, idx2, ghist, bounds, left, right, wa, wb, next_count,
+        void* p[] = { boxes, sorted, ibox, keys, keys2, idx, idx2, ghist, bounds, left, right, count, wa, wb, next_count,
                       cba, cbb, cra, crb, nn, pflags, bsum, totals, bbase };
         for (void* q : p) if (q) (void)hipFree(q);
         *this = BuildScratch();
@@ -386,7 +396,7 @@ struct BuildScratch {
         HIPCHK(hipMalloc(&boxes, N * sizeof(Box))); HIPCHK(hipMalloc(&sorted, N * sizeof(Box))); HIPCHK(hipMalloc(&ibox, N * sizeof(Box)));
         HIPCHK(hipMalloc(&keys, N * 4)); HIPCHK(hipMalloc(&keys2, N * 4)); HIPCHK(hipMalloc(&idx, N * 4)); HIPCHK(hipMalloc(&idx2, N * 4));
         HIPCHK(hipMalloc(&ghist, (size_t)ntiles * 256 * 4)); HIPCHK(hipMalloc(&bounds, 6 * 4));
-        HIPCHK(hipMalloc(&left, N * 4)); HIPCHK(hipMalloc(&right, N * 4));
+        HIPCHK(hipMalloc(&left, N * 4)); HIPCHK(hipMalloc(&right, N * 4)); HIPCHK(hipMalloc(&count, N * 4));
         HIPCHK(hipMalloc(&wa, N * sizeof(CollapseWork))); HIPCHK(hipMalloc(&wb, N * sizeof(CollapseWork)));
         HIPCHK(hipMalloc(&next_count, 4));
         const size_t nb = (N + PLOC_BLOCK - 1) / PLOC_BLOCK;
@@ -422,7 +432,7 @@ static bool build_from_boxes(hipStream_t s, uint32_t n, Node8* nodes, uint32_t* 
     }
     // after 4 passes (ka,va) are back in (keys, idx)
     hipLaunchKernelGGL(k_gather_boxes, dim3((n + 255) / 256), dim3(256), 0, s, S.boxes, va, n, S.sorted);
-    BinTree t{ S.left, S.right, S.ibox };
+    BinTree t{ S.left, S.right, S.count, S.ibox };
     uint32_t root_ref;
     if (n >= 2) {
         HIPCHK(hipMemcpyAsync(S.cba, S.sorted, (size_t)n * sizeof(Box), hipMemcpyDeviceToDevice, s));
