@@ -138,9 +138,16 @@ __global__ __launch_bounds__(64) void k_radix_scatter(const uint32_t* keys, cons
 constexpr uint32_t REF_LEAF = 0x80000000u;
 struct BinTree {
     uint32_t* left; uint32_t* right;         // child refs of internal node i (bit 31 = leaf: index into the sorted primitives)
-    uint32_t* count;                         // primitives under internal node i
     Box* box;                                // internal node boxes
+    float* cost;                             // [7 per node] cost[k-1] = cheapest way to put the subtree into k slots of a wide node (k = 1..7)
+    uint8_t* split;                          // [8 per node] split[j-1], j = 2..8: slots given to the left child when the subtree is spread over j slots
+                                             //              (0: k slots are not worth it, use j - 1); split[0] unused
 };
+// Optimal collapse of the binary tree into 8-wide nodes (Ylitie, Karras, Laine 2017, section 3.1) for leaves of one
+// primitive — every primitive is tested in the same place whatever the cut, so only node visits count:
+// cost(n, 1) = area(n) + spread(n, 8); spread(n, j) = min over k of cost(left, k) + cost(right, j - k);
+// cost(n, j) = min(spread(n, j), cost(n, j - 1)); cost(primitive, j) = 0.
+
 
 __global__ void k_gather_boxes(const Box* boxes, const uint32_t* idx, uint32_t n, Box* sorted) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -235,7 +242,25 @@ __global__ __launch_bounds__(PLOC_BLOCK) void k_ploc_merge(const uint32_t* cref,
         const uint32_t rj = cref[j]; const Box bj = cbox[j];
         for (int k = 0; k < 3; k++) { b.lo[k] = fminf(b.lo[k], bj.lo[k]); b.hi[k] = fmaxf(b.hi[k], bj.hi[k]); }
         t.left[id] = ref; t.right[id] = rj; t.box[id] = b;
-        t.count[id] = ((ref & REF_LEAF) ? 1u : t.count[ref]) + ((rj & REF_LEAF) ? 1u : t.count[rj]);
+        {   // children are final (made in earlier rounds): fill this node's table now
+            float cl[7], cr[7];
+            if (ref & REF_LEAF) { for (int k = 0; k < 7; k++) cl[k] = 0.0f; } else for (int k = 0; k < 7; k++) cl[k] = t.cost[7 * (size_t)ref + k];
+            if (rj & REF_LEAF) { for (int k = 0; k < 7; k++) cr[k] = 0.0f; } else for (int k = 0; k < 7; k++) cr[k] = t.cost[7 * (size_t)rj + k];
+            float spread[9]; uint8_t arg[9];
+            for (int j = 2; j <= 8; j++) {
+                float best = 3.0e38f; int bk = 1;
+                for (int k = 1; k < j; k++) if (k <= 7 && j - k <= 7) { const float v = cl[k - 1] + cr[j - k - 1]; if (v < best) { best = v; bk = k; } }
+                spread[j] = best; arg[j] = (uint8_t)bk;
+            }
+            float cn[8];
+            cn[1] = box_area(b) + spread[8];
+            t.split[8 * (size_t)id + 0] = 0; t.split[8 * (size_t)id + 7] = arg[8];
+            for (int j = 2; j <= 7; j++) {
+                if (spread[j] < cn[j - 1]) { cn[j] = spread[j]; t.split[8 * (size_t)id + j - 1] = arg[j]; }
+                else { cn[j] = cn[j - 1]; t.split[8 * (size_t)id + j - 1] = 0; }
+            }
+            for (int k = 0; k < 7; k++) t.cost[7 * (size_t)id + k] = cn[k + 1];
+        }
         ref = id;
     }
     oref[pos] = ref; obox[pos] = b;
@@ -256,25 +281,26 @@ __global__ void k_collapse(const CollapseWork* work, uint32_t nwork, CollapseWor
     if (w >= nwork) return;
     const uint32_t bin = work[w].bin, widx = work[w].wide;
     // Every leaf holds ONE primitive: a watertight triangle test costs about five quantised box tests in k_trace_*, so it
-    // pays to box every triangle on its own (S1: 9.3 -> 4.2 triangle tests per ray for 12.5 -> 13.6 node visits).
+    // pays to box every triangle on its own (S1: 9.3 -> 4.2 triangle tests per ray for 12.5 -> 13.6 node visits).  Which
+    // binary nodes become wide nodes is the optimal cut of BinTree::cost (S1: 4.1 -> 6.3 children per node against opening
+    // the largest child until the node is full).
     uint32_t ch[8]; int nch = 0;
     auto ref_box = [&](uint32_t r) -> Box { return (r & REF_LEAF) ? leaf_boxes[r & ~REF_LEAF] : t.box[r]; };
     if (bin & REF_LEAF) ch[nch++] = bin;
     else { ch[nch++] = t.left[bin]; ch[nch++] = t.right[bin]; }
-    // A node visit costs the same whatever the number of children (8 slots are tested), so nodes should be full: a child
-    // subtree small enough to be absorbed completely (its primitives fit the free slots) is opened first, smallest first —
-    // that removes a node for nothing; otherwise the internal child with the largest surface area is opened
-    // (without the first rule 44 % of the nodes of S1 had two children, 4.1 on average).
-    while (nch < 8) {
-        int best = -1; float ba = -1.0f; uint32_t bsz = MAX_UINT;
-        for (int i = 0; i < nch; i++) if (!(ch[i] & REF_LEAF)) {
-            const uint32_t sz = t.count[ch[i]];
-            if (sz - 1u <= (uint32_t)(8 - nch)) { if (sz < bsz) { bsz = sz; best = i; } }
-            else if (bsz == MAX_UINT) { Box b = ref_box(ch[i]); float ar = box_area(b); if (ar > ba) { ba = ar; best = i; } }
+    // the optimal cut below `bin` (see BinTree): spread its 8 slots over the two children as the table says
+    if (!(bin & REF_LEAF)) {
+        nch = 0;
+        uint32_t sn[8]; uint8_t sj[8]; int sp = 0;
+        { const uint32_t k = t.split[8 * (size_t)bin + 7]; sn[sp] = t.right[bin]; sj[sp++] = (uint8_t)(8 - k); sn[sp] = t.left[bin]; sj[sp++] = (uint8_t)k; }
+        while (sp) {
+            const uint32_t n_ = sn[--sp]; uint32_t j = sj[sp];
+            if (n_ & REF_LEAF) { ch[nch++] = n_; continue; }
+            while (j > 1 && t.split[8 * (size_t)n_ + j - 1] == 0) j--;   // fewer slots are as good
+            if (j == 1) { ch[nch++] = n_; continue; }                    // stays one child: a wide node of its own
+            const uint32_t k = t.split[8 * (size_t)n_ + j - 1];
+            sn[sp] = t.right[n_]; sj[sp++] = (uint8_t)(j - k); sn[sp] = t.left[n_]; sj[sp++] = (uint8_t)k;
         }
-        if (best < 0) break;
-        const uint32_t c = ch[best];
-        ch[best] = t.left[c]; ch[nch++] = t.right[c];
     }
     Box cb[8]; Box nb;
     for (int k = 0; k < 3; k++) { nb.lo[k] = 3.0e38f; nb.hi[k] = -3.0e38f; }
@@ -376,14 +402,14 @@ struct BuildScratch {
     uint32_t cap = 0;
     Box *boxes = nullptr, *sorted = nullptr, *ibox = nullptr;
     uint32_t *keys = nullptr, *keys2 = nullptr, *idx = nullptr, *idx2 = nullptr, *ghist = nullptr, *bounds = nullptr;
-    uint32_t *left = nullptr, *right = nullptr, *count = nullptr;
+    uint32_t *left = nullptr, *right = nullptr; float* cost = nullptr; uint8_t* split = nullptr;
     CollapseWork *wa = nullptr, *wb = nullptr;
     uint32_t* next_count = nullptr;
     Box *cba = nullptr, *cbb = nullptr;                                       // PLOC cluster boxes (ping-pong)
     uint32_t *cra = nullptr, *crb = nullptr, *nn = nullptr, *pflags = nullptr, *bsum = nullptr, *totals = nullptr;
     uint2* bbase = nullptr;
     void release() {
-        void* p[] = { boxes, sorted, ibox, keys, keys2, idx, idx2, ghist, bounds, left, right, count, wa, wb, next_count,
+        void* p[] = { boxes, sorted, ibox, keys, keys2, idx, idx2, ghist, bounds, left, right, cost, split, wa, wb, next_count,
                       cba, cbb, cra, crb, nn, pflags, bsum, totals, bbase };
         for (void* q : p) if (q) (void)hipFree(q);
         *this = BuildScratch();
@@ -396,7 +422,7 @@ struct BuildScratch {
         HIPCHK(hipMalloc(&boxes, N * sizeof(Box))); HIPCHK(hipMalloc(&sorted, N * sizeof(Box))); HIPCHK(hipMalloc(&ibox, N * sizeof(Box)));
         HIPCHK(hipMalloc(&keys, N * 4)); HIPCHK(hipMalloc(&keys2, N * 4)); HIPCHK(hipMalloc(&idx, N * 4)); HIPCHK(hipMalloc(&idx2, N * 4));
         HIPCHK(hipMalloc(&ghist, (size_t)ntiles * 256 * 4)); HIPCHK(hipMalloc(&bounds, 6 * 4));
-        HIPCHK(hipMalloc(&left, N * 4)); HIPCHK(hipMalloc(&right, N * 4)); HIPCHK(hipMalloc(&count, N * 4));
+        HIPCHK(hipMalloc(&left, N * 4)); HIPCHK(hipMalloc(&right, N * 4)); HIPCHK(hipMalloc(&cost, N * 28)); HIPCHK(hipMalloc(&split, N * 8));
         HIPCHK(hipMalloc(&wa, N * sizeof(CollapseWork))); HIPCHK(hipMalloc(&wb, N * sizeof(CollapseWork)));
         HIPCHK(hipMalloc(&next_count, 4));
         const size_t nb = (N + PLOC_BLOCK - 1) / PLOC_BLOCK;
@@ -432,7 +458,7 @@ static bool build_from_boxes(hipStream_t s, uint32_t n, Node8* nodes, uint32_t* 
     }
     // after 4 passes (ka,va) are back in (keys, idx)
     hipLaunchKernelGGL(k_gather_boxes, dim3((n + 255) / 256), dim3(256), 0, s, S.boxes, va, n, S.sorted);
-    BinTree t{ S.left, S.right, S.count, S.ibox };
+    BinTree t{ S.left, S.right, S.ibox, S.cost, S.split };
     uint32_t root_ref;
     if (n >= 2) {
         HIPCHK(hipMemcpyAsync(S.cba, S.sorted, (size_t)n * sizeof(Box), hipMemcpyDeviceToDevice, s));
