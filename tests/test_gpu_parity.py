@@ -350,6 +350,18 @@ def test_s1_full_size_tiles_match_oracle(orc, s1_full):
         assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), "tile %d differs" % t
 
 
+@pytest.mark.skipif((os.cpu_count() or 1) < 64, reason="the oracle needs a many-core host for the whole frame (the GPU box has 256 threads)")
+def test_s1_full_frame_matches_oracle(orc, s1_full):
+    """every pixel of the benchmark frame (1920x1080, 3 launches, ~26 M rays): bit-identical film, identical ray counts"""
+    _, _, _, film, counters = s1_full
+    oc = orc.Context(threads=os.cpu_count())
+    s, l = scenes.s1(oc, extent=(1920, 1080))
+    oc.set_pipeline(samples_per_run=1, max_bounces=8, env_samples_per_bounce=1, mesh_samples_per_bounce=1)
+    oc.render(s, l, launches=3)
+    assert_film_equal(film, oc.sensor_data(s), "S1 1920x1080 full frame")
+    assert counters == {k: v for k, v in oc.counters().items() if k in ("closest_rays", "shadow_rays", "samples")}
+
+
 def test_s1_full_size_batching_and_sharding_invariance(gpu_api, s1_full):
     """concurrent launches == sequential launches == tile-sharded render, bit for bit, at the benchmark's size"""
     c, s, l, film, counters = s1_full
