@@ -362,6 +362,21 @@ def test_s1_full_frame_matches_oracle(orc, s1_full):
     assert counters == {k: v for k, v in oc.counters().items() if k in ("closest_rays", "shadow_rays", "samples")}
 
 
+@pytest.mark.skipif((os.cpu_count() or 1) < 64, reason="the oracle needs a many-core host for whole frames (the GPU box has 256 threads)")
+@pytest.mark.parametrize("which", ["s1_sky", "s2"])
+def test_other_full_size_configs_match_oracle(orc, gpu_api, which):
+    """BASELINE.json's other full-size workloads, every pixel of one launch at 1920x1080: S1 under the 512x256 sky+sun
+    environment (mip descent) and S2 (10.24 M instanced triangles: TLAS + 500 transformed instances)"""
+    build = (lambda c: scenes.s1(c, extent=(1920, 1080), env="sky")) if which == "s1_sky" else (lambda c: scenes.s2(c, extent=(1920, 1080)))
+    gc = gpu_api.Context(); oc = orc.Context(threads=os.cpu_count())
+    sg, lg = build(gc); so, lo = build(oc)
+    for c in (gc, oc):
+        c.set_pipeline(samples_per_run=1, max_bounces=8, env_samples_per_bounce=1, mesh_samples_per_bounce=1)
+    gc.render(sg, lg, launches=1); oc.render(so, lo, launches=1)
+    assert_film_equal(gc.sensor_data(sg), oc.sensor_data(so), which + " 1920x1080 full frame")
+    assert gc.counters() == {k: v for k, v in oc.counters().items() if k in ("closest_rays", "shadow_rays", "samples")}
+
+
 def test_s1_full_size_batching_and_sharding_invariance(gpu_api, s1_full):
     """concurrent launches == sequential launches == tile-sharded render, bit for bit, at the benchmark's size"""
     c, s, l, film, counters = s1_full
