@@ -83,3 +83,34 @@ def write_gallery(path_glb, path_exr, u32=False):
     b.node(camera=b.camera(0.7), matrix=assets.look_at_yup((0.5, 3.0, 8.0), (0, 1.0, 0)))
     open(path_glb, "wb").write(b.tobytes())
     open(path_exr, "wb").write(assets.exr_bytes(scenes.sky_sun_equirect(64, 32), "RGB", "half", "zip"))
+
+
+def write_cornell(path_glb, path_exr):
+    """BASELINE.json configs[1]: Cornell box with an emissive ceiling quad ("Emitter…": sampled), black environment.
+    Y-up glTF coordinates; five Lambert walls, a short and a tall box, the light just below the ceiling."""
+    b = assets.GlbBuilder()
+    white = b.material("White", base_color=(0.73, 0.73, 0.73), metallic=0.0, roughness=1.0)
+    red = b.material("Red", base_color=(0.65, 0.05, 0.05), metallic=0.0, roughness=1.0)
+    green = b.material("Green", base_color=(0.12, 0.45, 0.15), metallic=0.0, roughness=1.0)
+    light = b.material("Emitter", base_color=(0, 0, 0), emissive=(1.0, 0.85, 0.6), emissive_strength=15.0)
+
+    def quad(p0, p1, p2, p3, mat):
+        return b.mesh([dict(positions=[p0, p1, p2, p3], indices=[0, 1, 2, 0, 2, 3], material=mat)])
+
+    def box(lo, hi, mat):
+        (x0, y0, z0), (x1, y1, z1) = lo, hi
+        P = [(x0, y0, z0), (x1, y0, z0), (x1, y1, z0), (x0, y1, z0), (x0, y0, z1), (x1, y0, z1), (x1, y1, z1), (x0, y1, z1)]
+        I = [0, 2, 1, 0, 3, 2, 4, 5, 6, 4, 6, 7, 0, 1, 5, 0, 5, 4, 3, 6, 2, 3, 7, 6, 0, 4, 7, 0, 7, 3, 1, 2, 6, 1, 6, 5]
+        return b.mesh([dict(positions=P, indices=I, material=mat)])
+
+    b.node(mesh=quad((-1, 0, -1), (1, 0, -1), (1, 0, 1), (-1, 0, 1), white))        # floor
+    b.node(mesh=quad((-1, 2, -1), (-1, 2, 1), (1, 2, 1), (1, 2, -1), white))        # ceiling
+    b.node(mesh=quad((-1, 0, -1), (-1, 2, -1), (1, 2, -1), (1, 0, -1), white))      # back wall
+    b.node(mesh=quad((-1, 0, -1), (-1, 0, 1), (-1, 2, 1), (-1, 2, -1), red))        # left
+    b.node(mesh=quad((1, 0, -1), (1, 2, -1), (1, 2, 1), (1, 0, 1), green))          # right
+    b.node(mesh=quad((-0.3, 1.98, -0.3), (0.3, 1.98, -0.3), (0.3, 1.98, 0.3), (-0.3, 1.98, 0.3), light))
+    b.node(mesh=box((-0.3, 0, -0.3), (0.3, 0.6, 0.3), white), translation=(0.35, 0, 0.3), rotation=(0, math.sin(-0.15), 0, math.cos(-0.15)))
+    b.node(mesh=box((-0.3, 0, -0.3), (0.3, 1.2, 0.3), white), translation=(-0.35, 0, -0.3), rotation=(0, math.sin(0.2), 0, math.cos(0.2)))
+    b.node(camera=b.camera(0.69), matrix=assets.look_at_yup((0, 1.0, 3.9), (0, 1.0, 0)))
+    open(path_glb, "wb").write(b.tobytes())
+    open(path_exr, "wb").write(assets.exr_bytes(np.zeros((1, 1, 4), np.float32)))

@@ -70,3 +70,27 @@ def test_offline_cli(tmp_path, orc):
     oc.set_pipeline(samples_per_run=1, max_bounces=8, env_samples_per_bounce=1, mesh_samples_per_bounce=1)
     oc.render(s, ol, launches=5)
     assert np.array_equal(bits(got[..., :3]), bits(oc.sensor_data(s)[..., :3]))
+
+
+@pytest.mark.skipif((os.cpu_count() or 1) < 64, reason="the oracle needs a many-core host for 16.7 M samples (the GPU box has 256 threads)")
+def test_config1_cornell_glb_offline_64spp(tmp_path, orc):
+    """BASELINE.json configs[1] end to end: Cornell-box GLB (tools/make_cornell_glb.py) -> `offline` at 512x512, 64 spp, depth 8,
+    mesh-light NEE -> EXR, bit-identical to the oracle fed the same GLB"""
+    glb, exr, out = str(tmp_path / "cornell.glb"), str(tmp_path / "black.exr"), str(tmp_path / "out.exr")
+    io.write_cornell(glb, exr)
+    exe = os.path.join(ROOT, "moonshine_amd", "offline")
+    r = subprocess.run([exe, glb, exr, out, "64", "--width", "512", "--height", "512", "--max-bounces", "8", "--env-samples", "0", "--mesh-samples", "1"],
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    from moonshine_amd import api
+    got = api.exr_load(out)
+    oc = orc.Context(threads=os.cpu_count())
+    ol, info = io.oracle_load(orc, oc, glb, exr)
+    assert info["triangles"] == 36 and info["instances"] == 8
+    s = oc.create_sensor(512, 512)
+    oc.set_pipeline(samples_per_run=1, max_bounces=8, env_samples_per_bounce=0, mesh_samples_per_bounce=1)
+    oc.render(s, ol, launches=64)
+    ref = oc.sensor_data(s)
+    assert np.array_equal(bits(got[..., :3]), bits(ref[..., :3]))
+    a, b_ = ref[256, 40], ref[256, 471]      # the two side walls (the importer's y/z swap mirrors the glTF scene, World.zig:256-262)
+    assert 0.05 < float(ref[..., :3].mean()) < 2.0 and (a[0] - a[1]) * (b_[0] - b_[1]) < 0      # lit; one wall red, the other green
