@@ -92,5 +92,5 @@ def test_config1_cornell_glb_offline_64spp(tmp_path, orc):
     oc.render(s, ol, launches=64)
     ref = oc.sensor_data(s)
     assert np.array_equal(bits(got[..., :3]), bits(ref[..., :3]))
-    a, b_ = ref[256, 40], ref[256, 471]      # the two side walls (the importer's y/z swap mirrors the glTF scene, World.zig:256-262)
+    a, b_ = ref[256, 40], ref[256, 471]      # the two side walls (the importer's Z-up row order mirrors the glTF scene, World.zig:339-346)
     assert 0.05 < float(ref[..., :3].mean()) < 2.0 and (a[0] - a[1]) * (b_[0] - b_[1]) < 0      # lit; one wall red, the other green
