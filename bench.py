@@ -150,7 +150,7 @@ def main():
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "S1: 7x7 order-5 icospheres (1 003 520 tris) + ground + emissive quad, %dx%d, %d spp, max_bounces 8, env+mesh NEE with MIS, %s env"
                                    % (a.width, a.height, a.steps, a.env),
-                       "sharding": "64x64 image tiles, tile t -> rank t mod %d, one RCCL gather of the packed film" % world},
+                       "sharding": "16x16 image tiles, tile t -> rank t mod %d, one RCCL gather of the packed film" % world},
             "msamples_per_s": samples / dt / 1e6,
             "rays": {"closest": closest, "shadow": shadow, "per_sample": rays / max(samples, 1.0)},
             "roofline": {"bound": "hbm", "kernel": "k_trace_closest", "achieved": achieved, "peak": HBM_PEAK / 1e9, "unit": "GB/s",

@@ -9,6 +9,7 @@ import ctypes as C
 import os
 
 import numpy as np
+from . import tiles
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libmoonshine_amd.so")
@@ -209,13 +210,13 @@ class Context:
 
     make_lens = staticmethod(make_lens)
 
-    def __init__(self, device=-1, tile_size=64, shard_index=0, shard_count=1):
+    def __init__(self, device=-1, tile_size=0, shard_index=0, shard_count=1):
         self.L = load_library()
         cfg = MsneConfig(device, tile_size, shard_index, shard_count)
         self.h = self.L.MsneCreate(C.byref(cfg))
         if not self.h:
             raise MoonshineError("MsneCreate failed: %s" % (self.L.MsneGetLastError(None) or b"").decode())
-        self.tile_size, self.shard_index, self.shard_count = tile_size, shard_index, shard_count
+        self.tile_size, self.shard_index, self.shard_count = tile_size or tiles.DEFAULT_TILE, shard_index, shard_count
         self._extents = {}
 
     def _err(self, what):

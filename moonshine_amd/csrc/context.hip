@@ -670,7 +670,7 @@ HdMoonshine* MsneCreate(const MsneConfig* cfg_in) {
     int dev = cfg.device;
     if (dev < 0) { const char* e = getenv("MSNE_DEVICE"); dev = e ? atoi(e) : 0; }
     if (dev >= ndev) { g_create_error = "requested HIP device does not exist"; return nullptr; }
-    if (cfg.tile_size == 0) cfg.tile_size = 64;
+    if (cfg.tile_size == 0) cfg.tile_size = MSNE_DEFAULT_TILE_SIZE;
     if (cfg.shard_count == 0) cfg.shard_count = 1;
     if (cfg.shard_index >= cfg.shard_count) { g_create_error = "shard_index >= shard_count"; return nullptr; }
     HdMoonshine* c = new (std::nothrow) HdMoonshine();

@@ -20,7 +20,8 @@ def test_pack_unpack_roundtrip():
         assert len({p.shape for p in parts}) == 1
         out = tiles.unpack(np.concatenate(parts), w, h, g, 4, ts)
         assert np.array_equal(out, film)
-    assert tiles.shard_tiles(1920, 1080, 3, 8) == list(range(3, 30 * 17, 8))
+    assert tiles.shard_tiles(1920, 1080, 3, 8, 64) == list(range(3, 30 * 17, 8))
+    assert tiles.shard_tiles(1920, 1080, 3, 8) == list(range(3, 120 * 68, 8))   # default 16x16 tiles
 
 
 WORKER = r'''
@@ -32,15 +33,16 @@ from moonshine_amd import scenes, tiles
 dist.init_process_group("gloo")
 rank, world = dist.get_rank(), dist.get_world_size()
 W, H = 150, 100
-c = orc.Context(shard_index=rank, shard_count=world, threads=2)
+TS = tiles.DEFAULT_TILE   # the library's default tile size
+c = orc.Context(tile_size=TS, shard_index=rank, shard_count=world, threads=2)
 s, l = scenes.cornell(c, extent=(W, H))
 c.set_pipeline(samples_per_run=1, max_bounces=4, env_samples_per_bounce=0, mesh_samples_per_bounce=1)
 c.render(s, l, launches=2)
-mine = torch.from_numpy(tiles.pack(c.sensor_data(s), rank, world))
+mine = torch.from_numpy(tiles.pack(c.sensor_data(s), rank, world, TS))
 parts = [torch.empty_like(mine) for _ in range(world)] if rank == 0 else None
 dist.gather(mine, parts, dst=0)
 if rank == 0:
-    film = tiles.unpack(torch.cat(parts).numpy(), W, H, world)
+    film = tiles.unpack(torch.cat(parts).numpy(), W, H, world, 4, TS)
     ref = orc.Context(threads=2)
     s2, l2 = scenes.cornell(ref, extent=(W, H))
     ref.set_pipeline(samples_per_run=1, max_bounces=4, env_samples_per_bounce=0, mesh_samples_per_bounce=1)
