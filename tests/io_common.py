@@ -26,7 +26,18 @@ def shim(orc):
         _SHIM.ShimError.restype = C.c_char_p
         _SHIM.ShimLoadGlb.argtypes = [C.c_void_p, C.c_char_p, C.c_void_p]
         _SHIM.ShimSetBackgroundExr.argtypes = [C.c_void_p, C.c_char_p]
+        _SHIM.ShimPngDecode.argtypes = [C.c_char_p, C.c_size_t, C.c_void_p, C.c_void_p]
     return _SHIM
+
+
+def png_decode(orc, data):
+    """the product's PNG decoder (moonshine_amd/host/png.cpp) -> (h, w, 3) uint8"""
+    s = shim(orc)
+    wh = (C.c_uint32 * 2)()
+    assert s.ShimPngDecode(data, len(data), None, wh) == 0, s.ShimError()
+    out = np.zeros((wh[1], wh[0], 3), np.uint8)
+    assert s.ShimPngDecode(data, len(data), out.ctypes.data_as(C.c_void_p), wh) == 0, s.ShimError()
+    return out
 
 
 def oracle_load(orc, ctx, glb_path, exr_path=None):

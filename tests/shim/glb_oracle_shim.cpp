@@ -2,6 +2,7 @@
 // CPU oracle's scene API, so a GLB / EXR pair can be loaded into the oracle exactly as MsneLoadGlb /
 // MsneSetBackgroundExr load it into the HIP library.  Lives under tests/: the product never links the oracle.
 #include "../../moonshine_amd/host/host.h"
+#include <cstring>
 struct OrcContext;
 extern "C" {
 int64_t OrcCreateMesh(OrcContext*, const F32x3*, const F32x3*, const F32x2*, size_t, size_t, const U32x3*, size_t);
@@ -31,6 +32,14 @@ int ShimLoadGlb(OrcContext* c, const char* path, uint32_t info[6]) {
     GlbSummary sum;
     if (!glb_import(path, s, sum, g_err)) return -1;
     info[0] = sum.meshes; info[1] = sum.materials; info[2] = sum.instances; info[3] = sum.textures; info[4] = sum.triangles; info[5] = (uint32_t)sum.lens;
+    return 0;
+}
+// png_decode on its own: rgb_out == NULL returns the extent only
+int ShimPngDecode(const uint8_t* data, size_t n, uint8_t* rgb_out, uint32_t wh[2]) {
+    Image8 img;
+    if (!png_decode(data, n, img, g_err)) return -1;
+    wh[0] = img.w; wh[1] = img.h;
+    if (rgb_out) memcpy(rgb_out, img.rgb.data(), img.rgb.size());
     return 0;
 }
 int ShimSetBackgroundExr(OrcContext* c, const char* path) {

@@ -143,3 +143,109 @@ def test_glb_errors(tmp_path, orc):
     nocam = str(tmp_path / "nocam.glb")
     open(nocam, "wb").write(b.tobytes())
     assert s.ShimLoadGlb(C.c_void_p(c.h), nocam.encode(), info) != 0 and b"NoCameraInGlb" in s.ShimError()     # Camera.zig:30
+
+
+# ---- third-party pins: Pillow's PNG encoder/decoder, and two files of CPython's own test suite ----
+THIRD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "third_party")
+
+
+@pytest.mark.parametrize("mode", ["RGB", "RGBA", "L", "LA", "P", "P4", "P2", "1", "I;16"])
+@pytest.mark.parametrize("size", [(37, 23), (64, 64), (1, 5)])
+def test_png_decoder_against_pillow(orc, mode, size):
+    """moonshine_amd/host/png.cpp against PNGs written by Pillow (adaptive per-row filters, all five filter types occur):
+    8-bit RGB out, alpha dropped, palette expanded (8-bit and packed), 1-bit gray, 16-bit samples keep their high byte."""
+    import io as _io
+    from PIL import Image
+    w, h = size
+    rs = np.random.default_rng(w * 131 + h)
+    yy, xx = np.mgrid[0:h, 0:w]
+    base = np.stack([(xx * 5 + yy * 3) % 256, (xx * yy) % 256, (255 - xx * 2 - yy) % 256, (xx + yy * 7) % 256], -1) + rs.integers(-6, 7, (h, w, 4))
+    base = np.clip(base, 0, 255).astype(np.uint8)
+    if mode == "I;16":
+        a16 = (base[..., 0].astype(np.uint16) << 8) | base[..., 1]
+        im = Image.fromarray(a16, "I;16")
+        want = np.repeat((a16 >> 8).astype(np.uint8)[..., None], 3, -1)
+    else:
+        nch = {"RGB": 3, "RGBA": 4, "L": 1, "LA": 2, "P": 3, "P4": 3, "P2": 3, "1": 1}[mode]
+        arr = base[..., :nch] if nch > 1 else base[..., 0]
+        im = Image.fromarray(arr, "RGB" if mode[0] == "P" else "L" if mode == "1" else mode)
+        if mode[0] == "P":
+            im = im.quantize({"P": 200, "P4": 13, "P2": 3}[mode])   # Pillow packs small palettes at 4 / 2 / 1 bits per pixel
+        if mode == "1":
+            im = im.convert("1")
+        want = np.asarray(im.convert("RGB"))
+    for kw in ({}, {"optimize": True}, {"compress_level": 1}):
+        buf = _io.BytesIO()
+        im.save(buf, "PNG", **kw)
+        got = io.png_decode(orc, buf.getvalue())
+        assert got.shape == want.shape and np.array_equal(got, want), (mode, size, kw)
+
+
+def test_third_party_png_and_exr_files(orc):
+    """python_logo.{png,exr}: Lib/test/imghdrdata/python.{png,exr} of CPython 3.11 (PSF licence), the same 16x16 RGBA picture
+    as a palette PNG with tRNS and as an uncompressed HALF OpenEXR.  Neither file nor the decoder they are checked with
+    (Pillow) was written here."""
+    from PIL import Image
+    png = open(os.path.join(THIRD, "python_logo.png"), "rb").read()
+    im = Image.open(os.path.join(THIRD, "python_logo.png"))
+    assert np.array_equal(io.png_decode(orc, png), np.asarray(im.convert("RGB")))
+    exr = api.exr_load(os.path.join(THIRD, "python_logo.exr"))
+    assert exr.shape == (16, 16, 4)
+    assert np.array_equal(bits(exr), bits(assets.exr_decode(open(os.path.join(THIRD, "python_logo.exr"), "rb").read())))
+    want = np.asarray(im.convert("RGBA")).astype(np.float64) / 255.0
+    seen = want[..., 3] > 0
+    assert seen.sum() > 100
+    assert np.abs(exr[..., 3] - want[..., 3]).max() < 5e-4           # half precision of values in [0, 1]
+    assert np.abs(exr[..., :3] - want[..., :3])[seen].max() < 5e-4
+
+
+def _png_adam7(w, h, ctype, depth, samples, palette=None):
+    """Adam7-interlaced PNG (filter 0 everywhere) of `samples` (h, w, channels) — Pillow reads interlaced files but cannot write them"""
+    import struct
+    import zlib
+
+    def chunk(t, b):
+        return struct.pack(">I", len(b)) + t + b + struct.pack(">I", zlib.crc32(t + b) & 0xffffffff)
+    raw = b""
+    for x0, y0, dx, dy in ((0, 0, 8, 8), (4, 0, 8, 8), (0, 4, 4, 8), (2, 0, 4, 4), (0, 2, 2, 4), (1, 0, 2, 2), (0, 1, 1, 2)):
+        sub = samples[y0::dy, x0::dx]
+        if sub.size == 0:
+            continue
+        for row in sub:
+            v = row.reshape(-1)
+            if depth == 16:
+                b = v.astype(">u2").tobytes()
+            elif depth == 8:
+                b = v.astype(np.uint8).tobytes()
+            else:
+                bitsrow = np.zeros(((len(v) * depth + 7) // 8) * 8, np.uint8)
+                for k in range(depth):
+                    bitsrow[k:len(v) * depth:depth] = (v >> (depth - 1 - k)) & 1
+                b = np.packbits(bitsrow).tobytes()
+            raw += b"\0" + b
+    out = b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", struct.pack(">IIBBBBB", w, h, depth, ctype, 0, 0, 1))
+    if palette is not None:
+        out += chunk(b"PLTE", np.asarray(palette, np.uint8).tobytes())
+    return out + chunk(b"IDAT", zlib.compress(raw)) + chunk(b"IEND", b"")
+
+
+@pytest.mark.parametrize("ctype,depth", [(2, 8), (6, 8), (0, 4), (0, 1), (3, 2), (3, 8), (4, 8), (2, 16), (0, 16)])
+@pytest.mark.parametrize("size", [(13, 9), (8, 8), (3, 1), (1, 1), (33, 20)])
+def test_png_adam7_against_pillow(orc, ctype, depth, size):
+    import io as _io
+    from PIL import Image
+    w, h = size
+    rs = np.random.default_rng(ctype * 100 + depth + w)
+    ch = {0: 1, 2: 3, 3: 1, 4: 2, 6: 4}[ctype]
+    hi = min(1 << depth, 4 if (ctype == 3 and depth == 2) else 1 << depth)
+    samples = rs.integers(0, hi, (h, w, ch)).astype(np.uint32)
+    palette = rs.integers(0, 256, (min(1 << depth, 256), 3)) if ctype == 3 else None
+    data = _png_adam7(w, h, ctype, depth, samples, palette)
+    got = io.png_decode(orc, data)
+    if depth == 16:   # Pillow keeps 16-bit gray as I;16 and truncates 16-bit RGB its own way: state the rule directly
+        want = np.repeat((samples[..., :1] >> 8), 3, -1) if ctype == 0 else (samples[..., :3] >> 8)
+        im = Image.open(_io.BytesIO(data)); im.load()          # ... but it must at least accept the file
+        assert im.size == (w, h)
+    else:
+        want = np.asarray(Image.open(_io.BytesIO(data)).convert("RGB"))
+    assert np.array_equal(got, want.astype(np.uint8))
