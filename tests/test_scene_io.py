@@ -155,7 +155,7 @@ def test_png_decoder_against_pillow(orc, mode, size):
     """moonshine_amd/host/png.cpp against PNGs written by Pillow (adaptive per-row filters, all five filter types occur):
     8-bit RGB out, alpha dropped, palette expanded (8-bit and packed), 1-bit gray, 16-bit samples keep their high byte."""
     import io as _io
-    from PIL import Image
+    Image = pytest.importorskip("PIL.Image")
     w, h = size
     rs = np.random.default_rng(w * 131 + h)
     yy, xx = np.mgrid[0:h, 0:w]
@@ -185,7 +185,7 @@ def test_third_party_png_and_exr_files(orc):
     """python_logo.{png,exr}: Lib/test/imghdrdata/python.{png,exr} of CPython 3.11 (PSF licence), the same 16x16 RGBA picture
     as a palette PNG with tRNS and as an uncompressed HALF OpenEXR.  Neither file nor the decoder they are checked with
     (Pillow) was written here."""
-    from PIL import Image
+    Image = pytest.importorskip("PIL.Image")
     png = open(os.path.join(THIRD, "python_logo.png"), "rb").read()
     im = Image.open(os.path.join(THIRD, "python_logo.png"))
     assert np.array_equal(io.png_decode(orc, png), np.asarray(im.convert("RGB")))
@@ -233,7 +233,7 @@ def _png_adam7(w, h, ctype, depth, samples, palette=None):
 @pytest.mark.parametrize("size", [(13, 9), (8, 8), (3, 1), (1, 1), (33, 20)])
 def test_png_adam7_against_pillow(orc, ctype, depth, size):
     import io as _io
-    from PIL import Image
+    Image = pytest.importorskip("PIL.Image")
     w, h = size
     rs = np.random.default_rng(ctype * 100 + depth + w)
     ch = {0: 1, 2: 3, 3: 1, 4: 2, 6: 4}[ctype]
