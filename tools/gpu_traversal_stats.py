@@ -4,7 +4,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.ins
 import torch  # noqa
 from moonshine_amd import api, scenes
 w, h, spp = (int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3])) if len(sys.argv) > 3 else (480, 270, 4)
-c = api.Context()
+c = api.Context(shard_index=0, shard_count=int(os.environ.get("SHARDS", "1")))   # SHARDS=8: rank 0 of an 8-way tile shard
 s, l = (scenes.s2 if os.environ.get("SCENE") == "s2" else scenes.s1)(c, extent=(w, h))
 c.set_pipeline(samples_per_run=1, max_bounces=8, env_samples_per_bounce=1, mesh_samples_per_bounce=1)
 c.set_profiling(True, True)
