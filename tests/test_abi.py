@@ -52,3 +52,44 @@ def test_product_never_imports_the_oracle():
                 if f.endswith((".py", ".hip", ".h", ".cpp", ".c")):
                     src = open(os.path.join(dirpath, f), errors="ignore").read()
                     assert not pat.search(src), (f, pat.search(src).group(0))
+
+
+REF_HEADER = "/root/reference/hydra/moonshine.h"
+
+
+@pytest.mark.skipif(not os.path.exists(REF_HEADER), reason="needs the reference checkout (not present on the GPU box)")
+def test_translation_unit_built_against_the_reference_header_links_and_loads(tmp_path, gpu_api):
+    """drop-in at the link level: a C++ file that sees ONLY the reference's hydra/moonshine.h (the header hydra/*.cpp
+    include) and calls all 24 entry points links against libmoonshine_amd.so and starts (nothing is executed: no GPU here)."""
+    import subprocess
+    from moonshine_amd import build as b
+    src = tmp_path / "hydra_tu.cpp"
+    src.write_text('''#include "%s"
+int main(int argc, char** argv) {
+    if (argc < 1000) return 0;            // never true: the calls below only have to compile and link
+    HdMoonshine* c = HdMoonshineCreate();
+    F32x3 p[3] = {}; F32x2 t[3] = {}; U32x3 i[1] = {}; uint8_t px[8] = {};
+    MeshHandle m = HdMoonshineCreateMesh(c, p, p, t, 3, i, 1);
+    ImageHandle i1 = HdMoonshineCreateSolidTexture1(c, 0.5f, "a"), i2 = HdMoonshineCreateSolidTexture2(c, F32x2{0, 0}, "b");
+    ImageHandle i3 = HdMoonshineCreateSolidTexture3(c, F32x3{0, 0, 0}, "c"), i4 = HdMoonshineCreateRawTexture(c, px, Extent2D{1, 1}, u8x4_srgb, "d");
+    MaterialHandle mat = HdMoonshineCreateMaterial(c, Material{i2, i3, i4, i1, i1, 1.5f});
+    HdMoonshineSetMaterialNormal(c, mat, i2); HdMoonshineSetMaterialEmissive(c, mat, i3); HdMoonshineSetMaterialColor(c, mat, i3);
+    HdMoonshineSetMaterialMetalness(c, mat, i1); HdMoonshineSetMaterialRoughness(c, mat, i1); HdMoonshineSetMaterialIOR(c, mat, 1.3f);
+    Geometry g{m, mat, false};
+    Mat3x4 x{};
+    InstanceHandle in = HdMoonshineCreateInstance(c, x, &g, 1, true);
+    HdMoonshineSetInstanceTransform(c, in, x); HdMoonshineSetInstanceVisibility(c, in, false); HdMoonshineDestroyInstance(c, in);
+    SensorHandle s = HdMoonshineCreateSensor(c, Extent2D{4, 4});
+    Lens l{};
+    LensHandle lh = HdMoonshineCreateLens(c, l); HdMoonshineSetLens(c, lh, l);
+    bool ok = HdMoonshineRebuildPipeline(c) && HdMoonshineRender(c, s, lh);
+    float* d = HdMoonshineGetSensorData(c, s);
+    HdMoonshineDestroy(c);
+    return ok && d ? 0 : 1;
+}
+''' % REF_HEADER)
+    exe = tmp_path / "hydra_tu"
+    libdir = os.path.dirname(b.LIB)
+    subprocess.check_call(["g++", "-std=c++17", "-Wall", "-Werror", "-o", str(exe), str(src), "-L" + libdir, "-lmoonshine_amd", "-Wl,-rpath," + libdir,
+                           "-Wl,-rpath-link," + os.path.join(os.environ.get("ROCM_PATH", "/opt/rocm"), "lib")])
+    assert subprocess.run([str(exe)], timeout=120).returncode == 0
