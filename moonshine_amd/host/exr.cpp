@@ -99,6 +99,7 @@ bool exr_load(const std::string& path, Image& img, std::string& err) {
         default: err = "EXR compression " + std::to_string(compression) + " is not supported (NONE, RLE, ZIPS, ZIP are)"; return false;
     }
     const size_t nblocks = (size_t)((H + lines_per_block - 1) / lines_per_block);
+    if (r.pos > file.size() || nblocks > (file.size() - r.pos) / 8) { err = "truncated EXR offset table"; return false; }   // before anything is sized by the header
     std::vector<uint64_t> offsets(nblocks);
     for (auto& o : offsets) o = r.u64();
     if (!r.ok) { err = "truncated EXR offset table"; return false; }
@@ -112,6 +113,8 @@ bool exr_load(const std::string& path, Image& img, std::string& err) {
         if (nm == "R") src[0] = (int)c; else if (nm == "G") src[1] = (int)c; else if (nm == "B") src[2] = (int)c; else if (nm == "A") src[3] = (int)c;
     }
     if (src[0] < 0 && src[1] < 0 && src[2] < 0) { if (channels.size() == 1 || channels[0].name == "Y") src[0] = src[1] = src[2] = 0; else { err = "EXR has no R/G/B channels"; return false; } }
+    // a header may claim more pixels than the file can hold: deflate expands at most ~1032:1, RLE 64:1
+    if ((double)line_bytes * (double)H > (double)file.size() * 1100.0) { err = "EXR data window exceeds the file's data"; return false; }
     img.w = (uint32_t)W; img.h = (uint32_t)H; img.rgba.assign((size_t)W * H * 4, 0.0f);
     for (size_t i = 0; i < (size_t)W * H; i++) img.rgba[4 * i + 3] = 1.0f;
     std::vector<uint8_t> tmp, raw;

@@ -54,6 +54,8 @@ bool png_decode(const uint8_t* d, size_t n, Image8& img, std::string& err) {
         const size_t pw = (w - ps.x0 + ps.dx - 1) / ps.dx, ph = (h - ps.y0 + ps.dy - 1) / ps.dy;
         raw_size += ph * (1 + (pw * bits + 7) / 8);
     }
+    // a corrupt IHDR may claim more pixels than the IDAT stream can hold (deflate expands at most ~1032:1)
+    if (w > 65536u || h > 65536u || (double)raw_size > (double)idat.size() * 1100.0 + 65536.0) { err = "PNG dimensions exceed its data"; return false; }
     std::vector<uint8_t> raw(raw_size);
     uLongf rl = (uLongf)raw.size();
     if (uncompress(raw.data(), &rl, idat.data(), (uLong)idat.size()) != Z_OK || rl != raw.size()) { err = "PNG inflate failed"; return false; }

@@ -249,3 +249,52 @@ def test_png_adam7_against_pillow(orc, ctype, depth, size):
     else:
         want = np.asarray(Image.open(_io.BytesIO(data)).convert("RGB"))
     assert np.array_equal(got, want.astype(np.uint8))
+
+
+def test_parsers_survive_mutated_files_under_sanitizers(tmp_path, orc):
+    """GLB / PNG / EXR parsers under AddressSanitizer + UBSan (CPU build) on a few hundred mutated files: rejecting a file is
+    fine, reading or writing out of bounds is not."""
+    import shutil
+    if shutil.which("g++") is None:
+        pytest.skip("no g++")
+    exe = tmp_path / "fuzz_io"
+    srcs = [os.path.join(io.ROOT, "tests", "shim", "fuzz_io.cpp")] + [os.path.join(io.ROOT, "moonshine_amd", "host", f) for f in ("glb.cpp", "png.cpp", "exr.cpp")]
+    r = subprocess.run(["g++", "-O1", "-g", "-std=c++17", "-fsanitize=address,undefined", "-fno-sanitize-recover=all", "-Wno-comment", "-o", str(exe)] + srcs + ["-lz"],
+                       capture_output=True, text=True)
+    if r.returncode != 0 and "sanitize" in r.stderr + r.stdout:
+        pytest.skip("sanitizer runtime not available: " + r.stderr[-200:])
+    assert r.returncode == 0, r.stderr[-2000:]
+    seeds = {}
+    glb = str(tmp_path / "gallery.glb"); io.write_gallery(glb, str(tmp_path / "gallery.exr"), u32=False); seeds["glb"] = open(glb, "rb").read()
+    exr_rgba = np.random.default_rng(3).random((9, 13, 4)).astype(np.float32)
+    for comp in ("none", "zips", "zip"):
+        seeds["exr_" + comp] = assets.exr_bytes(exr_rgba, "RGBA", "half" if comp == "zips" else "float", comp)
+    seeds["png"] = open(os.path.join(THIRD, "python_logo.png"), "rb").read()
+    seeds["png2"] = _png_adam7(13, 9, 6, 8, np.random.default_rng(1).integers(0, 256, (9, 13, 4)).astype(np.uint32))
+    rs = np.random.default_rng(2024)
+    files = []
+    for name, data in seeds.items():
+        ext = name.split("_")[0].rstrip("2")
+        files.append(((tmp_path / ("ok_%s.%s" % (name, ext)),), data))
+        for k in range(60):
+            b = bytearray(data)
+            mode = k % 4
+            if mode == 0:      # flip a few bytes anywhere
+                for _ in range(int(rs.integers(1, 6))):
+                    b[int(rs.integers(0, len(b)))] = int(rs.integers(0, 256))
+            elif mode == 1:    # corrupt the header region
+                for _ in range(int(rs.integers(1, 8))):
+                    b[int(rs.integers(0, min(len(b), 400)))] = int(rs.integers(0, 256))
+            elif mode == 2:    # truncate
+                b = b[:int(rs.integers(1, len(b)))]
+            else:              # overwrite a 4-byte field with an extreme value
+                at = int(rs.integers(0, max(1, len(b) - 4)))
+                b[at:at + 4] = [(0xff, 0xff, 0xff, 0x7f), (0xff, 0xff, 0xff, 0xff), (0, 0, 0, 0x80), (1, 0, 0, 0)][int(rs.integers(0, 4))]
+            files.append(((tmp_path / ("m_%s_%d.%s" % (name, k, ext)),), bytes(b)))
+    paths = []
+    for (p,), data in files:
+        open(p, "wb").write(data); paths.append(str(p))
+    env = dict(os.environ, ASAN_OPTIONS="detect_leaks=0:allocator_may_return_null=1", UBSAN_OPTIONS="print_stacktrace=1")
+    out = subprocess.run([str(exe)] + paths, capture_output=True, text=True, env=env, timeout=600)
+    assert out.returncode == 0, (out.stdout[-500:], out.stderr[-3000:])
+    assert "accepted" in out.stdout and int(out.stdout.split()[1]) >= len(seeds)     # the unmutated files all load
