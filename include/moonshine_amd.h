@@ -175,7 +175,8 @@ HdMoonshine* MsneCreate(const MsneConfig*);                       /* HdMoonshine
 
 /* MeshManager.upload (MeshManager.zig:70-156).  attribute_count = length of normals/texcoords:
  * position_count when the pipeline has indexed_attributes=true (glTF mode, world.hlsl:130),
- * index_count*3 when false (Hydra mode).  Negative on error. */
+ * index_count*3 when false (Hydra mode).  Indices are range-checked here; a render whose pipeline would read past
+ * attribute_count on a mesh some instance uses fails with an error instead of reading out of bounds.  Negative on error. */
 int64_t MsneCreateMesh(HdMoonshine*, const F32x3* positions, const F32x3* normals, const F32x2* texcoords,
                        size_t position_count, size_t attribute_count, const U32x3* indices, size_t index_count);
 /* TextureManager.upload with a .raw source (MaterialManager.zig:351-445) */

@@ -57,7 +57,7 @@ struct TextureH { uint32_t w, h; std::vector<float> rgba; };
 struct MeshH {
     DevBuf<float> positions, normals, texcoords; DevBuf<uint32_t> indices;
     std::vector<float> h_positions; std::vector<uint32_t> h_indices;   // host copies for the alias-table areas (Accel.zig:503-519)
-    uint32_t position_count = 0, attribute_count = 0, index_count = 0; bool has_normals = false, has_texcoords = false;
+    uint32_t position_count = 0, attribute_count = 0, index_count = 0, max_index = 0; bool has_normals = false, has_texcoords = false;
 };
 struct InstanceH { m34 transform; bool visible; std::vector<GeometryRec> geos; };
 struct BlasInfo { uint32_t root; float box[6]; uint32_t tris; };
@@ -520,6 +520,18 @@ bool HdMoonshine::readback(SensorH* s) {
 bool HdMoonshine::render(uint32_t sensor, uint32_t lens, uint32_t launches, bool do_readback) {
     if (sensor >= sensors.size() || lens >= lenses.size()) { fail("render: bad sensor or lens handle"); return false; }
     if (!ensure_scene()) return false;
+    // normals / texcoords are read by vertex index (indexed_attributes, the glTF path) or by corner = 3 * triangle + k (Hydra's
+    // face-varying path, world.hlsl:127-135): the array every referenced mesh handed over must cover what this pipeline reads
+    for (const InstanceH& in : instances) for (const GeometryRec& g : in.geos) {
+        const MeshH* m = meshes[g.mesh];
+        if (!m->has_normals && !m->has_texcoords) continue;
+        const uint64_t need = opts.indexed_attributes ? (uint64_t)m->max_index + 1u : 3ull * m->index_count;
+        if (m->attribute_count < need) {
+            fail("mesh " + std::to_string(g.mesh) + " has " + std::to_string(m->attribute_count) + " normals/texcoords, the pipeline (indexed_attributes = "
+                 + (opts.indexed_attributes ? "true" : "false") + ") reads " + std::to_string(need));
+            return false;
+        }
+    }
     SensorH* s = sensors[sensor];
     const size_t P = s->shard.pixels;
     const uint32_t spr = opts.samples_per_run;
@@ -699,8 +711,13 @@ int64_t MsneCreateMesh(HdMoonshine* c, const F32x3* positions, const F32x3* norm
     if (!c->bind()) return -1;
     if (!positions || !indices || position_count == 0 || index_count == 0) { c->fail("mesh: positions and indices are required"); return -1; }
     if ((normals || texcoords) && attribute_count == 0) { c->fail("mesh: attribute_count is zero"); return -1; }
-    for (size_t i = 0; i < index_count; i++) if (indices[i].x >= position_count || indices[i].y >= position_count || indices[i].z >= position_count) { c->fail("mesh: index out of range"); return -1; }
+    uint32_t max_index = 0;
+    for (size_t i = 0; i < index_count; i++) {
+        if (indices[i].x >= position_count || indices[i].y >= position_count || indices[i].z >= position_count) { c->fail("mesh: index out of range"); return -1; }
+        max_index = std::max(max_index, std::max(indices[i].x, std::max(indices[i].y, indices[i].z)));
+    }
     MeshH* m = new MeshH();
+    m->max_index = max_index;
     m->position_count = (uint32_t)position_count; m->attribute_count = (uint32_t)attribute_count; m->index_count = (uint32_t)index_count;
     m->has_normals = normals != nullptr; m->has_texcoords = texcoords != nullptr;
     bool ok = m->positions.alloc(3 * position_count) && m->indices.alloc(3 * index_count);

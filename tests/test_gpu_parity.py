@@ -456,3 +456,25 @@ def test_unsupported_pipeline_is_rejected_loudly(gpu_api):
         gc.create_material(scenes.LAMBERT, 999, 0)
     with pytest.raises(gpu_api.MoonshineError):
         gc.create_mesh(np.zeros((3, 3), np.float32), [[0, 1, 7]])
+
+
+@pytest.mark.gpu
+def test_attribute_arrays_must_cover_what_the_pipeline_reads(gpu_api):
+    """per-vertex normals (glTF layout) under the face-varying pipeline (Hydra's constants) would be read out of bounds:
+    MsneRender refuses instead"""
+    c = gpu_api.Context()
+    pos = np.array([[0, 0, 0], [1, 0, 0], [0, 1, 0], [1, 1, 0]], np.float32)
+    idx = np.array([[0, 1, 2], [2, 1, 3]], np.uint32)
+    nrm = np.tile(np.array([[0, 0, 1]], np.float32), (4, 1))
+    m = c.create_mesh(pos, idx, normals=nrm)
+    t0, t1 = c.solid_texture(0.5, 0.5), c.solid_texture(0.0, 0.0, 0.0)
+    mat = c.create_material(scenes.LAMBERT, t0, t1, color=c.solid_texture(0.8, 0.8, 0.8))
+    c.create_instance([(m, mat, False)])
+    s = c.create_sensor(16, 16)
+    l = c.create_lens(gpu_api.make_lens((0.5, 0.5, 3), (0, 0, -1), (0, 1, 0), 0.8))
+    c.set_pipeline(samples_per_run=1, max_bounces=2, env_samples_per_bounce=0, mesh_samples_per_bounce=0, indexed_attributes=True)
+    c.render(s, l)                                   # 4 normals, indices up to 3: fine
+    c.set_pipeline(samples_per_run=1, max_bounces=2, env_samples_per_bounce=0, mesh_samples_per_bounce=0, indexed_attributes=False)
+    with pytest.raises(gpu_api.MoonshineError, match="reads 6"):
+        c.render(s, l)
+    c.close()
