@@ -135,7 +135,7 @@ struct HdMoonshine {
     DevBuf<float4> d_lbuf;
     size_t lbuf_cap = 0;
     DevBuf<uint32_t> d_overflow; DevBuf<unsigned long long> d_trace_stats;
-    int trace_grid = 1024, shade_grid = 2048;
+    int trace_grid = 1024, shade_grid = 2048, shade_k_grid = 2048;
     uint32_t refill = 16;              // traversal: idle lanes (of 64) at which a wave refills from the ray queue; $MSNE_REFILL
     size_t max_inflight = 160u << 20;  // most paths traced concurrently (288 B of wavefront state each at one env + one mesh light sample, allocated on demand); $MSNE_MAX_INFLIGHT
     // statistics
@@ -584,7 +584,7 @@ bool HdMoonshine::render(uint32_t sensor, uint32_t lens, uint32_t launches, bool
             timed2(0, pp.s0, [&] { launch_trace_closest(pp.s0, trace_grid, trace_stats, sv, cur, hits, cnt + b, pp.spill.p, d_overflow.p, d_trace_stats.p, refill); });
             if (shadow_done) CHECK_HIP(this, hipStreamWaitEvent(pp.s0, shadow_done, 0));   // k_shade(b) consumes the results of k_trace_shadow(b-1)
             const ShadowQueue shq{ shq_f4, shq_f4 + qc, contrib[b & 1] };
-            timed2(2, pp.s0, [&] { launch_shade(pp.s0, shade_grid, sv, opts, cur, hits, nxt, shq, contrib[(b + 1) & 1], lbuf, cnt + b); });
+            timed2(2, pp.s0, [&] { launch_shade(pp.s0, shade_k_grid, sv, opts, cur, hits, nxt, shq, contrib[(b + 1) & 1], lbuf, cnt + b); });
             hipEvent_t shade_done = next_event();
             if (!shade_done) { fail("hipEventCreate failed"); return false; }
             CHECK_HIP(this, hipEventRecord(shade_done, pp.s0));
@@ -690,7 +690,8 @@ HdMoonshine* MsneCreate(const MsneConfig* cfg_in) {
     c->device = dev; c->cfg = cfg;
     if (hipSetDevice(dev) != hipSuccess || hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { g_create_error = "cannot create HIP stream"; delete c; return nullptr; }
     hipDeviceProp_t prop;
-    if (hipGetDeviceProperties(&prop, dev) == hipSuccess) { c->trace_grid = prop.multiProcessorCount * trace_blocks_per_cu(); c->shade_grid = prop.multiProcessorCount * 8; }
+    if (hipGetDeviceProperties(&prop, dev) == hipSuccess) { c->trace_grid = prop.multiProcessorCount * trace_blocks_per_cu(); c->shade_grid = prop.multiProcessorCount * 8; c->shade_k_grid = prop.multiProcessorCount * 96; }   // k_shade: workgroups differ in cost (what their 256 paths hit); 96 per CU instead of 8 evens the CUs out (-6 %)
+    if (const char* e = getenv("MSNE_SHADE_BLOCKS_PER_CU")) c->shade_k_grid = prop.multiProcessorCount * std::max(1, atoi(e));
     if (const char* e = getenv("MSNE_MAX_INFLIGHT")) c->max_inflight = (size_t)atoll(e);
     if (const char* e = getenv("MSNE_PIPES")) c->n_pipes = std::max(1, std::min((int)HdMoonshine::MAX_PIPES, atoi(e)));
     if (const char* e = getenv("MSNE_SINGLE_PIPE_PATHS")) c->single_pipe_paths = (size_t)atoll(e);
