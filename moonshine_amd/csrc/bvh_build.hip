@@ -354,6 +354,9 @@ __global__ void k_collapse(const CollapseWork* work, uint32_t nwork, CollapseWor
         if (i < 0) continue;
         for (int k = 0; k < 3; k++) {
             const float origin = k == 0 ? nd.ox : (k == 1 ? nd.oy : nd.oz);
+            // outward by at least 1e-3 quantum: a ray that runs exactly in a face plane of the TRUE box (axis-parallel, reciprocal
+            // +-1e30) then sees the quantised plane at +-(1e-3 * scale * 1e30), far above the ~1e-5 * scale * 1e30 rounding noise of
+            // q*a + b in the traversal; a child on the node's own lower face quantises to 0 and gives t = 0 exactly
             float ql = floorf((cb[i].lo[k] - origin) * inv_s[k] - 1e-3f);
             float qh = ceilf((cb[i].hi[k] - origin) * inv_s[k] + 1e-3f);
             ql = fminf(fmaxf(ql, 0.0f), 255.0f); qh = fminf(fmaxf(qh, 0.0f), 255.0f);

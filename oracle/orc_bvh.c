@@ -235,15 +235,18 @@ static inline int tri_intersect(v3 o, const orc_rayk *k, const orc_tri *tr, floa
 
 static inline float safe_inv(float d) { return fabsf(d) < 1e-30f ? (d < 0.0f ? -1e30f : 1e30f) : 1.0f / d; }
 
-/* slab test with a relative slack so equal-t candidates are never culled */
+/* Slab test that never culls a box holding a triangle the watertight test accepts (the hit record must not depend on the
+ * BVH).  Each axis interval is widened by 1e-5 of the larger of its two plane distances: that covers the rounding of
+ * (plane - o) * id, keeps equal-t candidates, and — the case a slack relative to t itself misses — a ray that runs exactly
+ * in a face plane of the box (direction component 0, id = +-1e30, origin on the plane: the interval is [-2e30, 0] or
+ * [0, 2e30] depending on which face) stays inside. */
 static inline int box_hit(const float lo[3], const float hi[3], v3 o, v3 id, float tmax, float *tnear) {
-    float t1 = (lo[0] - o.x) * id.x, t2 = (hi[0] - o.x) * id.x;
-    float tn = orc_minf(t1, t2), tf = orc_maxf(t1, t2);
-    t1 = (lo[1] - o.y) * id.y; t2 = (hi[1] - o.y) * id.y;
-    tn = orc_maxf(tn, orc_minf(t1, t2)); tf = orc_minf(tf, orc_maxf(t1, t2));
-    t1 = (lo[2] - o.z) * id.z; t2 = (hi[2] - o.z) * id.z;
-    tn = orc_maxf(tn, orc_minf(t1, t2)); tf = orc_minf(tf, orc_maxf(t1, t2));
-    tn = tn - fabsf(tn) * 1e-5f; tf = tf + fabsf(tf) * 1e-5f;
+    float t1 = (lo[0] - o.x) * id.x, t2 = (hi[0] - o.x) * id.x, e = 1e-5f * orc_maxf(fabsf(t1), fabsf(t2));
+    float tn = orc_minf(t1, t2) - e, tf = orc_maxf(t1, t2) + e;
+    t1 = (lo[1] - o.y) * id.y; t2 = (hi[1] - o.y) * id.y; e = 1e-5f * orc_maxf(fabsf(t1), fabsf(t2));
+    tn = orc_maxf(tn, orc_minf(t1, t2) - e); tf = orc_minf(tf, orc_maxf(t1, t2) + e);
+    t1 = (lo[2] - o.z) * id.z; t2 = (hi[2] - o.z) * id.z; e = 1e-5f * orc_maxf(fabsf(t1), fabsf(t2));
+    tn = orc_maxf(tn, orc_minf(t1, t2) - e); tf = orc_minf(tf, orc_maxf(t1, t2) + e);
     *tnear = tn;
     return tn <= tf && tf >= 0.0f && tn <= tmax;
 }

@@ -478,3 +478,46 @@ def test_attribute_arrays_must_cover_what_the_pipeline_reads(gpu_api):
     with pytest.raises(gpu_api.MoonshineError, match="reads 6"):
         c.render(s, l)
     c.close()
+
+
+@pytest.mark.gpu
+def test_coincident_triangles_edges_and_vertices(orc, gpu_api):
+    """collisions as this domain has them: the same triangles several times over — duplicated primitives in one mesh, two
+    geometries of one instance, two identity instances (merged into the world BLAS), one translated instance landing on the
+    same plane — so every hit is an exact tie that must go to the smallest (instance, geometry, primitive); and rays aimed at
+    shared edges, the diagonal and the vertices (the watertight test's own edge cases).  Hit records equal the oracle's."""
+    quad = np.array([[-1, -1, 0], [1, -1, 0], [1, 1, 0], [-1, 1, 0]], np.float32)
+    idx2 = np.array([[0, 1, 2], [0, 2, 3], [0, 1, 2], [0, 2, 3]], np.uint32)              # primitives 2, 3 repeat 0, 1
+    shifted = quad + np.array([0, 0, -2], np.float32)                                       # instance 2 moves it back by +2 in z
+    rays = []
+    g = np.linspace(-1.0, 1.0, 17, dtype=np.float32)                                        # includes the edges, the centre and x == y (the diagonal)
+    for x in g:
+        for y in g:
+            rays.append([x, y, 3.0, 0, 0, -1, 1e12])
+            rays.append([x, y, -2.5, 0, 0, 1, 1e12])                                        # from behind
+    rs = np.random.default_rng(5)
+    for _ in range(600):                                                                    # oblique rays through grid points of the quad
+        tx, ty = rs.choice(g), rs.choice(g)
+        o = np.array([rs.normal() * 2, rs.normal() * 2, 2.0 + rs.random() * 3], np.float32)
+        d = np.array([tx, ty, 0], np.float32) - o; d /= np.linalg.norm(d)
+        rays.append([*o, *d, 1e12])
+    rays = np.array(rays, np.float32)
+    ctxs = []
+    for c in (orc.Context(threads=8), gpu_api.Context()):
+        m0 = c.create_mesh(quad, idx2)
+        m1 = c.create_mesh(shifted, idx2[:2])
+        mat = c.create_material(scenes.LAMBERT, c.solid_texture(0.5, 0.5), c.solid_texture(0.0, 0.0, 0.0), color=c.solid_texture(0.8, 0.8, 0.8))
+        c.create_instance([(m0, mat, False), (m0, mat, False)])                             # instance 0: geometries 0 and 1 coincide
+        c.create_instance([(m0, mat, False)])                                               # instance 1: identity as well
+        T = np.eye(3, 4, dtype=np.float32); T[2, 3] = 2.0
+        c.create_instance([(m1, mat, False)], transform=T)                                  # instance 2: lands on z = 0 in world space
+        c.set_pipeline(samples_per_run=1, max_bounces=1, env_samples_per_bounce=0, mesh_samples_per_bounce=0)
+        s = c.create_sensor(8, 8); l = c.create_lens(c.make_lens((0, 0, 5), (0, 0, -1), (0, 1, 0), 0.5))
+        c.render(s, l)                                                                      # builds the acceleration structures
+        ctxs.append(c)
+    oc, gc = ctxs
+    _check_rays(oc, gc, rays)
+    ids, _ = gc.trace_rays(rays[:2 * 17 * 17], any_hit=False)
+    inside = ids[:, 0] == 1
+    assert inside.sum() >= 2 * 15 * 15                                                      # every interior grid ray hits ...
+    assert set(map(tuple, ids[inside][:, 1:4])) <= {(0, 0, 0), (0, 0, 1)}                   # ... and the tie goes to instance 0, geometry 0, primitive 0 or 1
