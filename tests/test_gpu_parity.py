@@ -521,3 +521,52 @@ def test_coincident_triangles_edges_and_vertices(orc, gpu_api):
     inside = ids[:, 0] == 1
     assert inside.sum() >= 2 * 15 * 15                                                      # every interior grid ray hits ...
     assert set(map(tuple, ids[inside][:, 1:4])) <= {(0, 0, 0), (0, 0, 1)}                   # ... and the tie goes to instance 0, geometry 0, primitive 0 or 1
+
+
+def _edge_scene(ctx, scale, extent=(64, 48)):
+    """a small lit scene with what real assets contain: zero-area triangles (repeated vertex, collinear vertices) inside
+    ordinary meshes AND inside the sampled emitter (alias-table weight 0), a mirrored (negative-determinant) and a
+    non-uniformly scaled instance, everything multiplied by `scale`"""
+    S = np.float32(scale)
+    normal = ctx.solid_texture(0.5, 0.5); black = ctx.solid_texture(0.0, 0.0, 0.0)
+    grey = ctx.create_material(scenes.LAMBERT, normal, black, color=ctx.solid_texture(0.7, 0.7, 0.7))
+    gold = ctx.create_material(scenes.STANDARD_PBR, normal, black, color=ctx.solid_texture(0.9, 0.7, 0.3), metalness=ctx.solid_texture(1.0), roughness=ctx.solid_texture(0.3))
+    glass = ctx.create_material(scenes.GLASS, normal, black, ior=1.5)
+    light = ctx.create_material(scenes.LAMBERT, normal, ctx.solid_texture(20.0, 18.0, 15.0), color=black)
+    P, I = scenes.icosphere(2)
+    # degenerate triangles appended to the sphere: a repeated vertex, three collinear vertices, three identical vertices
+    Pd = np.concatenate([P, np.array([[0, 0, 2], [0, 0, 3], [0, 0, 4]], np.float32)])
+    n0 = len(P)
+    Id = np.concatenate([I, np.array([[0, 0, 1], [n0, n0 + 1, n0 + 2], [5, 5, 5]], np.uint32)])
+    sphere = ctx.create_mesh(Pd * S, Id)
+    fp, fi = scenes.quad((-6, -6, -1), (6, -6, -1), (6, 6, -1), (-6, 6, -1))
+    floor = ctx.create_mesh(fp * S, fi)
+    lp, li = scenes.quad((-1, -1, 4), (-1, 1, 4), (1, 1, 4), (1, -1, 4))
+    lp = np.concatenate([lp, np.array([[0.5, 0.5, 4], [0.5, 0.5, 4], [2, 2, 4]], np.float32)])      # + a zero-area emissive triangle
+    li = np.concatenate([li, np.array([[4, 5, 6]], np.uint32)])
+    lamp = ctx.create_mesh(lp * S, li)
+    def T(m3, t):
+        out = np.zeros((3, 4), np.float32); out[:, :3] = m3; out[:, 3] = np.asarray(t, np.float32) * S
+        return out
+    ctx.create_instance([(floor, grey, False)])
+    ctx.create_instance([(lamp, light, True)])
+    ctx.create_instance([(sphere, gold, False)], transform=T(np.eye(3), (-2.2, 0, 0)))
+    ctx.create_instance([(sphere, glass, False)], transform=T(np.diag([-1.0, 1.0, 1.0]), (0, 0.3, 0)))                 # mirrored
+    ctx.create_instance([(sphere, grey, False)], transform=T(np.diag([0.5, 1.5, 0.75]) @ scenes._rot((0, 0, 1), 0.6)[:3, :3], (2.3, -0.2, 0)))
+    ctx.set_background(np.array([0.3, 0.35, 0.5, 1], np.float32), 1, 1)
+    lens = ctx.create_lens(ctx.make_lens((0, -9 * S, 2.5 * S), (0, 1, -0.2), (0, 0, 1), 0.7, 0.0, 1.0))
+    return ctx.create_sensor(*extent), lens
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("scale", [1.0, 1.0e4, 1.0e-3])
+def test_degenerate_triangles_mirrored_instances_and_scales(orc, gpu_api, scale):
+    oc, so, lo, gc, sg, lg = both(orc, gpu_api, _edge_scene, scale=scale)
+    for c in (oc, gc):
+        c.set_pipeline(samples_per_run=1, max_bounces=6, env_samples_per_bounce=1, mesh_samples_per_bounce=2)
+    gc.render(sg, lg, launches=4); oc.render(so, lo, launches=4)
+    assert_film_equal(gc.sensor_data(sg), oc.sensor_data(so), "edge scene x%g" % scale)
+    assert gc.counters() == {k: v for k, v in oc.counters().items() if k in ("closest_rays", "shadow_rays", "samples")}
+    rays = _random_rays(1500, 9, radius=8.0)
+    rays[:, :3] *= np.float32(scale)                      # same directions, origins in the scaled scene
+    _check_rays(oc, gc, rays)
