@@ -137,7 +137,7 @@ void orc_build_blas(OrcContext *c, orc_bvh *out, const uint32_t *mesh_ids, uint3
     uint32_t total = 0;
     for (uint32_t g = 0; g < ngeo; g++) total += c->meshes[mesh_ids[g]].index_count;
     orc_tri *tris = (orc_tri *)malloc(sizeof(orc_tri) * (total ? total : 1));
-    aabb *boxes = (aabb *)malloc(sizeof(aabb) * (total ? total : 1));
+    aabb *boxes = (aabb *)calloc(total ? total : 1, sizeof(aabb));
     uint32_t k = 0;
     for (uint32_t g = 0; g < ngeo; g++) {
         const orc_mesh *m = &c->meshes[mesh_ids[g]];
