@@ -8,7 +8,7 @@ import torch  # noqa
 from moonshine_amd import api, scenes
 
 quick = "--quick" in sys.argv
-tile = int(sys.argv[sys.argv.index("--tile") + 1]) if "--tile" in sys.argv else 64
+tile = int(sys.argv[sys.argv.index("--tile") + 1]) if "--tile" in sys.argv else 0   # 0 = the library default (16)
 out = {}
 for G in (1, 2, 4, 8):
     per_rank = []
