@@ -16,8 +16,9 @@
 //  * every leaf holds one triangle; the hit leaves of a node form a triangle group {item base, hit bits | leaf mask}, two
 //    of which can wait per lane: node traversal runs ahead of the triangle tests (one per iteration), so both bodies
 //    run with more lanes; a node visited with a not yet shortened ray costs a few extra visits, never a wrong result;
-//  * entering / leaving an instance costs no extra iteration (the BLAS root is visited in the iteration that enters,
-//    the TLAS group below the sentinel is popped in the iteration that leaves).
+//  * entering and leaving an instance share one "space body" (reload the world-space ray, transform, shear constants) that a
+//    wave runs when SPACE_MIN_LANES lanes wait for it or nothing else can be done; the BLAS root is visited, and the TLAS group
+//    below the sentinel popped, in the iteration after.  Scenes without a TLAS level run an instantiation without any of it.
 // Box tests use fmaf and a relative slack (they only gate which triangles are tested); the triangle test is
 // the watertight Woop–Benthin–Wald test evaluated op-for-op like the test oracle, and equal-t ties resolve
 // to the smallest (instance, geometry, primitive), so results do not depend on BVH shape or visit order.
@@ -29,9 +30,13 @@ constexpr int TRACE_BLOCK = 256;
 #ifndef TRACE_WPS
 #define TRACE_WPS 6          // resident waves per SIMD the trace kernels are register-allocated for (= blocks of 256 per CU)
 #endif
+#ifndef TRACE_SPACE_MIN_LANES
+#define TRACE_SPACE_MIN_LANES 16   // lanes that must wait for a change of space (instance entry / exit) before the wave runs that body
+#endif
 #ifndef TRACE_STACK_LDS
 #define TRACE_STACK_LDS 12
 #endif
+constexpr uint32_t SPACE_MIN_LANES = TRACE_SPACE_MIN_LANES;
 constexpr int STACK_LDS = TRACE_STACK_LDS;   // group entries per lane kept in LDS (2 words each); 6 x (24 KB + 2 KB table) fit the CU's 160 KB
 constexpr int STACK_SPILL = 128 - STACK_LDS; // further entries per lane in HBM (2 words each)
 constexpr uint32_t GRP_NODE = 0u, GRP_INST = 1u << 16, GRP_SENTINEL = 2u << 16, GRP_KIND_MASK = 3u << 16;
@@ -225,33 +230,6 @@ __device__ __forceinline__ bool step_tri(Lane& L, const SceneView& sc, unsigned 
     return false;
 }
 
-// TLAS leaf: enter the instance's BLAS in instance space (t is preserved: d is not renormalised).  The ray is
-// restored when the sentinel entry pushed here is popped.  Returns the BLAS root (visited in the same iteration), or
-// MAX_UINT when there is nothing to enter.
-template <class Load>
-__device__ __forceinline__ uint32_t step_inst(Lane& L, const SceneView& sc, const StackRef& S, uint32_t item, uint32_t my, Load load) {
-    const uint32_t ii = sc.tlas_items[item];
-    const InstanceRec* ir = sc.instances + ii;
-    const uint32_t root = ir->blas_root, flags = ir->flags;
-    if (!(flags & INST_FLAG_VISIBLE) || root == MAX_UINT) return MAX_UINT;
-    if (flags & INST_FLAG_IDENTITY) {
-        lane_push(L, S, 0u, GRP_SENTINEL);   // identity transform: M·(o,1) = o and M·d = d exactly, the ray is left as is
-    } else {
-        const float4* mp = reinterpret_cast<const float4*>(&ir->world_to_instance);
-        const float4 r0 = mp[0], r1 = mp[1], r2 = mp[2];
-        m34 M;
-        M.m[0][0] = r0.x; M.m[0][1] = r0.y; M.m[0][2] = r0.z; M.m[0][3] = r0.w;
-        M.m[1][0] = r1.x; M.m[1][1] = r1.y; M.m[1][2] = r1.z; M.m[1][3] = r1.w;
-        M.m[2][0] = r2.x; M.m[2][1] = r2.y; M.m[2][2] = r2.z; M.m[2][3] = r2.w;
-        f3 o, d; float tmax;
-        (void)load(my, o, d, tmax);   // the world-space ray is not kept in registers
-        lane_set_space(L, m34_mul_point(M, o), m34_mul_vec(M, d));
-        lane_push(L, S, 1u, GRP_SENTINEL);
-    }
-    L.in_blas = true; L.cur_inst = (flags & INST_FLAG_WORLD) ? WORLD_INSTANCE : ii;
-    return root;
-}
-
 // ---------------------------------------------------------------------------------------------
 // Persistent-wave dequeue.  One device-scope atomic word saturates at ~88 dequeues/us on MI355X
 // (MI355X_MICROARCH.md "dequeue"), so (1) every wave's FIRST chunk is static (wave w takes chunk w: an
@@ -313,7 +291,9 @@ __device__ __forceinline__ void order_table_init(uint8_t* lut) {
 
 // Wave loop shared by the three kernels.  `load(i, o, d, tmax)` returns false for entries without a ray;
 // `store(i, lane)` receives the finished lane.
-template <bool ANY_HIT, bool STATS, class Load, class Store>
+// INSTANCED = the scene has a TLAS level.  Without one (sc.root_in_blas: the world BLAS is the root) no lane ever changes space,
+// and that instantiation carries none of the space-body bookkeeping (measured on S1: the shared code cost 7 %).
+template <bool ANY_HIT, bool STATS, bool INSTANCED, class Load, class Store>
 __device__ __forceinline__ void trace_wave_loop(const SceneView& sc, uint32_t n, uint32_t* head, uint32_t* lds_stack, const uint8_t* lut, uint32_t* spill, uint32_t* overflow,
                                                 uint32_t refill /* idle lanes of 64 that trigger a refill from the ray queue */, Load load, Store store, unsigned long long& nv, unsigned long long& nt, unsigned long long* prof,
                                                 uint32_t* rays_traced = nullptr /* += queue entries that held a ray */) {
@@ -343,8 +323,8 @@ __device__ __forceinline__ void trace_wave_loop(const SceneView& sc, uint32_t n,
                 lane_pop(L, S);
                 if (__builtin_expect((L.g1 & GRP_KIND_MASK) == GRP_SENTINEL, 0)) {   // leaving an instance: back to the world-space ray
                     if (has_t) { L.sp++; L.g1 = 0u; }   // ... but only once the triangles queued in instance space are done: un-pop
+                    else if (L.g0 & 1u) L.g1 = GRP_SENTINEL | 1u;   // the world-space ray has to be restored: in the space body of (c), with the lanes that enter instances
                     else {
-                        if (L.g0 & 1u) { f3 o, d; float tmax; (void)load(my, o, d, tmax); lane_set_space(L, o, d); }
                         L.in_blas = false; L.g1 = 0u;
                         if (L.sp == L.sb) { if (ANY_HIT || L.own == lane) { store(my, L); active = false; } }   // (sentinels only exist on owners' own stacks below sb... see (b'))
                         else lane_pop(L, S);   // what lies under a sentinel is a TLAS-level group (two levels only), never another sentinel
@@ -441,14 +421,59 @@ __device__ __forceinline__ void trace_wave_loop(const SceneView& sc, uint32_t n,
         // may run ahead of the triangle tests by two nodes' worth of hit leaves; visiting nodes with a not yet shortened
         // ray is conservative (a few extra visits), results do not change.
         const bool want_t = active && (L.ta1 & 0xffu);
-        const bool want_n = active && (L.g1 & 0xffu) && !(L.tb1 & 0xffu);
+        const bool has_g = active && (L.g1 & 0xffu);
+        const bool want_n = has_g && (!INSTANCED || (L.g1 & GRP_KIND_MASK) == GRP_NODE) && !(L.tb1 & 0xffu);
+        const bool want_s = INSTANCED && has_g && (L.g1 & GRP_KIND_MASK) != GRP_NODE;   // enters an instance (GRP_INST) or leaves one (GRP_SENTINEL | 1): the ray changes space
         const bool do_n = __ballot(want_n) != 0ull, do_t = __ballot(want_t) != 0ull;
+        // Changing space costs ~250 instructions (reload the world-space ray, transform, three IEEE divisions for the shear constants)
+        // and few lanes need it in any one iteration: entering and leaving share one body, and it runs when enough lanes wait for
+        // it or nothing else can be done.
+        const unsigned long long ms = INSTANCED ? __ballot(want_s) : 0ull;
+        const bool do_s = INSTANCED && ms != 0ull && ((uint32_t)__popcll(ms) >= SPACE_MIN_LANES || (!do_n && !do_t));
         lap(2);
+        if (INSTANCED && do_s && want_s) {
+            const bool enter = (L.g1 & GRP_KIND_MASK) == GRP_INST;
+            bool need_ray = !enter;
+            uint32_t root = MAX_UINT, new_inst = 0u;
+            float4 r0 = make_float4(1.0f, 0.0f, 0.0f, 0.0f), r1 = make_float4(0.0f, 1.0f, 0.0f, 0.0f), r2 = make_float4(0.0f, 0.0f, 1.0f, 0.0f);
+            if (enter) {   // TLAS leaf (one instance of the group; the rest of the group goes back on the stack)
+                const uint32_t item = group_take(L, S, lut);
+                const uint32_t ii = sc.tlas_items[item];
+                const InstanceRec* ir = sc.instances + ii;
+                const uint32_t flags = ir->flags;
+                root = ir->blas_root;
+                if (!(flags & INST_FLAG_VISIBLE)) root = MAX_UINT;
+                new_inst = (flags & INST_FLAG_WORLD) ? WORLD_INSTANCE : ii;
+                if (root != MAX_UINT) {
+                    if (flags & INST_FLAG_IDENTITY) lane_push(L, S, 0u, GRP_SENTINEL);   // M·(o,1) = o and M·d = d exactly: the ray is left as is
+                    else {
+                        const float4* mp = reinterpret_cast<const float4*>(&ir->world_to_instance);
+                        r0 = mp[0]; r1 = mp[1]; r2 = mp[2];
+                        lane_push(L, S, 1u, GRP_SENTINEL);
+                        need_ray = true;
+                    }
+                }
+            }
+            if (need_ray) {   // the world-space ray is not kept in registers
+                f3 o, d; float tmax;
+                (void)load(my, o, d, tmax);
+                if (enter) {   // t is preserved: d is not renormalised
+                    m34 M;
+                    M.m[0][0] = r0.x; M.m[0][1] = r0.y; M.m[0][2] = r0.z; M.m[0][3] = r0.w;
+                    M.m[1][0] = r1.x; M.m[1][1] = r1.y; M.m[1][2] = r1.z; M.m[1][3] = r1.w;
+                    M.m[2][0] = r2.x; M.m[2][1] = r2.y; M.m[2][2] = r2.z; M.m[2][3] = r2.w;
+                    const f3 oi = m34_mul_point(M, o), di = m34_mul_vec(M, d);
+                    o = oi; d = di;
+                }
+                lane_set_space(L, o, d);
+            }
+            if (enter) {
+                if (root != MAX_UINT) { L.in_blas = true; L.cur_inst = new_inst; L.g0 = root; L.g1 = GRP_NODE | 0x0101u; }   // a group of one: the BLAS root
+            } else { L.in_blas = false; L.g1 = 0u; }   // the TLAS group under the sentinel is popped in (a)
+        }
         if (do_n && want_n) {
-            const uint32_t kind = L.g1 & GRP_KIND_MASK;
-            uint32_t idx = group_take(L, S, lut);
-            if (__builtin_expect(kind == GRP_INST, 0)) idx = step_inst(L, sc, S, idx, my, load);   // then straight into the BLAS root
-            if (idx != MAX_UINT) step_node<STATS>(L, sc, S, idx, nv);
+            const uint32_t idx = group_take(L, S, lut);
+            step_node<STATS>(L, sc, S, idx, nv);
         }
         lap(3);
         if (STATS && do_n) cyc[6] += __popcll(__ballot(want_n));   // node-lane steps
@@ -470,13 +495,13 @@ __device__ __forceinline__ void trace_wave_loop(const SceneView& sc, uint32_t n,
     __shared__ uint8_t lds_lut[2048]; \
     order_table_init(lds_lut)
 
-template <bool STATS>
+template <bool STATS, bool INSTANCED>
 __global__ __launch_bounds__(TRACE_BLOCK, TRACE_WPS) void k_trace_closest(SceneView sc, PathState st, HitBuf hits, BounceCounters* cnt,
                                                                 uint32_t* spill, uint32_t* overflow, unsigned long long* stat_out, uint32_t refill) {
     TRACE_LDS_DECL;
     const uint32_t n = cnt->n_paths;
     unsigned long long nv = 0, nt = 0;
-    trace_wave_loop<false, STATS>(sc, n, &cnt->head_closest, lds_stack, lds_lut, spill, overflow, refill,
+    trace_wave_loop<false, STATS, INSTANCED>(sc, n, &cnt->head_closest, lds_stack, lds_lut, spill, overflow, refill,
         [&](uint32_t i, f3& o, f3& d, float& tmax) -> bool {
             const float4 ro = st.ro[i];
             if (f2u(ro.w) & PATH_FLAG_ZOMBIE) return false;
@@ -490,13 +515,13 @@ __global__ __launch_bounds__(TRACE_BLOCK, TRACE_WPS) void k_trace_closest(SceneV
     if (STATS) { atomicAdd(&stat_out[0], nv); atomicAdd(&stat_out[1], nt); }
 }
 
-template <bool STATS>
+template <bool STATS, bool INSTANCED>
 __global__ __launch_bounds__(TRACE_BLOCK, TRACE_WPS) void k_trace_shadow(SceneView sc, ShadowQueue q, BounceCounters* cnt,
                                                                uint32_t* spill, uint32_t* overflow, unsigned long long* stat_out, uint32_t refill) {
     TRACE_LDS_DECL;
     const uint32_t n = cnt->n_shadow_in;
     unsigned long long nv = 0, nt = 0;
-    trace_wave_loop<true, STATS>(sc, n, &cnt->head_shadow, lds_stack, lds_lut, spill, overflow, refill,
+    trace_wave_loop<true, STATS, INSTANCED>(sc, n, &cnt->head_shadow, lds_stack, lds_lut, spill, overflow, refill,
         [&](uint32_t i, f3& o, f3& d, float& tmax) -> bool {
             const float4 qo = q.o[i], qd = q.d[i];
             if (qo.w < 0.0f) return false;   // unused entry
@@ -517,7 +542,7 @@ __global__ __launch_bounds__(TRACE_BLOCK, TRACE_WPS) void k_trace_probe(SceneVie
                                                               uint32_t* spill, uint32_t* overflow, uint32_t refill) {
     TRACE_LDS_DECL;
     unsigned long long nv = 0, nt = 0;
-    trace_wave_loop<ANY_HIT, false>(sc, n, head, lds_stack, lds_lut, spill, overflow, refill,
+    trace_wave_loop<ANY_HIT, false, true>(sc, n, head, lds_stack, lds_lut, spill, overflow, refill,
         [&](uint32_t i, f3& o, f3& d, float& tmax) -> bool {
             const float* r = rays + 7 * (size_t)i;
             o = F3(r[0], r[1], r[2]); d = F3(r[3], r[4], r[5]); tmax = r[6];
@@ -539,13 +564,19 @@ __global__ __launch_bounds__(TRACE_BLOCK, TRACE_WPS) void k_trace_probe(SceneVie
 // ---------------- host launch wrappers ----------------
 void launch_trace_closest(hipStream_t s, int grid, bool stats, const SceneView& sc, const PathState& st, const HitBuf& hits, BounceCounters* cnt,
                           uint32_t* spill, uint32_t* overflow, unsigned long long* stat_out, uint32_t refill) {
-    if (stats) hipLaunchKernelGGL(k_trace_closest<true>, dim3(grid), dim3(TRACE_BLOCK), 0, s, sc, st, hits, cnt, spill, overflow, stat_out, refill);
-    else hipLaunchKernelGGL(k_trace_closest<false>, dim3(grid), dim3(TRACE_BLOCK), 0, s, sc, st, hits, cnt, spill, overflow, stat_out, refill);
+    const bool inst = sc.root_in_blas == 0u;   // a TLAS level exists
+    if (stats) { if (inst) hipLaunchKernelGGL((k_trace_closest<true, true>), dim3(grid), dim3(TRACE_BLOCK), 0, s, sc, st, hits, cnt, spill, overflow, stat_out, refill);
+                 else hipLaunchKernelGGL((k_trace_closest<true, false>), dim3(grid), dim3(TRACE_BLOCK), 0, s, sc, st, hits, cnt, spill, overflow, stat_out, refill); }
+    else { if (inst) hipLaunchKernelGGL((k_trace_closest<false, true>), dim3(grid), dim3(TRACE_BLOCK), 0, s, sc, st, hits, cnt, spill, overflow, stat_out, refill);
+           else hipLaunchKernelGGL((k_trace_closest<false, false>), dim3(grid), dim3(TRACE_BLOCK), 0, s, sc, st, hits, cnt, spill, overflow, stat_out, refill); }
 }
 void launch_trace_shadow(hipStream_t s, int grid, bool stats, const SceneView& sc, const ShadowQueue& q, BounceCounters* cnt,
                          uint32_t* spill, uint32_t* overflow, unsigned long long* stat_out, uint32_t refill) {
-    if (stats) hipLaunchKernelGGL(k_trace_shadow<true>, dim3(grid), dim3(TRACE_BLOCK), 0, s, sc, q, cnt, spill, overflow, stat_out, refill);
-    else hipLaunchKernelGGL(k_trace_shadow<false>, dim3(grid), dim3(TRACE_BLOCK), 0, s, sc, q, cnt, spill, overflow, stat_out, refill);
+    const bool inst = sc.root_in_blas == 0u;
+    if (stats) { if (inst) hipLaunchKernelGGL((k_trace_shadow<true, true>), dim3(grid), dim3(TRACE_BLOCK), 0, s, sc, q, cnt, spill, overflow, stat_out, refill);
+                 else hipLaunchKernelGGL((k_trace_shadow<true, false>), dim3(grid), dim3(TRACE_BLOCK), 0, s, sc, q, cnt, spill, overflow, stat_out, refill); }
+    else { if (inst) hipLaunchKernelGGL((k_trace_shadow<false, true>), dim3(grid), dim3(TRACE_BLOCK), 0, s, sc, q, cnt, spill, overflow, stat_out, refill);
+           else hipLaunchKernelGGL((k_trace_shadow<false, false>), dim3(grid), dim3(TRACE_BLOCK), 0, s, sc, q, cnt, spill, overflow, stat_out, refill); }
 }
 void launch_trace_probe(hipStream_t s, int grid, const SceneView& sc, const float* rays, uint32_t n, int any_hit, uint32_t* head, uint32_t* out_ids, float* out_tuv,
                         uint32_t* spill, uint32_t* overflow, uint32_t refill) {
