@@ -469,14 +469,20 @@ __device__ __forceinline__ void trace_wave_loop(const SceneView& sc, uint32_t n,
             }
             if (enter) {
                 if (root != MAX_UINT) { L.in_blas = true; L.cur_inst = new_inst; L.g0 = root; L.g1 = GRP_NODE | 0x0101u; }   // a group of one: the BLAS root
-            } else { L.in_blas = false; L.g1 = 0u; }   // the TLAS group under the sentinel is popped in (a)
+            } else {   // back in world space: take the TLAS group under the sentinel right away (a ray with nothing left is finished in (a))
+                L.in_blas = false; L.g1 = 0u;
+                if (L.sp != L.sb) lane_pop(L, S);   // a TLAS-level group (two levels only), never another sentinel
+            }
         }
-        if (do_n && want_n) {
+        // lanes that just entered hold their BLAS root, lanes that just left hold a TLAS group: they visit it in this iteration
+        const bool want_n2 = INSTANCED && do_s ? (active && (L.g1 & 0xffu) && (L.g1 & GRP_KIND_MASK) == GRP_NODE && !(L.tb1 & 0xffu)) : want_n;
+        const bool do_n2 = INSTANCED && do_s ? __ballot(want_n2) != 0ull : do_n;
+        if (do_n2 && want_n2) {
             const uint32_t idx = group_take(L, S, lut);
             step_node<STATS>(L, sc, S, idx, nv);
         }
         lap(3);
-        if (STATS && do_n) cyc[6] += __popcll(__ballot(want_n));   // node-lane steps
+        if (STATS && do_n2) cyc[6] += __popcll(__ballot(want_n2));   // node-lane steps
         if (do_t && want_t) {
             if (step_tri<ANY_HIT, STATS>(L, sc, nt)) { L.sp = 0; L.sb = 0; L.g1 = 0; L.ta1 = 0; L.tb1 = 0; store(my, L); active = false; }
         }
