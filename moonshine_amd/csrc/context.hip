@@ -326,7 +326,7 @@ bool HdMoonshine::rebuild_accel() {
         std::vector<BlasGeo> bg; uint32_t off = 0, g = 0;
         for (uint32_t m : keys[i]) { bg.push_back(BlasGeo{ meshes[m]->positions.p, meshes[m]->indices.p, off, meshes[m]->index_count, g++, 0u }); off += meshes[m]->index_count; }
         BlasInfo info{}; info.tris = off;
-        if (!bvh_build_blas(stream, bg, off, d_nodes.p, d_build_counters.p, (uint32_t)d_nodes.n, d_tris.p, d_build_counters.p + 1, d_item_src.p, &info.root, info.box)) { fail("BLAS build failed (non-finite vertex positions, or out of node memory: see stderr)"); return false; }
+        if (!bvh_build_blas(stream, bg, off, d_nodes.p, d_build_counters.p, (uint32_t)d_nodes.n, d_tris.p, d_build_counters.p + 1, d_item_src.p, &info.root, info.box)) { fail("BLAS build failed (details on stderr)"); return false; }
         blas_cache[keys[i]] = info;
     }
     if (!world_key.empty() && !blas_cache.count(world_key)) {
@@ -337,7 +337,7 @@ bool HdMoonshine::rebuild_accel() {
             for (uint32_t m : keys[i]) { bg.push_back(BlasGeo{ meshes[m]->positions.p, meshes[m]->indices.p, off, meshes[m]->index_count, g++, (uint32_t)i }); off += meshes[m]->index_count; }
         }
         BlasInfo info{}; info.tris = off;
-        if (!bvh_build_blas(stream, bg, off, d_nodes.p, d_build_counters.p, (uint32_t)d_nodes.n, d_tris.p, d_build_counters.p + 1, d_item_src.p, &info.root, info.box)) { fail("world BLAS build failed (non-finite vertex positions, or out of node memory: see stderr)"); return false; }
+        if (!bvh_build_blas(stream, bg, off, d_nodes.p, d_build_counters.p, (uint32_t)d_nodes.n, d_tris.p, d_build_counters.p + 1, d_item_src.p, &info.root, info.box)) { fail("world BLAS build failed (details on stderr)"); return false; }
         blas_cache[world_key] = info;
     }
     { uint32_t c[2]; CHECK_HIP(this, hipMemcpy(c, d_build_counters.p, 8, hipMemcpyDeviceToHost)); blas_nodes_end = c[0]; blas_tris_end = c[1]; }
@@ -388,7 +388,7 @@ bool HdMoonshine::rebuild_accel() {
     if (ids.size() == 1 && ids[0] == (uint32_t)N) {
         tlas_root = irec[N].blas_root; root_in_blas = 1;     // nothing but static geometry: traversal starts inside the world BLAS
         const uint32_t zero = 0; CHECK_HIP(this, hipMemcpyAsync(d_build_counters.p + 2, &zero, 4, hipMemcpyHostToDevice, stream));
-    } else if (!bvh_build_tlas(stream, boxes.data(), ids.data(), (uint32_t)ids.size(), d_nodes.p, d_build_counters.p, (uint32_t)d_nodes.n, d_tlas_items.p, d_build_counters.p + 2, d_item_src.p, &tlas_root)) { fail("TLAS build failed (non-finite instance transforms, or out of node memory: see stderr)"); return false; }
+    } else if (!bvh_build_tlas(stream, boxes.data(), ids.data(), (uint32_t)ids.size(), d_nodes.p, d_build_counters.p, (uint32_t)d_nodes.n, d_tlas_items.p, d_build_counters.p + 2, d_item_src.p, &tlas_root)) { fail("TLAS build failed (details on stderr)"); return false; }
 
     // emissive-triangle alias table (Accel.zig:491-539): entry 0 = {count, sum of areas}
     std::vector<float> w; h_alias.assign(1, AliasEntry{ 0u, 0.0f, 0u, 0u, 0u });

@@ -570,3 +570,25 @@ def test_degenerate_triangles_mirrored_instances_and_scales(orc, gpu_api, scale)
     rays = _random_rays(1500, 9, radius=8.0)
     rays[:, :3] *= np.float32(scale)                      # same directions, origins in the scaled scene
     _check_rays(oc, gc, rays)
+
+
+@pytest.mark.gpu
+def test_triangles_with_a_nan_vertex_are_inactive(orc, gpu_api):
+    """a NaN vertex position makes its triangles inactive (never hit), as in the Vulkan acceleration-structure rules the reference
+    relies on; everything else renders as usual and equals the oracle"""
+    def build(c, extent=(48, 36)):
+        P, I = scenes.icosphere(2)
+        P = P.copy(); P[7, 1] = np.nan
+        m = c.create_mesh(P, I)
+        mat = c.create_material(scenes.LAMBERT, c.solid_texture(0.5, 0.5), c.solid_texture(0.0, 0.0, 0.0), color=c.solid_texture(0.8, 0.8, 0.8))
+        c.create_instance([(m, mat, False)])
+        c.set_background(np.array([0.6, 0.7, 0.9, 1], np.float32), 1, 1)
+        return c.create_sensor(*extent), c.create_lens(c.make_lens((0, -4, 0), (0, 1, 0), (0, 0, 1), 0.6))
+    oc, so, lo, gc, sg, lg = both(orc, gpu_api, build)
+    for c in (oc, gc):
+        c.set_pipeline(samples_per_run=1, max_bounces=3, env_samples_per_bounce=1, mesh_samples_per_bounce=0)
+    gc.render(sg, lg, launches=4); oc.render(so, lo, launches=4)
+    g = gc.sensor_data(sg)
+    assert np.isfinite(g).all()
+    assert_film_equal(g, oc.sensor_data(so), "NaN vertex")
+    _check_rays(oc, gc, _random_rays(800, 4))
