@@ -25,10 +25,14 @@ def _stale(out, deps):
     return not os.path.exists(out) or any(os.path.getmtime(d) > os.path.getmtime(out) for d in deps)
 
 
-def build(force=False, verbose=False):
+def build(force=False, verbose=False, variant=None, extra_flags=()):
+    """variant: build a second library libmoonshine_amd_<variant>.so with extra compiler flags (tests use it to run the
+    traversal with a one-entry LDS stack, i.e. through the HBM spill path); the default build is untouched."""
+    lib = LIB if variant is None else os.path.join(HERE, "libmoonshine_amd_%s.so" % variant)
+    flags = list(extra_flags) + FLAGS
     api_h = os.path.join(HERE, "..", "include", "moonshine_amd.h")
     hdrs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")] + [api_h]
-    objdir = os.path.join(HERE, "build")
+    objdir = os.path.join(HERE, "build" if variant is None else "build_" + variant)
     os.makedirs(objdir, exist_ok=True)
     objs, procs = [], []
     for src in SOURCES:
@@ -36,7 +40,7 @@ def build(force=False, verbose=False):
         o = os.path.join(objdir, src.replace(".hip", ".o"))
         objs.append(o)
         if force or _stale(o, [s] + hdrs):
-            cmd = [HIPCC] + FLAGS + ["-c", s, "-o", o]
+            cmd = [HIPCC] + flags + ["-c", s, "-o", o]
             if verbose:
                 print(" ".join(cmd))
             procs.append((src, subprocess.Popen(cmd)))
@@ -52,8 +56,10 @@ def build(force=False, verbose=False):
     for src, p in procs:
         if p.wait() != 0:
             raise RuntimeError("compile failed on %s" % src)
-    if force or procs or _stale(LIB, objs):
-        subprocess.check_call([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs + ["-lz"])
+    if force or procs or _stale(lib, objs):
+        subprocess.check_call([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib] + objs + ["-lz"])
+    if variant is not None:
+        return lib
     cli = os.path.join(HOST, "offline.cpp")
     if force or _stale(OFFLINE, [cli, LIB, api_h]):
         subprocess.check_call([CXX] + HOST_FLAGS + ["-o", OFFLINE, cli, "-L" + HERE, "-lmoonshine_amd", "-Wl,-rpath,$ORIGIN", "-Wl,-rpath-link," + os.path.join(os.environ.get("ROCM_PATH", "/opt/rocm"), "lib")])

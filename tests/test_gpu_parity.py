@@ -592,3 +592,38 @@ def test_triangles_with_a_nan_vertex_are_inactive(orc, gpu_api):
     assert np.isfinite(g).all()
     assert_film_equal(g, oc.sensor_data(so), "NaN vertex")
     _check_rays(oc, gc, _random_rays(800, 4))
+
+
+SPILL_WORKER = r'''
+import sys
+sys.path.insert(0, sys.argv[1])
+import numpy as np
+from moonshine_amd import api, scenes
+api.LIB_PATH = sys.argv[2]                      # the variant library, before anything is loaded
+from oracle import orc
+for name, builder, kw in (("s1", scenes.s1, dict(extent=(96, 54), grid=3, order=4)), ("s2", scenes.s2, dict(extent=(64, 36), dims=(3, 3, 2), order=3))):
+    films = []
+    for c in (api.Context(), orc.Context(threads=8)):
+        s, l = builder(c, **kw)
+        c.set_pipeline(samples_per_run=1, max_bounces=8, env_samples_per_bounce=1, mesh_samples_per_bounce=1)
+        c.render(s, l, launches=4)
+        films.append((c.sensor_data(s), {k: v for k, v in c.counters().items() if k in ("closest_rays", "shadow_rays", "samples")}))
+    assert np.array_equal(films[0][0].view(np.uint32), films[1][0].view(np.uint32)), name + ": film differs"
+    assert films[0][1] == films[1][1], name + ": ray counts differ"
+print("SPILL_OK")
+'''
+
+
+@pytest.mark.gpu
+def test_traversal_stack_spill_path(tmp_path):
+    """the per-lane traversal stack keeps 12 group entries in LDS and the rest in HBM; no test scene is deep enough to leave
+    LDS, so a second library is built with ONE LDS entry (every push beyond it goes through the spill path, work sharing
+    reads donors' entries from it) and must render S1 and the instanced S2 like the oracle, bit for bit"""
+    import subprocess, sys, os
+    from moonshine_amd import build as b
+    lib = b.build(variant="stack1", extra_flags=["-DTRACE_STACK_LDS=1"])
+    script = tmp_path / "spill_worker.py"
+    script.write_text(SPILL_WORKER)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, str(script), root, lib], capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0 and "SPILL_OK" in out.stdout, out.stdout[-1500:] + out.stderr[-3000:]
