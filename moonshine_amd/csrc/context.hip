@@ -59,7 +59,8 @@ struct MeshH {
     std::vector<float> h_positions; std::vector<uint32_t> h_indices;   // host copies for the alias-table areas (Accel.zig:503-519)
     uint32_t position_count = 0, attribute_count = 0, index_count = 0, max_index = 0; bool has_normals = false, has_texcoords = false;
 };
-struct InstanceH { m34 transform; bool visible; std::vector<GeometryRec> geos; };
+struct InstanceH { m34 transform; bool visible; std::vector<GeometryRec> geos;
+                   float wbox[6]; m34 wbox_T; bool wbox_valid = false; };   // world box of the transformed vertices, and the transform it was computed for
 struct BlasInfo { uint32_t root; float box[6]; uint32_t tris; };
 struct MaterialUpdate { bool has[6] = { false, false, false, false, false, false }; uint32_t tex[5] = { 0, 0, 0, 0, 0 }; float ior = 0.0f; };
 
@@ -345,9 +346,32 @@ bool HdMoonshine::rebuild_accel() {
     // instance records + TLAS over the transformed visible instances and the world pseudo-instance (Accel.zig:394-484)
     std::vector<InstanceRec> irec(N + 1);
     std::vector<float> boxes; std::vector<uint32_t> ids;
-    auto add_box = [&](const m34& T, const float box[6], uint32_t id) {
+    // The world box of an instance: the box of its TRANSFORMED VERTICES while that is affordable (a rotated box of a box is up to
+    // 1.7x wider per axis than the geometry — every false TLAS hit costs a change of space in the traversal), else the transformed
+    // corners of the BLAS root box.  Host work, once per TLAS build: budget of 64 M vertex transforms (~0.1 s).
+    size_t exact_budget = 64u << 20;
+    static const bool exact_boxes = [] { const char* e = getenv("MSNE_EXACT_INSTANCE_BOXES"); return !e || atoi(e) != 0; }();
+    auto add_box = [&](const m34& T, const float box[6], uint32_t id, const std::vector<uint32_t>* mesh_ids) {
         float lo[3] = { 3e38f, 3e38f, 3e38f }, hi[3] = { -3e38f, -3e38f, -3e38f };
-        for (int k = 0; k < 8; k++) {
+        size_t work = 0;
+        if (mesh_ids) for (uint32_t mi : *mesh_ids) work += meshes[mi]->position_count;
+        InstanceH* cache = mesh_ids ? &instances[id] : nullptr;   // only edited instances are recomputed when the TLAS is rebuilt
+        if (exact_boxes && cache && cache->wbox_valid && memcmp(&cache->wbox_T, &T, sizeof(m34)) == 0) {
+            for (int k = 0; k < 3; k++) { lo[k] = cache->wbox[k]; hi[k] = cache->wbox[3 + k]; }
+        } else if (exact_boxes && mesh_ids && work != 0 && work <= exact_budget) {
+            exact_budget -= work;
+            for (uint32_t mi : *mesh_ids) {
+                const MeshH* mh = meshes[mi];
+                for (uint32_t v = 0; v < mh->position_count; v++) {
+                    const f3 q = m34_mul_point(T, F3(mh->h_positions[3 * (size_t)v], mh->h_positions[3 * (size_t)v + 1], mh->h_positions[3 * (size_t)v + 2]));
+                    if (!(q.x == q.x && q.y == q.y && q.z == q.z)) continue;   // NaN vertices belong to inactive triangles
+                    lo[0] = std::min(lo[0], q.x); lo[1] = std::min(lo[1], q.y); lo[2] = std::min(lo[2], q.z);
+                    hi[0] = std::max(hi[0], q.x); hi[1] = std::max(hi[1], q.y); hi[2] = std::max(hi[2], q.z);
+                }
+            }
+            if (lo[0] <= hi[0]) { for (int k = 0; k < 3; k++) { cache->wbox[k] = lo[k]; cache->wbox[3 + k] = hi[k]; } cache->wbox_T = T; cache->wbox_valid = true; }
+        }
+        if (lo[0] > hi[0]) for (int k = 0; k < 8; k++) {
             const f3 p = F3((k & 1) ? box[3] : box[0], (k & 2) ? box[4] : box[1], (k & 4) ? box[5] : box[2]);
             const f3 q = m34_mul_point(T, p);
             lo[0] = std::min(lo[0], q.x); lo[1] = std::min(lo[1], q.y); lo[2] = std::min(lo[2], q.z);
@@ -370,7 +394,7 @@ bool HdMoonshine::rebuild_accel() {
         const BlasInfo& bi = blas_cache[keys[i]];
         r.blas_root = bi.root;
         if (!instances[i].visible || bi.root == MAX_UINT) continue;
-        add_box(instances[i].transform, bi.box, (uint32_t)i);
+        add_box(instances[i].transform, bi.box, (uint32_t)i, &keys[i]);
     }
     m34 ident; for (int r = 0; r < 3; r++) for (int c = 0; c < 4; c++) ident.m[r][c] = r == c ? 1.0f : 0.0f;
     {
@@ -379,7 +403,7 @@ bool HdMoonshine::rebuild_accel() {
         if (!world_key.empty()) {
             const BlasInfo& bi = blas_cache[world_key];
             w.blas_root = bi.root; w.flags = INST_FLAG_VISIBLE | INST_FLAG_IDENTITY | INST_FLAG_WORLD;
-            add_box(ident, bi.box, (uint32_t)N);
+            add_box(ident, bi.box, (uint32_t)N, nullptr);
         }
     }
     if (!d_instances.alloc(irec.size())) { fail("out of device memory (instances)"); return false; }
