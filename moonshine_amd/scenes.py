@@ -72,15 +72,16 @@ def furnace_white_sphere(ctx, extent=(32, 32), order=5):
     return sensor, lens
 
 
-def furnace_inside_sphere(ctx, extent=(32, 32), order=5):
-    """tests.zig:366-455: camera inside a reversed-winding icosphere, albedo 0.5, emissive 0.5, black env."""
+def furnace_inside_sphere(ctx, extent=(32, 32), order=5, sampled=False):
+    """tests.zig:366-455: camera inside a reversed-winding icosphere, albedo 0.5, emissive 0.5, black env.
+    sampled=True: the sphere is a mesh light (the reference's disabled variant, tests.zig:457-487)."""
     P, I = icosphere(order, True)
     mesh = ctx.create_mesh(P, I)
     normal = ctx.solid_texture(0.5, 0.5)
     albedo = ctx.solid_texture(0.5, 0.5, 0.5)
     emissive = ctx.solid_texture(0.5, 0.5, 0.5)
     mat = ctx.create_material(LAMBERT, normal, emissive, color=albedo)
-    ctx.create_instance([(mesh, mat, False)])
+    ctx.create_instance([(mesh, mat, sampled)])
     lens = ctx.create_lens(ctx.make_lens(**_lens((0, 0, 0), (1, 0, 0), (0, 0, 1), math.pi / 3.0)))
     sensor = ctx.create_sensor(*extent)
     ctx.set_background(np.array([0, 0, 0, 1], np.float32), 1, 1)

@@ -66,6 +66,18 @@ def test_furnace_inside_sphere(orc, gpu_api):
     assert_film_equal(g, oc.sensor_data(so), "inside furnace")
 
 
+def test_furnace_inside_sphere_with_mesh_sampling(orc, gpu_api):
+    """tests.zig:457-487 (disabled in the reference): the emissive sphere as a mesh light, NEE + MIS"""
+    oc, so, lo, gc, sg, lg = both(orc, gpu_api, scenes.furnace_inside_sphere, sampled=True)
+    for c in (oc, gc):
+        c.set_pipeline(samples_per_run=512, max_bounces=1024, env_samples_per_bounce=0, mesh_samples_per_bounce=1)
+    gc.render(sg, lg); oc.render(so, lo)
+    g = gc.sensor_data(sg)
+    assert np.all(np.abs(g[..., :3] - 1.0) <= 0.1), "tests.zig:483"
+    assert_film_equal(g, oc.sensor_data(so), "inside furnace, mesh sampling")
+    assert gc.counters() == {k: v for k, v in oc.counters().items() if k in ("closest_rays", "shadow_rays", "samples")}
+
+
 # ---- traversal: hit records ----
 def _random_rays(n, seed, radius=4.0):
     rng = np.random.default_rng(seed)

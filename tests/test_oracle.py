@@ -163,6 +163,18 @@ def test_reference_furnace_inside_sphere(orc):
     assert np.all(np.abs(c.sensor_data(s)[..., :3] - 1.0) <= 0.02)  # tests.zig:449-454
 
 
+def test_reference_furnace_inside_sphere_with_mesh_sampling(orc):
+    """the reference's fourth furnace test (tests.zig:457-487), disabled there for want of an instance upload path for sampled
+    meshes: the emissive sphere is a mesh light, one light sample per bounce with MIS; its stated tolerance is 0.1"""
+    c = orc.Context(threads=os.cpu_count())
+    s, l = scenes.furnace_inside_sphere(c, sampled=True)
+    c.set_pipeline(samples_per_run=512, max_bounces=1024, env_samples_per_bounce=0, mesh_samples_per_bounce=1)   # tests.zig:470-475
+    c.render(s, l)
+    img = c.sensor_data(s)[..., :3]
+    assert np.all(np.abs(img - 1.0) <= 0.1)                         # tests.zig:483
+    assert abs(float(img.mean()) - 1.0) < 0.005                     # unbiased: the mean over 1024 pixels x 512 samples
+
+
 def test_icosphere_fixture():
     P, I = scenes.icosphere(5)
     assert P.shape == (10242, 3) and I.shape == (20480, 3)       # tests.zig:115-247 at order 5
