@@ -639,3 +639,44 @@ def test_traversal_stack_spill_path(tmp_path):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     out = subprocess.run([sys.executable, str(script), root, lib], capture_output=True, text=True, timeout=900)
     assert out.returncode == 0 and "SPILL_OK" in out.stdout, out.stdout[-1500:] + out.stderr[-3000:]
+
+
+def _odd_scene(c, extent, ior, aperture):
+    """texture coordinates far outside [0, 1] (negative, > 1, 1e4: the sampler's wrap rule), non-square and 1-texel-wide textures,
+    an emissive texture on a sampled mesh, glass with the given ior, a thin lens with a large aperture"""
+    rs = np.random.default_rng(21)
+    gp, gi = scenes.quad((-5, -5, -1), (5, -5, -1), (5, 5, -1), (-5, 5, -1))
+    uv = np.array([[-2.3, -1.7], [3.9, -1.7], [3.9, 10001.25], [-2.3, 10001.25]], np.float32)
+    col = c.create_texture(rs.integers(0, 256, size=(5, 13, 4), dtype=np.uint8), 13, 5, "r8g8b8a8_srgb")      # 13 x 5
+    strip = c.create_texture(rs.integers(40, 220, size=(7, 1), dtype=np.uint8), 1, 7, "r8_unorm")             # 1 x 7
+    nrm = c.create_texture((128 + rs.integers(-50, 50, size=(3, 9, 2))).astype(np.uint8), 9, 3, "r8g8_unorm")
+    black = c.solid_texture(0.0, 0.0, 0.0)
+    floor = c.create_material(scenes.STANDARD_PBR, nrm, black, color=col, metalness=c.solid_texture(0.5), roughness=strip, ior=1.5)
+    c.create_instance([(c.create_mesh(gp, gi, normals=np.tile(np.array([[0, 0, 1]], np.float32), (4, 1)), texcoords=uv), floor, False)])
+    P, I = scenes.icosphere(3)
+    glass = c.create_material(scenes.GLASS, c.solid_texture(0.5, 0.5), black, ior=ior)
+    c.create_instance([(c.create_mesh(P, I), glass, False)])
+    mirror = c.create_material(scenes.PERFECT_MIRROR, c.solid_texture(0.5, 0.5), black)
+    T = np.eye(3, 4, dtype=np.float32); T[:, 3] = [2.4, 0.5, 0.0]
+    c.create_instance([(c.create_mesh(P, I), mirror, False)], transform=T)
+    lp, li = scenes.quad((-1, -1, 3.5), (-1, 1, 3.5), (1, 1, 3.5), (1, -1, 3.5))
+    luv = np.array([[0, 0], [0, 2.5], [2.5, 2.5], [2.5, 0]], np.float32)
+    etex = c.create_texture((rs.random((4, 4, 4)) * 30).astype(np.float32), 4, 4, "r32g32b32a32_sfloat")
+    lamp = c.create_material(scenes.LAMBERT, c.solid_texture(0.5, 0.5), etex, color=black)
+    c.create_instance([(c.create_mesh(lp, li, texcoords=luv), lamp, True)])
+    c.set_background(np.array([0.2, 0.25, 0.3, 1], np.float32), 1, 1)
+    lens = c.create_lens(c.make_lens((0.5, -7, 2.0), (0, 1, -0.25), (0, 0, 1), 0.9, aperture=aperture, focus_distance=6.5))
+    return c.create_sensor(*extent), lens
+
+
+@pytest.mark.parametrize("extent,ior,aperture,bounces,spr", [((37, 23), 1.5, 0.0, 6, 1), ((16, 16), 1.0, 0.6, 3, 3), ((1, 1), 0.8, 0.1, 0, 2), ((130, 7), 2.4, 0.0, 1, 1)])
+def test_odd_parameters(orc, gpu_api, extent, ior, aperture, bounces, spr):
+    oc, so, lo, gc, sg, lg = both(orc, gpu_api, _odd_scene, extent=extent, ior=ior, aperture=aperture)
+    for c in (oc, gc):
+        c.set_pipeline(samples_per_run=spr, max_bounces=bounces, env_samples_per_bounce=1, mesh_samples_per_bounce=1)
+    n = 64 if extent == (1, 1) else 3
+    gc.render(sg, lg, launches=n); oc.render(so, lo, launches=n)
+    g = gc.sensor_data(sg)
+    assert np.isfinite(g).all()
+    assert_film_equal(g, oc.sensor_data(so), "odd parameters %s" % (extent,))
+    assert gc.counters() == {k: v for k, v in oc.counters().items() if k in ("closest_rays", "shadow_rays", "samples")}
