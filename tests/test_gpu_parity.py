@@ -680,3 +680,42 @@ def test_odd_parameters(orc, gpu_api, extent, ior, aperture, bounces, spr):
     assert np.isfinite(g).all()
     assert_film_equal(g, oc.sensor_data(so), "odd parameters %s" % (extent,))
     assert gc.counters() == {k: v for k, v in oc.counters().items() if k in ("closest_rays", "shadow_rays", "samples")}
+
+
+def _env_image(kind):
+    rs = np.random.default_rng(33)
+    if kind == "odd_size":        # 37 x 19: neither a power of two nor 2:1
+        img = rs.random((19, 37, 4)).astype(np.float32) * 2.0
+    elif kind == "two_by_one":    # the smallest equirect that is not constant
+        img = np.array([[[3.0, 0.5, 0.1, 1.0], [0.1, 0.5, 3.0, 1.0]]], np.float32)
+    elif kind == "hot_pixel":     # one texel 1e6 times brighter than the rest: importance sampling puts nearly every sample there
+        img = np.full((64, 128, 4), 0.01, np.float32); img[20, 90, :3] = [1.0e4, 0.8e4, 0.5e4]
+    elif kind == "black":         # nothing to sample: every env light sample has pdf 0
+        img = np.zeros((8, 16, 4), np.float32)
+    elif kind == "tall":          # higher than wide
+        img = rs.random((64, 8, 4)).astype(np.float32)
+    img[..., 3] = 1.0
+    return np.ascontiguousarray(img)
+
+
+@pytest.mark.parametrize("kind", ["odd_size", "two_by_one", "hot_pixel", "black", "tall"])
+def test_environment_edge_cases(orc, gpu_api, kind):
+    """env preprocessing (equirect -> equal-area square, luminance mips) and env importance sampling + MIS on maps the sky test
+    does not look like"""
+    img = _env_image(kind)
+    def build(c):
+        s, l = scenes.s1(c, extent=(72, 40), grid=2, order=3)
+        c.set_background(img, img.shape[1], img.shape[0])
+        return s, l
+    oc, so, lo, gc, sg, lg = both(orc, gpu_api, build)
+    grgb, glum = gc.env(); orgb, olum = oc.env()
+    assert np.array_equal(grgb.view(np.uint32), orgb.view(np.uint32)) and len(glum) == len(olum)
+    for a, b in zip(glum, olum):
+        assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
+    for c in (oc, gc):
+        c.set_pipeline(samples_per_run=1, max_bounces=5, env_samples_per_bounce=2, mesh_samples_per_bounce=1)
+    gc.render(sg, lg, launches=4); oc.render(so, lo, launches=4)
+    g = gc.sensor_data(sg)
+    assert np.isfinite(g).all()
+    assert_film_equal(g, oc.sensor_data(so), "env " + kind)
+    assert gc.counters() == {k: v for k, v in oc.counters().items() if k in ("closest_rays", "shadow_rays", "samples")}
