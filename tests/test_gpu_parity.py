@@ -719,3 +719,32 @@ def test_environment_edge_cases(orc, gpu_api, kind):
     assert np.isfinite(g).all()
     assert_film_equal(g, oc.sensor_data(so), "env " + kind)
     assert gc.counters() == {k: v for k, v in oc.counters().items() if k in ("closest_rays", "shadow_rays", "samples")}
+
+
+def test_contexts_render_concurrently_from_threads(gpu_api):
+    """one mutex per context (hydra.zig:76-78), nothing shared between contexts: four contexts rendering at the same time from four
+    host threads give the films they give one after the other"""
+    import threading
+    def make(k):
+        c = gpu_api.Context()
+        s, l = (scenes.cornell(c, extent=(64, 64)) if k % 2 else scenes.s1(c, extent=(80, 45), grid=2, order=3))
+        c.set_pipeline(samples_per_run=1, max_bounces=6, env_samples_per_bounce=1 - k % 2, mesh_samples_per_bounce=1)
+        return c, s, l
+    ctxs = [make(k) for k in range(4)]
+    ref = []
+    for c, s, l in ctxs:
+        c.render(s, l, launches=6); ref.append(c.sensor_data(s).copy()); c.clear_sensor(s)
+    out = [None] * 4; err = []
+    def work(k):
+        try:
+            c, s, l = ctxs[k]
+            for _ in range(3):
+                c.render(s, l, launches=2)
+            out[k] = c.sensor_data(s).copy()
+        except Exception as e:   # noqa
+            err.append(e)
+    th = [threading.Thread(target=work, args=(k,)) for k in range(4)]
+    [t.start() for t in th]; [t.join() for t in th]
+    assert not err, err
+    for k in range(4):
+        assert np.array_equal(out[k].view(np.uint32), ref[k].view(np.uint32)), "context %d" % k
