@@ -32,7 +32,8 @@ def png_rgb8(img):
 class GlbBuilder:
     """Minimal glTF 2.0 writer: meshes with POSITION/NORMAL/TEXCOORD_0 + indices, materials, PNG textures, one camera."""
 
-    def __init__(self):
+    def __init__(self, interleaved=False):
+        self.interleaved = interleaved
         self.bin = bytearray()
         self.j = {"asset": {"version": "2.0"}, "scene": 0, "scenes": [{"nodes": []}], "nodes": [], "meshes": [], "materials": [],
                   "accessors": [], "bufferViews": [], "buffers": [{}], "cameras": [], "textures": [], "images": []}
@@ -92,6 +93,20 @@ class GlbBuilder:
             pos = np.asarray(p["positions"], np.float32)
             idx = np.asarray(p["indices"]).reshape(-1)
             small = pos.shape[0] <= 65535 and not p.get("u32")
+            if self.interleaved and p.get("normals") is not None and p.get("texcoords") is not None:
+                # one vertex buffer, attributes interleaved (bufferView.byteStride = 32, accessor.byteOffset 0 / 12 / 24): what exporters write
+                inter = np.concatenate([pos, np.asarray(p["normals"], np.float32), np.asarray(p["texcoords"], np.float32)], 1).astype(np.float32)
+                bv = self._view(inter.tobytes(), 34962)
+                self.j["bufferViews"][bv]["byteStride"] = 32
+                attrs = {}
+                for name, off, typ, arr in (("POSITION", 0, "VEC3", pos), ("NORMAL", 12, "VEC3", None), ("TEXCOORD_0", 24, "VEC2", None)):
+                    acc = {"bufferView": bv, "byteOffset": off, "componentType": 5126, "count": int(pos.shape[0]), "type": typ}
+                    if arr is not None:
+                        acc["min"] = [float(x) for x in arr.min(0)]; acc["max"] = [float(x) for x in arr.max(0)]
+                    self.j["accessors"].append(acc); attrs[name] = len(self.j["accessors"]) - 1
+                prims.append({"attributes": attrs, "material": p["material"], "mode": 4,
+                              "indices": self._accessor(idx.astype(np.uint16 if small else np.uint32), 5123 if small else 5125, "SCALAR", 34963)})
+                continue
             attrs = {"POSITION": self._accessor(pos, 5126, "VEC3", 34962)}
             if p.get("normals") is not None:
                 attrs["NORMAL"] = self._accessor(np.asarray(p["normals"], np.float32), 5126, "VEC3", 34962)

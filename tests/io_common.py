@@ -61,11 +61,11 @@ def write_single_triangle(path_glb, path_exr):
     open(path_exr, "wb").write(assets.exr_bytes(np.ones((1, 1, 4), np.float32)))
 
 
-def write_gallery(path_glb, path_exr, u32=False):
+def write_gallery(path_glb, path_exr, u32=False, interleaved=False):
     """every import rule of World.zig in one file: Lambert / mirror / glass / constant PBR / textured PBR with normal +
     metallic-roughness + emissive maps, an "Emitter…" quad (sampled), node hierarchy with TRS + matrix, uv + normals."""
     rs = np.random.default_rng(11)
-    b = assets.GlbBuilder()
+    b = assets.GlbBuilder(interleaved=interleaved)
     white = b.material("Floor", base_color=(0.7, 0.7, 0.7), metallic=0.0, roughness=1.0)
     mirror = b.material("Mirror", metallic=1.0, roughness=0.0)
     glass = b.material("Glass", transmission=1.0, ior=1.45)

@@ -130,6 +130,22 @@ def test_gallery_import_rules(tmp_path, orc, u32):
     assert np.array_equal(bits(img), bits(g))
 
 
+def test_interleaved_vertex_buffers_load_like_separate_ones(tmp_path, orc):
+    """bufferView.byteStride + accessor.byteOffset (one interleaved POSITION/NORMAL/TEXCOORD_0 buffer per primitive, the layout
+    exporters write): the same scene, the same film as the golden gallery"""
+    glb, exr = str(tmp_path / "gallery_i.glb"), str(tmp_path / "sky.exr")
+    io.write_gallery(glb, exr, interleaved=True)
+    assert b'"byteStride":32' in open(glb, "rb").read().replace(b" ", b"")
+    c = orc.Context(threads=os.cpu_count())
+    lens, info = io.oracle_load(orc, c, glb, exr)
+    assert info["triangles"] == 4 * 320 + 4
+    s = c.create_sensor(96, 64)
+    c.set_pipeline(samples_per_run=4, max_bounces=6, env_samples_per_bounce=1, mesh_samples_per_bounce=1)
+    c.render(s, lens)
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "gallery_96x64_4spp.npy"))
+    assert np.array_equal(bits(c.sensor_data(s)), bits(g))
+
+
 def test_glb_errors(tmp_path, orc):
     c = orc.Context()
     s = io.shim(orc)
