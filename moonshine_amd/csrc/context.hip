@@ -218,8 +218,18 @@ bool HdMoonshine::upload_textures() {
 
 bool HdMoonshine::upload_materials() {
     // flush deferred edits (hydra.zig:152-223)
+    for (auto& kv : material_updates) {   // the Hydra setters return nothing: a bad handle surfaces here, at the Render that would have used it
+        const MaterialUpdate& u0 = kv.second;
+        bool bad = kv.first >= materials.size();
+        for (int f = 0; f < 5; f++) if (u0.has[f] && u0.tex[f] >= textures.size()) bad = true;
+        if (bad) {
+            const uint32_t which = kv.first;
+            material_updates.clear();
+            fail("material edit: unknown material or texture handle (material " + std::to_string(which) + "); the edit was dropped");
+            return false;
+        }
+    }
     for (auto& kv : material_updates) {
-        if (kv.first >= materials.size()) continue;
         MaterialRec& m = materials[kv.first]; const MaterialUpdate& u = kv.second;
         if (u.has[0]) m.normal = u.tex[0];
         if (u.has[1]) m.emissive = u.tex[1];

@@ -468,6 +468,18 @@ def test_unsupported_pipeline_is_rejected_loudly(gpu_api):
         gc.create_material(scenes.LAMBERT, 999, 0)
     with pytest.raises(gpu_api.MoonshineError):
         gc.create_mesh(np.zeros((3, 3), np.float32), [[0, 1, 7]])
+    # a deferred Hydra material edit with a texture handle that does not exist: the next render reports it and drops the edit,
+    # the one after renders with the material as it was
+    s, l = scenes.cornell(gc, extent=(16, 16))
+    gc.set_pipeline(samples_per_run=1, max_bounces=2, env_samples_per_bounce=0, mesh_samples_per_bounce=1)
+    gc.render(s, l); before = gc.sensor_data(s).copy(); gc.clear_sensor(s)
+    gc.L.HdMoonshineSetMaterialColor(gc.h, 0, 123456)
+    with pytest.raises(gpu_api.MoonshineError, match="unknown material or texture handle"):
+        gc.render(s, l)
+    gc.clear_sensor(s); gc.render(s, l)
+    assert np.array_equal(gc.sensor_data(s).view(np.uint32), before.view(np.uint32))
+    with pytest.raises(gpu_api.MoonshineError):
+        gc.render(999, l)
 
 
 @pytest.mark.gpu
