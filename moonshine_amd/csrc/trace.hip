@@ -235,6 +235,8 @@ __device__ __forceinline__ bool step_tri(Lane& L, const SceneView& sc, unsigned 
 // (MI355X_MICROARCH.md "dequeue"), so (1) every wave's FIRST chunk is static (wave w takes chunk w: an
 // empty or short queue costs no atomics at all), (2) later chunks come from one atomicAdd per wave on the
 // queue head, and (3) a chunk is 64..256 rays that the wave's lanes consume one by one as they go idle.
+// Small chunks handed out IN ORDER also keep all resident waves inside one window of ~1.5 M consecutive rays of the
+// (screen-ordered) queue, so they share BVH nodes in L2: a big static share per wave was measured 1.4-2x slower.
 struct WaveQueue {
     uint32_t n, chunk, pos, end, nwaves_chunk;
     uint32_t* head;
