@@ -13,6 +13,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <algorithm>
+#include <new>
 
 namespace msne {
 
@@ -437,15 +438,18 @@ struct BuildScratch {
     }
 };
 
-static BuildScratch g_scratch;   // guarded by the context mutex of the caller
-void bvh_release_scratch() { g_scratch.release(); }
+// The scratch belongs to ONE context (allocated on its device, used on its stream under its mutex): contexts that rebuild
+// concurrently from different threads, or live on different GPUs, share nothing.
+BuildScratch* bvh_scratch_create() { return new (std::nothrow) BuildScratch(); }
+void bvh_scratch_destroy(BuildScratch* s) { if (s) { s->release(); delete s; } }
+void bvh_scratch_release(BuildScratch* s) { if (s) s->release(); }
+size_t bvh_scratch_capacity(const BuildScratch* s) { return s ? s->cap : 0; }
 
-// Builds a wide BVH over the n boxes in g_scratch.boxes.  Nodes are appended at *node_counter (device),
+// Builds a wide BVH over the n boxes in S.boxes.  Nodes are appended at *node_counter (device),
 // items at *item_counter; item_src[pos] = source box index for final item position pos.
 // Returns the root node index and the root box (host).
-static bool build_from_boxes(hipStream_t s, uint32_t n, Node8* nodes, uint32_t* node_counter, uint32_t node_capacity,
+static bool build_from_boxes(BuildScratch& S, hipStream_t s, uint32_t n, Node8* nodes, uint32_t* node_counter, uint32_t node_capacity,
                              uint32_t* item_counter, uint32_t* item_src, uint32_t* root_out, Box* root_box) {
-    BuildScratch& S = g_scratch;
     const uint32_t ntiles = (n + RS_TILE - 1) / RS_TILE;
     const uint32_t init_bounds[6] = { 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0u, 0u, 0u };
     HIPCHK(hipMemcpyAsync(S.bounds, init_bounds, sizeof init_bounds, hipMemcpyHostToDevice, s));
@@ -513,9 +517,11 @@ static bool build_from_boxes(hipStream_t s, uint32_t n, Node8* nodes, uint32_t* 
 }
 
 // BLAS over the triangles of a geometry list (Accel.zig:94-184; one BLAS per unique mesh list, :315-343)
-bool bvh_build_blas(hipStream_t s, const std::vector<BlasGeo>& geos, uint32_t ntris, Node8* nodes, uint32_t* node_counter, uint32_t node_capacity,
+bool bvh_build_blas(BuildScratch* scratch, hipStream_t s, const std::vector<BlasGeo>& geos, uint32_t ntris, Node8* nodes, uint32_t* node_counter, uint32_t node_capacity,
                     TriRec* tris, uint32_t* tri_counter, uint32_t* item_src, uint32_t* root_out, float root_box[6]) {
     if (ntris == 0) { *root_out = MAX_UINT; for (int k = 0; k < 6; k++) root_box[k] = 0.0f; return true; }
+    if (!scratch) return false;
+    BuildScratch& g_scratch = *scratch;
     if (!g_scratch.reserve(ntris)) return false;
     BlasGeo* dgeos = nullptr;
     HIPCHK(hipMalloc(&dgeos, geos.size() * sizeof(BlasGeo)));
@@ -524,7 +530,7 @@ bool bvh_build_blas(hipStream_t s, const std::vector<BlasGeo>& geos, uint32_t nt
     uint32_t item_begin = 0;
     HIPCHK(hipMemcpyAsync(&item_begin, tri_counter, 4, hipMemcpyDeviceToHost, s));
     Box rb;
-    bool ok = build_from_boxes(s, ntris, nodes, node_counter, node_capacity, tri_counter, item_src, root_out, &rb);
+    bool ok = build_from_boxes(g_scratch, s, ntris, nodes, node_counter, node_capacity, tri_counter, item_src, root_out, &rb);
     if (ok) {
         hipLaunchKernelGGL(k_emit_tris, dim3((ntris + 255) / 256), dim3(256), 0, s, dgeos, (uint32_t)geos.size(), item_src, item_begin, ntris, tris);
         HIPCHK(hipStreamSynchronize(s));
@@ -535,9 +541,11 @@ bool bvh_build_blas(hipStream_t s, const std::vector<BlasGeo>& geos, uint32_t nt
 }
 
 // TLAS over instance world boxes (Accel.zig:484).  host_boxes: n x {lo[3],hi[3]}, ids: instance index per box.
-bool bvh_build_tlas(hipStream_t s, const float* host_boxes, const uint32_t* host_ids, uint32_t n, Node8* nodes, uint32_t* node_counter, uint32_t node_capacity,
+bool bvh_build_tlas(BuildScratch* scratch, hipStream_t s, const float* host_boxes, const uint32_t* host_ids, uint32_t n, Node8* nodes, uint32_t* node_counter, uint32_t node_capacity,
                     uint32_t* tlas_items, uint32_t* item_counter, uint32_t* item_src, uint32_t* root_out) {
     if (n == 0) { *root_out = MAX_UINT; return true; }
+    if (!scratch) return false;
+    BuildScratch& g_scratch = *scratch;
     if (!g_scratch.reserve(n)) return false;
     HIPCHK(hipMemcpyAsync(g_scratch.boxes, host_boxes, (size_t)n * sizeof(Box), hipMemcpyHostToDevice, s));
     uint32_t* dids = nullptr;
@@ -546,7 +554,7 @@ bool bvh_build_tlas(hipStream_t s, const float* host_boxes, const uint32_t* host
     uint32_t item_begin = 0;
     HIPCHK(hipMemcpyAsync(&item_begin, item_counter, 4, hipMemcpyDeviceToHost, s));
     Box rb;
-    bool ok = build_from_boxes(s, n, nodes, node_counter, node_capacity, item_counter, item_src, root_out, &rb);
+    bool ok = build_from_boxes(g_scratch, s, n, nodes, node_counter, node_capacity, item_counter, item_src, root_out, &rb);
     if (ok) {
         hipLaunchKernelGGL(k_emit_items, dim3((n + 255) / 256), dim3(256), 0, s, item_src, item_begin, n, dids, tlas_items);
         HIPCHK(hipStreamSynchronize(s));

@@ -31,9 +31,13 @@ void launch_film(hipStream_t, int, const ShardView&, const PipelineOpts&, const 
 void launch_unpack_film(hipStream_t, int, const ShardView&, const float4*, uint32_t, uint32_t, size_t, float4*);
 void launch_env_build(hipStream_t, const float4*, uint32_t, uint32_t, float4*, float*, const uint32_t*, uint32_t, uint32_t);
 struct BlasGeo { const float* positions; const uint32_t* indices; uint32_t tri_offset, tri_count, geo, inst; };
-bool bvh_build_blas(hipStream_t, const std::vector<BlasGeo>&, uint32_t, Node8*, uint32_t*, uint32_t, TriRec*, uint32_t*, uint32_t*, uint32_t*, float[6]);
-bool bvh_build_tlas(hipStream_t, const float*, const uint32_t*, uint32_t, Node8*, uint32_t*, uint32_t, uint32_t*, uint32_t*, uint32_t*, uint32_t*);
-void bvh_release_scratch();
+struct BuildScratch;   // per-context build buffers (bvh_build.hip)
+BuildScratch* bvh_scratch_create();
+void bvh_scratch_destroy(BuildScratch*);
+void bvh_scratch_release(BuildScratch*);
+size_t bvh_scratch_capacity(const BuildScratch*);
+bool bvh_build_blas(BuildScratch*, hipStream_t, const std::vector<BlasGeo>&, uint32_t, Node8*, uint32_t*, uint32_t, TriRec*, uint32_t*, uint32_t*, uint32_t*, float[6]);
+bool bvh_build_tlas(BuildScratch*, hipStream_t, const float*, const uint32_t*, uint32_t, Node8*, uint32_t*, uint32_t, uint32_t*, uint32_t*, uint32_t*, uint32_t*);
 }  // namespace msne
 
 using namespace msne;
@@ -113,6 +117,9 @@ struct HdMoonshine {
     DevBuf<uint32_t> d_build_counters;    // [0] node count, [1] tri count, [2] tlas item count
     uint32_t blas_nodes_end = 0, blas_tris_end = 0;
     std::map<std::vector<uint32_t>, BlasInfo> blas_cache;
+    std::vector<uint32_t> world_blas_key;                 // key of the ONE world BLAS kept in blas_cache (empty: none)
+    uint32_t dead_tris = 0;                               // triangles of evicted world BLASes still lying in the pools (reclaimed by a pool reset)
+    BuildScratch* build_scratch = nullptr;                // this context's BVH build buffers: nothing is shared between contexts
     uint32_t tlas_root = MAX_UINT, root_in_blas = 0;
     std::vector<AliasEntry> h_alias;
     // environment
@@ -164,6 +171,15 @@ struct HdMoonshine {
     bool set_background(const float* rgba, Extent2D e);
     bool render(uint32_t sensor, uint32_t lens, uint32_t launches, bool readback);
     bool readback(SensorH* s);
+    // the traversal kernels raise a flag when a ray needs more than 128 stack entries; read and re-arm it after every render / probe
+    bool check_overflow() {
+        uint32_t overflow = 0;
+        CHECK_HIP(this, hipMemcpy(&overflow, d_overflow.p, 4, hipMemcpyDeviceToHost));
+        if (!overflow) return true;
+        CHECK_HIP(this, hipMemset(d_overflow.p, 0, 4));
+        fail("traversal stack overflow");
+        return false;
+    }
     ~HdMoonshine();
 };
 
@@ -304,6 +320,16 @@ bool HdMoonshine::rebuild_accel() {
             world_key.insert(world_key.end(), keys[i].begin(), keys[i].end());
         }
     }
+    // At most one world BLAS is kept: when the set of visible identity instances changes (Hydra visibility / transform edits,
+    // hydra.zig:495-513) the previous one is evicted, and once evicted BLASes make up more than half of the pools the pools are
+    // reset and everything still referenced is rebuilt — device memory stays within 2x of what the scene needs however long
+    // an interactive session edits instances.
+    if (world_key != world_blas_key) {
+        auto old = blas_cache.find(world_blas_key);
+        if (!world_blas_key.empty() && old != blas_cache.end()) { dead_tris += old->second.tris; blas_cache.erase(old); }
+        world_blas_key = world_key;
+        if ((size_t)dead_tris * 2 > (size_t)blas_tris_end) { blas_cache.clear(); blas_nodes_end = 0; blas_tris_end = 0; dead_tris = 0; }
+    }
     size_t new_tris = 0;
     {
         std::map<std::vector<uint32_t>, bool> seen;
@@ -314,6 +340,7 @@ bool HdMoonshine::rebuild_accel() {
         if (!world_key.empty() && !blas_cache.count(world_key))
             for (size_t i = 0; i < N; i++) if (in_world[i]) for (uint32_t m : keys[i]) new_tris += meshes[m]->index_count;
     }
+    if (!build_scratch && !(build_scratch = bvh_scratch_create())) { fail("out of host memory"); return false; }
     if (!d_build_counters.p) { if (!d_build_counters.alloc(4)) { fail("out of device memory"); return false; } CHECK_HIP(this, hipMemsetAsync(d_build_counters.p, 0, 16, stream)); }
     const size_t need_tris = (size_t)blas_tris_end + new_tris;
     const size_t need_nodes = (size_t)blas_nodes_end + new_tris + 2 * N + 64;
@@ -337,7 +364,7 @@ bool HdMoonshine::rebuild_accel() {
         std::vector<BlasGeo> bg; uint32_t off = 0, g = 0;
         for (uint32_t m : keys[i]) { bg.push_back(BlasGeo{ meshes[m]->positions.p, meshes[m]->indices.p, off, meshes[m]->index_count, g++, 0u }); off += meshes[m]->index_count; }
         BlasInfo info{}; info.tris = off;
-        if (!bvh_build_blas(stream, bg, off, d_nodes.p, d_build_counters.p, (uint32_t)d_nodes.n, d_tris.p, d_build_counters.p + 1, d_item_src.p, &info.root, info.box)) { fail("BLAS build failed (details on stderr)"); return false; }
+        if (!bvh_build_blas(build_scratch, stream, bg, off, d_nodes.p, d_build_counters.p, (uint32_t)d_nodes.n, d_tris.p, d_build_counters.p + 1, d_item_src.p, &info.root, info.box)) { fail("BLAS build failed (details on stderr)"); return false; }
         blas_cache[keys[i]] = info;
     }
     if (!world_key.empty() && !blas_cache.count(world_key)) {
@@ -348,7 +375,7 @@ bool HdMoonshine::rebuild_accel() {
             for (uint32_t m : keys[i]) { bg.push_back(BlasGeo{ meshes[m]->positions.p, meshes[m]->indices.p, off, meshes[m]->index_count, g++, (uint32_t)i }); off += meshes[m]->index_count; }
         }
         BlasInfo info{}; info.tris = off;
-        if (!bvh_build_blas(stream, bg, off, d_nodes.p, d_build_counters.p, (uint32_t)d_nodes.n, d_tris.p, d_build_counters.p + 1, d_item_src.p, &info.root, info.box)) { fail("world BLAS build failed (details on stderr)"); return false; }
+        if (!bvh_build_blas(build_scratch, stream, bg, off, d_nodes.p, d_build_counters.p, (uint32_t)d_nodes.n, d_tris.p, d_build_counters.p + 1, d_item_src.p, &info.root, info.box)) { fail("world BLAS build failed (details on stderr)"); return false; }
         blas_cache[world_key] = info;
     }
     { uint32_t c[2]; CHECK_HIP(this, hipMemcpy(c, d_build_counters.p, 8, hipMemcpyDeviceToHost)); blas_nodes_end = c[0]; blas_tris_end = c[1]; }
@@ -422,7 +449,7 @@ bool HdMoonshine::rebuild_accel() {
     if (ids.size() == 1 && ids[0] == (uint32_t)N) {
         tlas_root = irec[N].blas_root; root_in_blas = 1;     // nothing but static geometry: traversal starts inside the world BLAS
         const uint32_t zero = 0; CHECK_HIP(this, hipMemcpyAsync(d_build_counters.p + 2, &zero, 4, hipMemcpyHostToDevice, stream));
-    } else if (!bvh_build_tlas(stream, boxes.data(), ids.data(), (uint32_t)ids.size(), d_nodes.p, d_build_counters.p, (uint32_t)d_nodes.n, d_tlas_items.p, d_build_counters.p + 2, d_item_src.p, &tlas_root)) { fail("TLAS build failed (details on stderr)"); return false; }
+    } else if (!bvh_build_tlas(build_scratch, stream, boxes.data(), ids.data(), (uint32_t)ids.size(), d_nodes.p, d_build_counters.p, (uint32_t)d_nodes.n, d_tlas_items.p, d_build_counters.p + 2, d_item_src.p, &tlas_root)) { fail("TLAS build failed (details on stderr)"); return false; }
 
     // emissive-triangle alias table (Accel.zig:491-539): entry 0 = {count, sum of areas}
     std::vector<float> w; h_alias.assign(1, AliasEntry{ 0u, 0.0f, 0u, 0u, 0u });
@@ -447,6 +474,8 @@ bool HdMoonshine::rebuild_accel() {
     CHECK_HIP(this, hipMemcpyAsync(d_alias.p, h_alias.data(), h_alias.size() * sizeof(AliasEntry), hipMemcpyHostToDevice, stream));
     lights_dirty = true;
     CHECK_HIP(this, hipStreamSynchronize(stream));
+    // ~200 B of scratch per primitive: a scene-sized scratch is given back, a TLAS-sized one (interactive instance edits) is kept
+    if (bvh_scratch_capacity(build_scratch) > (1u << 16)) bvh_scratch_release(build_scratch);
     accel_dirty = false;
     return true;
 }
@@ -679,9 +708,7 @@ bool HdMoonshine::render(uint32_t sensor, uint32_t lens, uint32_t launches, bool
     if (ev_end) (void)hipEventRecord(ev_end, stream);
     if (do_readback) { if (!readback(s)) return false; }
     else CHECK_HIP(this, hipStreamSynchronize(stream));
-    uint32_t overflow = 0;
-    CHECK_HIP(this, hipMemcpy(&overflow, d_overflow.p, 4, hipMemcpyDeviceToHost));
-    if (overflow) { fail("traversal stack overflow"); return false; }
+    if (!check_overflow()) { s->sample_count = 0; return false; }   // the film holds truncated traversals: the next render starts it over (Sensor.clear)
     float ms = 0.0f;
     if (ev_begin && ev_end && hipEventElapsedTime(&ms, ev_begin, ev_end) == hipSuccess) stats.render_ms += ms;
     for (const Span& sp : spans) {
@@ -698,6 +725,7 @@ HdMoonshine::~HdMoonshine() {
     for (auto* m : meshes) delete m;
     for (auto* s : sensors) { if (s->host) (void)hipHostFree(s->host); delete s; }
     for (auto e : events) (void)hipEventDestroy(e);
+    bvh_scratch_destroy(build_scratch);
     if (stream) (void)hipStreamDestroy(stream);
 }
 
@@ -723,8 +751,9 @@ HdMoonshine* MsneCreate(const MsneConfig* cfg_in) {
     if (!c) { g_create_error = "out of host memory"; return nullptr; }
     c->device = dev; c->cfg = cfg;
     if (hipSetDevice(dev) != hipSuccess || hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { g_create_error = "cannot create HIP stream"; delete c; return nullptr; }
-    hipDeviceProp_t prop;
-    if (hipGetDeviceProperties(&prop, dev) == hipSuccess) { c->trace_grid = prop.multiProcessorCount * trace_blocks_per_cu(); c->shade_grid = prop.multiProcessorCount * 8; c->shade_k_grid = prop.multiProcessorCount * 96; }   // k_shade: workgroups differ in cost (what their 256 paths hit); 96 per CU instead of 8 evens the CUs out (-6 %)
+    hipDeviceProp_t prop{};
+    if (hipGetDeviceProperties(&prop, dev) != hipSuccess || prop.multiProcessorCount <= 0) { g_create_error = "hipGetDeviceProperties failed"; delete c; return nullptr; }
+    { c->trace_grid = prop.multiProcessorCount * trace_blocks_per_cu(); c->shade_grid = prop.multiProcessorCount * 8; c->shade_k_grid = prop.multiProcessorCount * 96; }   // k_shade: workgroups differ in cost (what their 256 paths hit); 96 per CU instead of 8 evens the CUs out (-6 %)
     if (const char* e = getenv("MSNE_SHADE_BLOCKS_PER_CU")) c->shade_k_grid = prop.multiProcessorCount * std::max(1, atoi(e));
     if (const char* e = getenv("MSNE_MAX_INFLIGHT")) c->max_inflight = (size_t)atoll(e);
     if (const char* e = getenv("MSNE_PIPES")) c->n_pipes = std::max(1, std::min((int)HdMoonshine::MAX_PIPES, atoi(e)));
@@ -951,7 +980,7 @@ int MsneTraceRays(HdMoonshine* c, const float* rays, uint32_t n, int any_hit, ui
     if (hipMemcpyAsync(out_ids, di.p, 16 * (size_t)n, hipMemcpyDeviceToHost, c->stream) != hipSuccess) return -1;
     if (hipMemcpyAsync(out_tuv, dt.p, 12 * (size_t)n, hipMemcpyDeviceToHost, c->stream) != hipSuccess) return -1;
     if (hipStreamSynchronize(c->stream) != hipSuccess) { c->fail("probe failed"); return -1; }
-    return 0;
+    return c->check_overflow() ? 0 : -1;
 }
 int MsnePick(HdMoonshine* c, SensorHandle sensor, LensHandle lens, F32x2 nc, MsneClickData* out) {
     if (!c || !out) return -1;

@@ -25,7 +25,7 @@ static float half_to_float(uint16_t h) {
 
 struct Reader {
     const uint8_t* p; size_t n, pos = 0; bool ok = true;
-    bool need(size_t k) { if (pos + k > n) { ok = false; return false; } return true; }
+    bool need(size_t k) { if (pos > n || k > n - pos) { ok = false; return false; } return true; }   // (pos + k may wrap: offsets come from the file)
     uint8_t u8() { if (!need(1)) return 0; return p[pos++]; }
     uint32_t u32() { if (!need(4)) return 0; uint32_t v; memcpy(&v, p + pos, 4); pos += 4; return v; }
     int32_t i32() { return (int32_t)u32(); }
@@ -119,6 +119,7 @@ bool exr_load(const std::string& path, Image& img, std::string& err) {
     for (size_t i = 0; i < (size_t)W * H; i++) img.rgba[4 * i + 3] = 1.0f;
     std::vector<uint8_t> tmp, raw;
     for (size_t b = 0; b < nblocks; b++) {
+        if (offsets[b] >= file.size()) { err = "EXR chunk offset outside the file"; return false; }
         Reader c{ file.data(), file.size(), (size_t)offsets[b] };
         const int32_t y0 = c.i32(); const int32_t dsize = c.i32();
         if (!c.ok || dsize < 0 || !c.need((size_t)dsize)) { err = "truncated EXR chunk"; return false; }

@@ -26,14 +26,23 @@ struct JVal {
     std::vector<JVal> arr; std::vector<std::pair<std::string, JVal>> obj;
     const JVal* get(const char* k) const { if (t != OBJ) return nullptr; for (auto& kv : obj) if (kv.first == k) return &kv.second; return nullptr; }
     double number(const char* k, double d) const { const JVal* v = get(k); return v && v->t == NUM ? v->num : d; }
-    int64_t integer(const char* k, int64_t d) const { const JVal* v = get(k); return v && v->t == NUM ? (int64_t)v->num : d; }
+    // a JSON number that is not finite or does not fit (NaN, 1e300, ...) reads as -1: every caller rejects negative indices, offsets and counts
+    int64_t integer(const char* k, int64_t d) const { const JVal* v = get(k); if (!v || v->t != NUM) return d; return (v->num >= -9.0e15 && v->num <= 9.0e15) ? (int64_t)v->num : -1; }
     std::string str(const char* k, const char* d = "") const { const JVal* v = get(k); return v && v->t == STR ? v->s : std::string(d); }
     size_t size() const { return t == ARR ? arr.size() : 0; }
 };
 struct JParser {
-    const char* p; const char* e; bool ok = true;
+    const char* p; const char* e; bool ok = true; int depth = 0;
+    static constexpr int MAX_DEPTH = 64;   // glTF nests 6-7 levels; a chunk of 200 k '[' must not recurse 200 k frames deep
     void ws() { while (p < e && (*p == ' ' || *p == '\n' || *p == '\t' || *p == '\r')) p++; }
     JVal parse() {
+        JVal v;
+        if (++depth > MAX_DEPTH) { ok = false; depth--; return v; }
+        v = parse_value();
+        depth--;
+        return v;
+    }
+    JVal parse_value() {
         ws(); JVal v;
         if (p >= e) { ok = false; return v; }
         if (*p == '{') {
@@ -66,7 +75,11 @@ struct JParser {
         } else if (!strncmp(p, "true", 4)) { v.t = JVal::BOOL; v.b = true; p += 4; }
         else if (!strncmp(p, "false", 5)) { v.t = JVal::BOOL; p += 5; }
         else if (!strncmp(p, "null", 4)) { p += 4; }
-        else { char* end = nullptr; v.t = JVal::NUM; v.num = strtod(p, &end); if (end == p) ok = false; p = end; }
+        else {   // the JSON chunk is NUL-terminated by std::string, so strtod cannot run past it
+            char* end = nullptr; v.t = JVal::NUM; v.num = strtod(p, &end);
+            if (end == p || end > e || !std::isfinite(v.num)) ok = false;
+            p = end;
+        }
         return v;
     }
 };
@@ -117,9 +130,13 @@ static bool read_accessor(const Glb& g, int64_t idx, int want_components, bool a
     const JVal& bv = bvs.arr[(size_t)bvi];
     const size_t csize = ctype == 5126 || ctype == 5125 ? 4 : (ctype == 5123 || ctype == 5122 ? 2 : 1);
     const size_t elem = csize * (size_t)comps;
-    size_t stride = (size_t)bv.integer("byteStride", 0); if (!stride) stride = elem;
-    const size_t base = (size_t)bv.integer("byteOffset", 0) + (size_t)a.integer("byteOffset", 0);
-    if (count < 0 || base + (count ? (size_t)(count - 1) * stride + elem : 0) > g.bin_len) { err = "accessor out of range of the BIN chunk"; return false; }
+    // every number below comes straight from the file: negative, huge or wrapping values are rejected before any arithmetic on them
+    const int64_t bv_off = bv.integer("byteOffset", 0), acc_off = a.integer("byteOffset", 0), bv_stride = bv.integer("byteStride", 0);
+    if (count < 0 || bv_off < 0 || acc_off < 0 || bv_stride < 0 || (uint64_t)bv_off > g.bin_len || (uint64_t)acc_off > g.bin_len || (uint64_t)bv_stride > g.bin_len + elem) { err = "accessor out of range of the BIN chunk"; return false; }
+    const size_t stride = bv_stride ? (size_t)bv_stride : elem;
+    const size_t base = (size_t)bv_off + (size_t)acc_off;
+    if (count && (base > g.bin_len || elem > g.bin_len - base || (uint64_t)(count - 1) > (g.bin_len - base - elem) / stride)) { err = "accessor out of range of the BIN chunk"; return false; }
+    if (as_index) u.reserve((size_t)count * comps); else f.reserve((size_t)count * comps);
     for (int64_t i = 0; i < count; i++) for (int c = 0; c < comps; c++) {
         const uint8_t* p = g.bin + base + (size_t)i * stride + (size_t)c * csize;
         if (as_index) {
@@ -145,9 +162,9 @@ static bool image_rgb(const Glb& g, int64_t texture_index, Image8& img, std::str
     const int64_t bvi = im.integer("bufferView", -1);
     const JVal& bvs = g.arr("bufferViews");
     if (bvi < 0 || (size_t)bvi >= bvs.size()) { err = "image without bufferView (external URIs are not supported in .glb)"; return false; }
-    const size_t off = (size_t)bvs.arr[(size_t)bvi].integer("byteOffset", 0), len = (size_t)bvs.arr[(size_t)bvi].integer("byteLength", 0);
-    if (off + len > g.bin_len) { err = "image out of range"; return false; }
-    return png_decode(g.bin + off, len, img, err);
+    const int64_t off = bvs.arr[(size_t)bvi].integer("byteOffset", 0), len = bvs.arr[(size_t)bvi].integer("byteLength", 0);
+    if (off < 0 || len < 0 || (uint64_t)off > g.bin_len || (uint64_t)len > g.bin_len - (uint64_t)off) { err = "image out of range"; return false; }
+    return png_decode(g.bin + off, (size_t)len, img, err);
 }
 
 static int64_t tex_index(const JVal* parent, const char* key) {
@@ -249,7 +266,7 @@ bool glb_import(const std::string& path, const SceneSink& s, GlbSummary& out, st
     // global transforms: parent chain (zgltf getGlobalTransform)
     const JVal& nodes = g.arr("nodes");
     std::vector<int64_t> parent(nodes.size(), -1);
-    for (size_t i = 0; i < nodes.size(); i++) if (const JVal* ch = nodes.arr[i].get("children")) for (const JVal& c : ch->arr) if (c.t == JVal::NUM && (size_t)c.num < nodes.size()) parent[(size_t)c.num] = (int64_t)i;
+    for (size_t i = 0; i < nodes.size(); i++) if (const JVal* ch = nodes.arr[i].get("children")) for (const JVal& c : ch->arr) if (c.t == JVal::NUM && c.num >= 0.0 && c.num < (double)nodes.size()) parent[(size_t)c.num] = (int64_t)i;
     auto global = [&](size_t i) { M4 m = node_local(nodes.arr[i]); int guard = 0; for (int64_t p = parent[i]; p >= 0 && guard < 1024; p = parent[(size_t)p], guard++) m = m4_mul(node_local(nodes.arr[(size_t)p]), m); return m; };
 
     const JVal& meshes = g.arr("meshes");
@@ -266,7 +283,7 @@ bool glb_import(const std::string& path, const SceneSink& s, GlbSummary& out, st
             const JVal* attrs = pr.get("attributes");
             if (!attrs || attrs->t != JVal::OBJ) { err = "primitive without attributes"; return false; }
             for (auto& kv : attrs->obj) {
-                const int64_t a = (int64_t)kv.second.num;
+                const int64_t a = (kv.second.t == JVal::NUM && kv.second.num >= 0.0 && kv.second.num < 4.0e9) ? (int64_t)kv.second.num : -1;
                 if (kv.first == "POSITION") { if (!read_accessor(g, a, 3, false, pos3, dummy_u, err)) return false; }
                 else if (kv.first == "NORMAL") { if (!read_accessor(g, a, 3, false, nrm, dummy_u, err)) return false; }
                 else if (kv.first == "TEXCOORD_0") { if (!read_accessor(g, a, 2, false, uv, dummy_u, err)) return false; }

@@ -30,7 +30,7 @@ bool png_decode(const uint8_t* d, size_t n, Image8& img, std::string& err) {
     while (pos + 12 <= n) {
         const uint32_t len = be32(d + pos); const uint8_t* type = d + pos + 4; const uint8_t* body = d + pos + 8;
         if (pos + 12 + (size_t)len > n) { err = "truncated PNG"; return false; }
-        if (!memcmp(type, "IHDR", 4)) { w = be32(body); h = be32(body + 4); depth = body[8]; ctype = body[9]; interlace = body[12]; }
+        if (!memcmp(type, "IHDR", 4)) { if (len != 13) { err = "bad PNG IHDR"; return false; } w = be32(body); h = be32(body + 4); depth = body[8]; ctype = body[9]; interlace = body[12]; }
         else if (!memcmp(type, "PLTE", 4)) plte.assign(body, body + len);
         else if (!memcmp(type, "IDAT", 4)) idat.insert(idat.end(), body, body + len);
         else if (!memcmp(type, "IEND", 4)) break;

@@ -556,3 +556,50 @@ void OrcBsdfProbe(uint32_t type, const float params[6], const float wi[3], const
     orc_msample s = material_sample(&m, b, V2(sq[0], sq[1]));
     out[4] = s.dirFs.x; out[5] = s.dirFs.y; out[6] = s.dirFs.z; out[7] = s.pdf;
 }
+
+/* Batch probes of the shading functions: `n` records of PROBE_IN[fn] floats in, PROBE_OUT[fn] floats out (the table is
+ * mirrored by MsneShadeProbe in the product and by tests/second_source.py, the independent float64 restatement).
+ *  0 bsdf        {type, color rgb, metalness, roughness, ior, wi xyz, wo xyz, sq xy} -> {pdf, eval rgb, sample dir xyz, sample pdf}
+ *  1 env sample  {rand xy} -> {dir xyz, radiance rgb, pdf}            (context environment; unoccluded)
+ *  2 env eval    {dir xyz} -> {radiance rgb, pdf}
+ *  3 env incomingRadiance {dir xyz} -> {rgb}
+ *  4 squareToEqualAreaSphere {uv} -> {dir}          5 ...Inverse {dir} -> {uv}
+ *  6 squareToTriangle {sq} -> {ab}                  7 squareToGaussian {sq} -> {xy}
+ *  8 squareToCosineHemisphere {sq} -> {dir}         9 Fresnel::dielectric {cos, etaI, etaT} -> {F}
+ * 10 offsetAlongNormal {p, n} -> {p'}              11 coordinateSystem {v1} -> {v2, v3}
+ * 12 areaMeasureToSolidAngleMeasure {pos1, pos2, dir1, dir2} -> {x}
+ * 13 GGX {alpha, a xyz, b xyz} -> {D(a), Lambda(a), G(a, b)}
+ * 14 refractDir {wi, n, eta} -> {dir}              15 powerHeuristic {numf, fPdf, numg, gPdf} -> {w}
+ * 16 Frame: {n xyz, s xyz, v xyz} -> reorthogonalize(n, s) then {worldToFrame(v), frameToWorld(v)} */
+static const uint32_t PROBE_IN[17]  = { 15, 2, 3, 3, 2, 3, 2, 2, 2, 3, 6, 3, 12, 7, 7, 4, 9 };
+static const uint32_t PROBE_OUT[17] = {  8, 7, 4, 3, 3, 2, 2, 2, 3, 1, 3, 6,  1, 3, 3, 1, 6 };
+int OrcProbeBatch(OrcContext *c, int fn, const float *in, uint32_t n, float *out) {
+    if (fn < 0 || fn > 16) return -1;
+    orc_counters cnt; memset(&cnt, 0, sizeof cnt);
+    for (uint32_t i = 0; i < n; i++) {
+        const float *a = in + (size_t)i * PROBE_IN[fn]; float *o = out + (size_t)i * PROBE_OUT[fn];
+        switch (fn) {
+            case 0: OrcBsdfProbe((uint32_t)a[0], a + 1, a + 7, a + 10, a + 13, o); break;
+            case 1: { orc_lsample s = env_sample(c, V3(0, 0, 0), V3(0, 0, 1), V2(a[0], a[1]), &cnt);
+                      o[0] = s.dirWs.x; o[1] = s.dirWs.y; o[2] = s.dirWs.z; o[3] = s.radiance.x; o[4] = s.radiance.y; o[5] = s.radiance.z; o[6] = s.pdf; break; }
+            case 2: { v3 r; float p; env_eval(c, V3(a[0], a[1], a[2]), &r, &p); o[0] = r.x; o[1] = r.y; o[2] = r.z; o[3] = p; break; }
+            case 3: { v3 r = env_incoming_radiance(c, V3(a[0], a[1], a[2])); o[0] = r.x; o[1] = r.y; o[2] = r.z; break; }
+            case 4: { v3 d = square_to_equal_area_sphere(V2(a[0], a[1])); o[0] = d.x; o[1] = d.y; o[2] = d.z; break; }
+            case 5: { v2 u = square_to_equal_area_sphere_inverse(V3(a[0], a[1], a[2])); o[0] = u.x; o[1] = u.y; break; }
+            case 6: { v2 u = square_to_triangle(V2(a[0], a[1])); o[0] = u.x; o[1] = u.y; break; }
+            case 7: { v2 u = square_to_gaussian(V2(a[0], a[1])); o[0] = u.x; o[1] = u.y; break; }
+            case 8: { v3 d = square_to_cosine_hemisphere(V2(a[0], a[1])); o[0] = d.x; o[1] = d.y; o[2] = d.z; break; }
+            case 9: o[0] = fresnel_dielectric(a[0], a[1], a[2]); break;
+            case 10: { v3 r = offset_along_normal(V3(a[0], a[1], a[2]), V3(a[3], a[4], a[5])); o[0] = r.x; o[1] = r.y; o[2] = r.z; break; }
+            case 11: { v3 p, q; coordinate_system(V3(a[0], a[1], a[2]), &p, &q); o[0] = p.x; o[1] = p.y; o[2] = p.z; o[3] = q.x; o[4] = q.y; o[5] = q.z; break; }
+            case 12: o[0] = area_to_solid_angle(V3(a[0], a[1], a[2]), V3(a[3], a[4], a[5]), V3(a[6], a[7], a[8]), V3(a[9], a[10], a[11])); break;
+            case 13: o[0] = ggx_D(a[0], V3(a[1], a[2], a[3])); o[1] = ggx_Lambda(a[0], V3(a[1], a[2], a[3])); o[2] = ggx_G(a[0], V3(a[1], a[2], a[3]), V3(a[4], a[5], a[6])); break;
+            case 14: { v3 r = refract_dir(V3(a[0], a[1], a[2]), V3(a[3], a[4], a[5]), a[6]); o[0] = r.x; o[1] = r.y; o[2] = r.z; break; }
+            case 15: o[0] = power_heuristic((uint32_t)a[0], a[1], (uint32_t)a[2], a[3]); break;
+            case 16: { orc_frame f; f.n = V3(a[0], a[1], a[2]); f.s = V3(a[3], a[4], a[5]); f.t = V3(0, 0, 0); frame_reorthogonalize(&f);
+                       v3 p = frame_world_to_frame(&f, V3(a[6], a[7], a[8])), q = frame_frame_to_world(&f, V3(a[6], a[7], a[8]));
+                       o[0] = p.x; o[1] = p.y; o[2] = p.z; o[3] = q.x; o[4] = q.y; o[5] = q.z; break; }
+        }
+    }
+    return 0;
+}

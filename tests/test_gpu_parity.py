@@ -760,3 +760,59 @@ def test_contexts_render_concurrently_from_threads(gpu_api):
     assert not err, err
     for k in range(4):
         assert np.array_equal(out[k].view(np.uint32), ref[k].view(np.uint32)), "context %d" % k
+
+
+def test_contexts_build_concurrently_from_threads(gpu_api):
+    """the BVH build buffers belong to the context: four contexts whose FIRST render (BLAS + TLAS build) and later rebuilds
+    (instance edits) run at the same time from four host threads give the films they give alone"""
+    import threading
+    def scene(c, k):
+        s, l = scenes.s1(c, extent=(80, 45), grid=2 + k % 2, order=3 + k % 2)
+        c.set_pipeline(samples_per_run=1, max_bounces=4, env_samples_per_bounce=1, mesh_samples_per_bounce=1)
+        return s, l
+    def run(c, s, l, k):
+        films = []
+        for rep in range(3):
+            c.render(s, l, launches=2); films.append(c.sensor_data(s).copy())
+            c.set_instance_visibility(rep, False)        # a different set of static instances: the world BLAS is rebuilt
+        return films
+    ref = []
+    for k in range(4):
+        c = gpu_api.Context(); s, l = scene(c, k); ref.append(run(c, s, l, k)); c.close()
+    out = [None] * 4; err = []
+    ctxs = [gpu_api.Context() for _ in range(4)]
+    handles = [scene(c, k) for k, c in enumerate(ctxs)]     # scene description only: nothing is built before the first render
+    def work(k):
+        try:
+            out[k] = run(ctxs[k], *handles[k], k)
+        except Exception as e:   # noqa
+            err.append(e)
+    th = [threading.Thread(target=work, args=(k,)) for k in range(4)]
+    [t.start() for t in th]; [t.join() for t in th]
+    assert not err, err
+    for k in range(4):
+        for a, b in zip(out[k], ref[k]):
+            assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), "context %d" % k
+
+
+def test_world_blas_is_evicted_not_accumulated(gpu_api):
+    """Hydra-style visibility edits of identity instances rebuild the merged world BLAS; the pools must not grow without bound
+    (one world BLAS is kept, evicted ones are reclaimed by a pool reset) and the films stay those of a fresh context"""
+    c = gpu_api.Context()
+    s, l = scenes.s1(c, extent=(64, 36), grid=2, order=3)
+    c.set_pipeline(samples_per_run=1, max_bounces=3, env_samples_per_bounce=1, mesh_samples_per_bounce=1)
+    c.render(s, l, launches=1)
+    n0 = len(c.read_bvh()[1])
+    for rep in range(12):
+        c.set_instance_visibility(rep % 4, rep % 2 == 1)
+        c.render(s, l, launches=1)
+        nt = len(c.read_bvh()[1])
+        assert nt <= 3 * n0, "triangle pool grows with every edit (%d -> %d)" % (n0, nt)
+    film = c.sensor_data(s).copy()
+    f = gpu_api.Context()
+    s2, l2 = scenes.s1(f, extent=(64, 36), grid=2, order=3)
+    f.set_pipeline(samples_per_run=1, max_bounces=3, env_samples_per_bounce=1, mesh_samples_per_bounce=1)
+    for rep in range(12):
+        f.set_instance_visibility(rep % 4, rep % 2 == 1)
+    f.render(s2, l2, launches=1)
+    assert np.array_equal(film.view(np.uint32), f.sensor_data(s2).view(np.uint32))

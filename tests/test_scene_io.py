@@ -307,6 +307,54 @@ def test_parsers_survive_mutated_files_under_sanitizers(tmp_path, orc):
                 at = int(rs.integers(0, max(1, len(b) - 4)))
                 b[at:at + 4] = [(0xff, 0xff, 0xff, 0x7f), (0xff, 0xff, 0xff, 0xff), (0, 0, 0, 0x80), (1, 0, 0, 0)][int(rs.integers(0, 4))]
             files.append(((tmp_path / ("m_%s_%d.%s" % (name, k, ext)),), bytes(b)))
+    # crafted files (byte mutation never produces these): negative / wrapping JSON numbers, NaN-sized numbers, deep nesting,
+    # an EXR offset-table entry near 2^64, a PNG whose IHDR is shorter than 13 bytes
+    import json as _json
+    import struct as _struct
+
+    def glb_bytes(doc, bin_=b"\0" * 64, raw_json=None):
+        js = raw_json if raw_json is not None else _json.dumps(doc).encode()
+        js += b" " * (-len(js) % 4)
+        body = _struct.pack("<II", len(js), 0x4E4F534A) + js + _struct.pack("<II", len(bin_), 0x004E4942) + bin_
+        return b"glTF" + _struct.pack("<II", 2, 12 + len(body)) + body
+
+    def tri_doc(**bv):
+        view = dict(buffer=0, byteOffset=0, byteLength=36); view.update(bv)
+        return {"asset": {"version": "2.0"}, "buffers": [{"byteLength": 64}], "bufferViews": [view],
+                "accessors": [{"bufferView": 0, "componentType": 5126, "count": 3, "type": "VEC3"}],
+                "meshes": [{"primitives": [{"attributes": {"POSITION": 0}}]}], "nodes": [{"mesh": 0}, {"camera": 0}],
+                "cameras": [{"type": "perspective", "perspective": {"yfov": 0.8}}]}
+    crafted = {
+        "neg_offset.glb": glb_bytes(tri_doc(byteOffset=-100000, byteStride=100012)),
+        "wrap_stride.glb": glb_bytes(tri_doc(byteStride=2 ** 63 - 1)),
+        "huge_offset.glb": glb_bytes(tri_doc(byteOffset=1e300)),
+        "neg_count.glb": glb_bytes({**tri_doc(), "accessors": [{"bufferView": 0, "componentType": 5126, "count": -3, "type": "VEC3"}]}),
+        "acc_offset.glb": glb_bytes({**tri_doc(), "accessors": [{"bufferView": 0, "byteOffset": 2 ** 62, "componentType": 5126, "count": 3, "type": "VEC3"}]}),
+        "nan_number.glb": glb_bytes(None, raw_json=_json.dumps(tri_doc()).replace('"byteOffset": 0', '"byteOffset": 1e999').encode()),
+        "deep_nesting.glb": glb_bytes(None, raw_json=b"[" * 200000),
+        "deep_objects.glb": glb_bytes(None, raw_json=b'{"a":' * 100000),
+        "neg_image.glb": glb_bytes({**tri_doc(), "materials": [{"pbrMetallicRoughness": {"baseColorTexture": {"index": 0}}}], "textures": [{"source": 0}],
+                                    "images": [{"mimeType": "image/png", "bufferView": 1}],
+                                    "bufferViews": [dict(buffer=0, byteOffset=0, byteLength=36), dict(buffer=0, byteOffset=-8, byteLength=2 ** 63)]}),
+        "neg_attr.glb": glb_bytes({**tri_doc(), "meshes": [{"primitives": [{"attributes": {"POSITION": -1e30}}]}]}),
+    }
+    ok_exr = bytearray(seeds["exr_zip"])
+    hdr_end = ok_exr.index(b"\0\0", ok_exr.index(b"screenWindowWidth")) if b"screenWindowWidth" in ok_exr else None
+    # the offset table follows the header's terminating NUL: find it as the first u64 that points at a plausible chunk
+    for at in range(8, len(ok_exr) - 16):
+        v = _struct.unpack_from("<Q", ok_exr, at)[0]
+        if at + 8 <= v < len(ok_exr) and _struct.unpack_from("<i", ok_exr, v)[0] == 0:   # chunk of scanline 0
+            bad = bytearray(ok_exr); _struct.pack_into("<Q", bad, at, 0xFFFFFFFFFFFFFFFC); crafted["wrap_offset.exr"] = bytes(bad)
+            bad = bytearray(ok_exr); _struct.pack_into("<Q", bad, at, len(ok_exr) - 2); crafted["late_offset.exr"] = bytes(bad)
+            break
+    assert "wrap_offset.exr" in crafted
+    png = seeds["png2"]
+    assert png[12:16] == b"IHDR"
+    import zlib as _zlib
+    short_ihdr = png[:8] + _struct.pack(">I", 8) + b"IHDR" + png[16:24] + _struct.pack(">I", _zlib.crc32(b"IHDR" + png[16:24])) + png[33:]
+    crafted["short_ihdr.png"] = short_ihdr
+    for name, data in crafted.items():
+        files.append(((tmp_path / ("c_" + name),), data))
     paths = []
     for (p,), data in files:
         open(p, "wb").write(data); paths.append(str(p))
@@ -314,3 +362,5 @@ def test_parsers_survive_mutated_files_under_sanitizers(tmp_path, orc):
     out = subprocess.run([str(exe)] + paths, capture_output=True, text=True, env=env, timeout=600)
     assert out.returncode == 0, (out.stdout[-500:], out.stderr[-3000:])
     assert "accepted" in out.stdout and int(out.stdout.split()[1]) >= len(seeds)     # the unmutated files all load
+    crafted_out = subprocess.run([str(exe)] + [q for q in paths if os.path.basename(q).startswith("c_")], capture_output=True, text=True, env=env, timeout=600)
+    assert crafted_out.returncode == 0 and crafted_out.stdout.split()[1] == "0", (crafted_out.stdout[-500:], crafted_out.stderr[-3000:])   # every crafted file is REJECTED
