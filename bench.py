@@ -3,47 +3,75 @@
 packed film.  A "step" = one launch of the hot path = one sample per pixel over the rank's tiles, all bounces
 (the reference's vkCmdTraceRaysKHR, offline/main.zig:131-165).  Prints ONE JSON line on rank 0.
 
-    python bench.py --gpus 1 --steps 64 --warmup 4
+    python bench.py --gpus 1 --steps 64 --warmup 4 [--scene s2] [--env sky]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+Timed region: EXACTLY `steps` steps, bracketed by barrier + synchronize on both sides, max over ranks.  The region is
+repeated `--repeats` times (default 5, SURVEY.md §8(d): "median of >= 5 runs") on a cleared sensor; `value` is the median
+repeat, every repeat is listed in `repeat_values`.
 """
 import argparse
 import json
 import os
+import statistics
 import sys
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-import numpy as np  # noqa: E402
+import numpy as np  # noqa: E402,F401
 import torch  # noqa: E402  (before the HIP library: one HIP runtime per process)
 import torch.distributed as dist  # noqa: E402
 
 from moonshine_amd import api, scenes  # noqa: E402
 
 HBM_PEAK = 8.0e12  # B/s, /opt/skills/guides/MI355X_MICROARCH.md "HBM3E peak BW"
+KERNELS = ("k_trace_closest", "k_trace_shadow", "k_shade")
 
 
-def cpu_baseline(fixture):
-    """The oracle (a scalar C restatement, kind="port") timed on this host's cores on a bounded sample of the
-    same workload: S1 at 1920x1080, 6 spp (about 10-30 s of CPU work).  Reported baseline only — never the product path."""
+def build_scene(ctx, a):
+    if a.scene == "s2":
+        return scenes.s2(ctx, extent=(a.width, a.height))
+    return scenes.s1(ctx, extent=(a.width, a.height), env=a.env)
+
+
+def cpu_baseline(a):
+    """The oracle (a scalar C restatement, kind="port") timed on this host's cores on a bounded sample of the same
+    workload (about 10-30 s of CPU work): all hardware threads at full resolution, and ONE thread at 480x270 (SURVEY.md
+    §8(d) asks for both).  Reported baseline only — never the product path."""
     from oracle import orc
     orc.build()
     cores = os.cpu_count() or 1
-    c = orc.Context(threads=cores)
-    W, H, SPP = 1920, 1080, 16
-    s, l = scenes.s1(c, extent=(W, H))
-    c.set_pipeline(samples_per_run=1, max_bounces=8, env_samples_per_bounce=1, mesh_samples_per_bounce=1)
-    c.render(s, l, launches=1)          # builds the BVH, touches memory
-    c.reset_counters()
-    t0 = time.perf_counter()
-    c.render(s, l, launches=SPP)
-    dt = time.perf_counter() - t0
-    k = c.counters()
-    rays = k["closest_rays"] + k["shadow_rays"]
+
+    def run(threads, W, H, spp):
+        c = orc.Context(threads=threads)
+        s, l = build_scene(c, argparse.Namespace(scene=a.scene, env=a.env, width=W, height=H))
+        c.set_pipeline(samples_per_run=1, max_bounces=8, env_samples_per_bounce=1, mesh_samples_per_bounce=1)
+        c.render(s, l, launches=1)          # builds the BVH, touches memory
+        c.reset_counters()
+        t0 = time.perf_counter()
+        c.render(s, l, launches=spp)
+        dt = time.perf_counter() - t0
+        k = c.counters()
+        return k["closest_rays"] + k["shadow_rays"], k["samples"], dt
+
+    W, H, SPP = a.width, a.height, 16 if cores >= 64 else 1
+    rays, samples, dt = run(cores, W, H, SPP)
+    rays1, samples1, dt1 = run(1, 480, 270, 1)
     return {"value": rays / dt / 1e6, "unit": "Mrays/s", "cores": cores, "kind": "port",
-            "sample": "S1 (1 003 520 tris) at %dx%d, %d spp, max_bounces 8, env+mesh NEE; %d rays in %.2f s on %d threads; Msamples/s %.3f"
-                      % (W, H, SPP, rays, dt, cores, k["samples"] / dt / 1e6)}
+            "sample": "%s at %dx%d, %d spp, max_bounces 8, env+mesh NEE; %d rays in %.2f s on %d threads; Msamples/s %.3f"
+                      % (a.scene.upper(), W, H, SPP, rays, dt, cores, samples / dt / 1e6),
+            "one_thread": {"value": rays1 / dt1 / 1e6, "unit": "Mrays/s", "cores": 1,
+                           "sample": "%s at 480x270, 1 spp; %d rays in %.2f s on 1 thread" % (a.scene.upper(), rays1, dt1)}}
+
+
+def newest_counters(scene):
+    """profiles/rNN*_counters_<scene>.json: per-RAY figures from the committed rocprofv3 PMC passes of this command (HBM bytes,
+    VALU instructions, issue-busy fraction, lanes per instruction) — per ray, so they apply at any --steps"""
+    d = os.path.join(ROOT, "profiles")
+    fs = sorted(f for f in os.listdir(d) if f.endswith("_counters_%s.json" % scene))
+    return (json.load(open(os.path.join(d, fs[-1]))), fs[-1]) if fs else (None, None)
 
 
 def main():
@@ -51,8 +79,10 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=64)
     ap.add_argument("--warmup", type=int, default=4)
+    ap.add_argument("--repeats", type=int, default=5)
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
+    ap.add_argument("--scene", default="s1", choices=["s1", "s2"])
     ap.add_argument("--env", default="constant", choices=["constant", "sky"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     a = ap.parse_args()
@@ -73,7 +103,7 @@ def main():
             dist.init_process_group(backend)
 
     ctx = api.Context(device=dev, shard_index=rank, shard_count=world)
-    sensor, lens = scenes.s1(ctx, extent=(a.width, a.height), env=a.env)
+    sensor, lens = build_scene(ctx, a)
     ctx.set_pipeline(samples_per_run=1, max_bounces=8, env_samples_per_bounce=1, mesh_samples_per_bounce=1)
     ctx.set_profiling(kernel_events=True, traversal_counters=False)
     ctx.reserve(sensor, max(a.steps, a.warmup))   # wavefront state for the whole batch, allocated outside the timed region
@@ -112,55 +142,79 @@ def main():
     if a.warmup:
         ctx.render(sensor, lens, launches=a.warmup, readback=False)
     gather()
-    ctx.clear_sensor(sensor)
+    warm = ctx.stats()
     ctx.reset_stats()
-    sync()
-    t0 = time.perf_counter()
-    ctx.render(sensor, lens, launches=a.steps, readback=False)   # EXACTLY K steps; returns after the stream is idle
-    gather()
-    sync()
-    dt = time.perf_counter() - t0
-    st = ctx.stats()
+    times = []
+    for _ in range(max(a.repeats, 1)):
+        ctx.clear_sensor(sensor)
+        sync()
+        t0 = time.perf_counter()
+        ctx.render(sensor, lens, launches=a.steps, readback=False)   # EXACTLY K steps; returns after the stream is idle
+        gather()
+        sync()
+        times.append(time.perf_counter() - t0)
+    st = ctx.stats()          # sums over the repeats (every repeat traces the same rays: same sample indices)
+    R = len(times)
 
-    tt = torch.tensor([dt, float(st["closest_rays"]), float(st["shadow_rays"]), float(st["samples"])], dtype=torch.float64, device="cuda")
+    tt = torch.tensor(times + [float(st["closest_rays"]) / R, float(st["shadow_rays"]) / R, float(st["samples"]) / R], dtype=torch.float64, device="cuda")
     if world > 1:
         tmax = tt.clone(); dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dist.all_reduce(tt, op=dist.ReduceOp.SUM)
-        dt = float(tmax[0])
-    closest, shadow, samples = float(tt[1]), float(tt[2]), float(tt[3])
+        times = [float(x) for x in tmax[:R]]
+    closest, shadow, samples = float(tt[R]), float(tt[R + 1]), float(tt[R + 2])     # per repeat, all ranks
     rays = closest + shadow
+    dt = statistics.median(times)
 
     if rank == 0:
-        fx = json.load(open(os.path.join(ROOT, "tests", "golden", "roofline_s1.json")))
-        b_ray = fx["B_ray"]
-        # dominant kernel: k_trace_closest — algorithmic bytes per launch / average launch duration (HIP events on the render stream)
-        nl = max(int(st["trace_closest_launches"]), 1)
-        avg_ms = st["trace_closest_ms"] / nl
-        bytes_per_launch = b_ray * st["closest_rays"] / nl
+        fx = json.load(open(os.path.join(ROOT, "tests", "golden", "roofline_%s.json" % a.scene)))
+        # bytes per unit of each kernel: V_n * 80 + V_t * 48 + 48 with the kernel's OWN canonical visit counts;
+        # k_shade: B_hit per surface hit + the 288 B of wavefront state it reads and writes per path
+        unit_bytes = {"k_trace_closest": fx["V_n_closest"] * 80 + fx["V_t_closest"] * 48 + 48,
+                      "k_trace_shadow": fx["V_n_shadow"] * 80 + fx["V_t_shadow"] * 48 + 48,
+                      "k_shade": fx["B_hit"] + 288.0}
+        # this rank's per-kernel time (HIP events on the stream each kernel is launched on), launches and units, summed over the repeats
+        kms = {"k_trace_closest": st["trace_closest_ms"], "k_trace_shadow": st["trace_shadow_ms"], "k_shade": st["shade_ms"]}
+        kln = {"k_trace_closest": st["trace_closest_launches"], "k_trace_shadow": st["trace_shadow_launches"], "k_shade": st["shade_launches"]}
+        kun = {"k_trace_closest": float(st["closest_rays"]), "k_trace_shadow": float(st["shadow_rays"]), "k_shade": float(st["closest_rays"])}
+        dom = max(KERNELS, key=lambda k: kms[k])          # the dominant kernel is whichever took the most time in THIS run
+        nl = max(int(kln[dom]), 1)
+        avg_ms = kms[dom] / nl
+        bytes_per_launch = unit_bytes[dom] * kun[dom] / nl
         achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
-        # HBM bytes per launch from the committed PMC passes (tools/profile_round.sh; FETCH_SIZE x2 + WRITE_SIZE) — only valid
-        # for the exact configuration they were collected on
-        traffic = None
-        tps = sorted(f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("_traffic.json"))   # newest round last
-        if tps and world == 1 and a.steps == 64 and (a.width, a.height, a.env) == (1920, 1080, "constant"):
-            traffic = json.load(open(os.path.join(ROOT, "profiles", tps[-1])))["traffic_bytes_per_launch"]
+        roof = {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
+                "frac": achieved / (HBM_PEAK / 1e9), "traffic": None, "algorithmic_bytes_per_launch": bytes_per_launch,
+                "bytes_per_unit": unit_bytes[dom], "units_per_launch": kun[dom] / nl, "avg_launch_ms": avg_ms, "launches": nl,
+                "note": "k_trace_closest(b+1) and k_trace_shadow(b) overlap on two streams: per-kernel durations include co-residency"}
+        cnt, cnt_file = newest_counters(a.scene if a.env == "constant" else a.scene + "_sky")
+        if cnt and dom in cnt["kernels"]:
+            k = cnt["kernels"][dom]
+            roof["traffic"] = k["hbm_bytes_per_unit"] * kun[dom] / nl           # measured HBM bytes per launch (PMC, per unit x this run's units)
+            roof["valu"] = {"issue_busy_frac": k["valu_issue_busy_frac"], "lanes_per_instruction": k["lanes_per_valu_instruction"],
+                            "thread_instructions_per_unit": k["valu_thread_instructions_per_unit"], "wave_instructions_per_unit": k["valu_wave_instructions_per_unit"],
+                            "source": "profiles/" + cnt_file}
+        rates = [rays / t / 1e6 for t in times]
         out = {
-            "metric": "Mrays/sec, 1M-tri scene @1080p", "value": rays / dt / 1e6, "unit": "Mrays/s",
+            "metric": "Mrays/sec, 1M-tri scene @1080p" if a.scene == "s1" else "Mrays/sec, 10M-tri instanced scene @1080p",
+            "value": rays / dt / 1e6, "unit": "Mrays/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3,
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "S1: 7x7 order-5 icospheres (1 003 520 tris) + ground + emissive quad, %dx%d, %d spp, max_bounces 8, env+mesh NEE with MIS, %s env"
-                                   % (a.width, a.height, a.steps, a.env),
+            "config": {"workload": ("S1: 7x7 order-5 icospheres (1 003 520 tris) + ground + emissive quad" if a.scene == "s1" else
+                                    "S2: 500 instances of one order-5 icosphere (10 240 000 instanced tris), glass / GGX")
+                                   + ", %dx%d, %d spp, max_bounces 8, env+mesh NEE with MIS, %s env" % (a.width, a.height, a.steps, a.env),
                        "sharding": "16x16 image tiles, tile t -> rank t mod %d, one RCCL gather of the packed film" % world},
+            "repeats": R, "repeat_values": rates, "spread": (max(rates) - min(rates)) / statistics.median(rates),
             "msamples_per_s": samples / dt / 1e6,
             "rays": {"closest": closest, "shadow": shadow, "per_sample": rays / max(samples, 1.0)},
-            "roofline": {"bound": "hbm", "kernel": "k_trace_closest", "achieved": achieved, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
-                         "frac": achieved / (HBM_PEAK / 1e9), "traffic": traffic, "algorithmic_bytes_per_launch": bytes_per_launch,
-                         "bytes_per_ray": b_ray, "rays_per_launch": st["closest_rays"] / nl, "avg_launch_ms": avg_ms, "launches": nl},
-            "whole_path_roofline_frac": (rays / dt * b_ray + samples / dt * (fx["B_shade"] + 32)) / HBM_PEAK / world,
-            "kernel_ms": {"trace_closest": st["trace_closest_ms"], "trace_shadow": st["trace_shadow_ms"], "shade": st["shade_ms"], "render": st["render_ms"]},
+            "roofline": roof,
+            "whole_path_roofline_frac": (rays / dt * fx["B_ray"] + samples / dt * (fx["B_shade"] + 32)) / HBM_PEAK / world,
+            "kernel_ms_per_repeat": {k: kms[k] / R for k in KERNELS}, "render_ms_per_repeat": st["render_ms"] / R,
+            "kernel_frac": {k: unit_bytes[k] * kun[k] / max(kms[k] * 1e-3, 1e-12) / HBM_PEAK for k in KERNELS},
+            # for tools/profile_counters.py: what the counters of a rocprofv3 run of this command have to be divided by
+            "profile_totals": {"closest_rays": warm["closest_rays"] + st["closest_rays"], "shadow_rays": warm["shadow_rays"] + st["shadow_rays"],
+                               "samples": warm["samples"] + st["samples"]},
         }
         if world == 1 and not a.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(fx)
+            out["cpu_baseline"] = cpu_baseline(a)
         print(json.dumps(out))
     if world > 1:
         dist.barrier()

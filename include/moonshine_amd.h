@@ -169,6 +169,8 @@ typedef struct MsneStats {
     double   shade_ms;
     double   render_ms;        /* first raygen launch → film complete, summed over MsneRender calls */
     uint64_t trace_closest_launches;
+    uint64_t trace_shadow_launches;
+    uint64_t shade_launches;
 } MsneStats;
 
 HdMoonshine* MsneCreate(const MsneConfig*);                       /* HdMoonshineCreate with placement */
@@ -239,8 +241,15 @@ const char* MsneGetIoError(void);
  * traversal_counters: count BVH node visits / triangle tests inside the trace kernels. */
 void MsneSetProfiling(HdMoonshine*, int kernel_events, int traversal_counters);
 int MsneGetTraversalCounters(HdMoonshine*, uint64_t out[20]); /* [0..3] closest {nodes,tris}, shadow {nodes,tris}; [4..19] wave-cycle profiles */
+/* queue lengths of the last batch, per bounce b: out[4b..4b+3] = {path-queue entries, of which entries without a ray, shadow-queue entries, shadow rays traced}; returns the number of bounces written */
+int MsneGetBounceCounters(HdMoonshine*, uint32_t* out, uint32_t max_bounces);
 /* rays: 7 floats each (origin, direction, tmax); out_ids: 4 per ray {hit, instance, geometry, primitive}; out_tuv: 3 per ray */
 int MsneTraceRays(HdMoonshine*, const float* rays, uint32_t n, int any_hit, uint32_t* out_ids, float* out_tuv);
+/* Batch probe of the device-side shading functions (the material.hlsl / light.hlsl / mappings.hlsl / math.hlsl restatements that
+ * k_shade runs), one record per thread: fn 0 BSDF pdf/eval/sample, 1-3 EnvMap sample/eval/incomingRadiance on the context's
+ * environment, 4-8 sampling warps, 9 Fresnel::dielectric, 10 offsetAlongNormal, 11 coordinateSystem, 12 areaMeasureToSolidAngleMeasure,
+ * 13 GGX D/Lambda/G, 14 refractDir, 15 powerHeuristic, 16 Frame.  Record widths: tests/second_source.py PROBES. */
+int MsneShadeProbe(HdMoonshine*, int fn, const float* in, uint32_t n, float* out);
 uint32_t MsneGetEnvSize(const HdMoonshine*);
 int MsneReadEnv(HdMoonshine*, float* rgb_out, float* lum_pyramid_out);
 uint32_t MsneGetAliasTable(HdMoonshine*, void* out_entries_20B, uint32_t max_entries);

@@ -72,7 +72,7 @@ class MsneClickData(C.Structure):   # input.hlsl:24-29
 class MsneStats(C.Structure):
     _fields_ = [("closest_rays", C.c_uint64), ("shadow_rays", C.c_uint64), ("samples", C.c_uint64), ("launches", C.c_uint64),
                 ("trace_closest_ms", C.c_double), ("trace_shadow_ms", C.c_double), ("shade_ms", C.c_double), ("render_ms", C.c_double),
-                ("trace_closest_launches", C.c_uint64)]
+                ("trace_closest_launches", C.c_uint64), ("trace_shadow_launches", C.c_uint64), ("shade_launches", C.c_uint64)]
 
 
 GLASS, LAMBERT, PERFECT_MIRROR, STANDARD_PBR = 0, 1, 2, 3
@@ -136,6 +136,8 @@ SYMBOLS = [
     ("MsneGetEnvSize", _u32, [_vp]),
     ("MsneReadEnv", C.c_int, [_vp, _vp, _vp]),
     ("MsneGetAliasTable", _u32, [_vp, _vp, _u32]),
+    ("MsneGetBounceCounters", C.c_int, [_vp, _vp, _u32]),
+    ("MsneShadeProbe", C.c_int, [_vp, C.c_int, _vp, _u32, _vp]),
     ("MsneReadBvh", C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
 ]
 
@@ -418,6 +420,20 @@ class Context:
         buf = np.zeros(n, dt)
         self.L.MsneGetAliasTable(self.h, _ptr(buf), n)
         return buf
+
+    def bounce_counters(self, max_bounces=16):
+        out = np.zeros((max_bounces, 4), np.uint32)
+        n = self.L.MsneGetBounceCounters(self.h, _ptr(out), max_bounces)
+        if n < 0:
+            self._err("MsneGetBounceCounters")
+        return out[:n]
+
+    def shade_probe(self, fn, win, wout, x):
+        """batch probe of the device shading functions (MsneShadeProbe): x (n, win) float32 -> (n, wout) float32"""
+        x = _f32(x, (-1, win)); out = np.zeros((len(x), wout), np.float32)
+        if self.L.MsneShadeProbe(self.h, fn, _ptr(x), len(x), _ptr(out)) != 0:
+            self._err("MsneShadeProbe")
+        return out
 
     def read_bvh(self):
         nn, nt, ni, root = C.c_uint32(0), C.c_uint32(0), C.c_uint32(0), C.c_uint32(0)

@@ -165,14 +165,142 @@ def look_at_yup(eye, target, up=(0, 1, 0)):
     return m
 
 
-def exr_bytes(rgba, channels="RGB", pixel_type="float", compression="none"):
+# ---------------- PIZ (OpenEXR's wavelet + Huffman scheme), encoder side ----------------
+# Written from the published description of the scheme (OpenEXR "PIZ": per 32-line block the 16-bit words of every channel are
+# (1) remapped onto 0..k through a bitmap of the values that occur, (2) transformed by a 2-D two-tap wavelet, level by level,
+# (3) Huffman-coded with canonical codes and a run-length escape).  Array-at-a-time numpy here; the C++ reader
+# (host/exr.cpp) walks pointers: the two share no code, only the format.
+def _piz_wenc(a, b, w14):
+    a = a.astype(np.int64); b = b.astype(np.int64)
+    if w14:
+        sa = np.where(a >= 0x8000, a - 0x10000, a); sb = np.where(b >= 0x8000, b - 0x10000, b)
+        return ((sa + sb) >> 1) & 0xffff, (sa - sb) & 0xffff
+    ao = (a + 0x8000) & 0xffff
+    m = (ao + b) >> 1
+    d = ao - b
+    m = np.where(d < 0, (m + 0x8000) & 0xffff, m)
+    return m, d & 0xffff
+
+
+def _piz_wavelet(plane, max_value):
+    """plane: (ny, nx) array of words, transformed in place level by level (finest first)"""
+    a = plane.astype(np.int64)
+    ny, nx = a.shape
+    w14 = max_value < (1 << 14)
+    p, p2 = 1, 2
+    while p2 <= min(nx, ny):
+        qy, qx = ny // p2, nx // p2
+        Y = np.arange(qy) * p2; X = np.arange(qx) * p2
+        y0, x0 = np.meshgrid(Y, X, indexing="ij")
+        i00, i01 = _piz_wenc(a[y0, x0], a[y0, x0 + p], w14)
+        i10, i11 = _piz_wenc(a[y0 + p, x0], a[y0 + p, x0 + p], w14)
+        a[y0, x0], a[y0 + p, x0] = _piz_wenc(i00, i10, w14)
+        a[y0, x0 + p], a[y0 + p, x0 + p] = _piz_wenc(i01, i11, w14)
+        if nx & p:      # a column without a right-hand partner: vertical pairs only
+            xl = qx * p2
+            a[Y, xl], a[Y + p, xl] = _piz_wenc(a[Y, xl], a[Y + p, xl], w14)
+        if ny & p:      # a row without a partner below: horizontal pairs only
+            yl = qy * p2
+            a[yl, X], a[yl, X + p] = _piz_wenc(a[yl, X], a[yl, X + p], w14)
+        p, p2 = p2, p2 * 2
+    return a.astype(np.uint16)
+
+
+def _piz_huffman(words, use_rle=True):
+    """-> the Huffman section: 20-byte header {im, iM, table bytes, data bits, 0}, packed code lengths, coded words"""
+    import heapq
+    words = np.asarray(words, np.int64)
+    freq = np.bincount(words, minlength=65537).astype(np.int64)
+    im = int(np.flatnonzero(freq)[0]); iM = int(np.flatnonzero(freq)[-1]) + 1
+    freq[iM] = 1                                   # the run-length escape takes the first free symbol above the data
+    heap = [(int(freq[s]), int(s), (int(s),)) for s in np.flatnonzero(freq)]
+    heapq.heapify(heap)
+    length = np.zeros(65537, np.int64)
+    if len(heap) == 1:
+        length[heap[0][1]] = 1
+    while len(heap) > 1:
+        fa, ka, sa = heapq.heappop(heap); fb, kb, sb = heapq.heappop(heap)
+        for t in sa + sb:
+            length[t] += 1
+        heapq.heappush(heap, (fa + fb, min(ka, kb), sa + sb))
+    assert length.max() <= 58
+    # canonical codes: the longest codes get the numerically smallest values; within a length, symbols in index order
+    count = np.bincount(length, minlength=59)
+    first = np.zeros(59, np.int64); c = 0
+    for l in range(58, 0, -1):
+        first[l] = c; c = (c + int(count[l])) >> 1
+    code = np.zeros(65537, object); nxt = [int(x) for x in first]
+    for sym in np.flatnonzero(length):
+        code[sym] = nxt[length[sym]]; nxt[length[sym]] += 1
+    bits = []                                       # (value, number of bits), most significant bit first
+
+    def put(v, n):
+        bits.append((int(v), int(n)))
+    sym = im
+    while sym <= iM:                                # 6 bits per length; 59..62 = 2..5 zeros, 63 + 8 bits = 6..261 zeros
+        if length[sym] == 0:
+            run = 1
+            while sym + run <= iM and length[sym + run] == 0 and run < 261:
+                run += 1
+            if run >= 6:
+                put(63, 6); put(run - 6, 8); sym += run; continue
+            if run >= 2:
+                put(59 + run - 2, 6); sym += run; continue
+        put(length[sym], 6); sym += 1
+    table_bits = sum(n for _, n in bits)
+    bits.append((0, -table_bits % 8))               # the table ends on a byte boundary
+    start = len(bits)
+    edges = np.flatnonzero(np.diff(words)) + 1
+    for a0, a1 in zip(np.concatenate([[0], edges]), np.concatenate([edges, [len(words)]])):
+        sy = int(words[a0]); n = int(a1 - a0)
+        while n > 0:
+            k = min(n, 256); n -= k                  # one symbol followed by up to 255 repeats
+            if use_rle and length[sy] + length[iM] + 8 < length[sy] * (k - 1):
+                put(code[sy], length[sy]); put(code[iM], length[iM]); put(k - 1, 8)
+            else:
+                for _ in range(k):
+                    put(code[sy], length[sy])
+    data_bits = sum(n for _, n in bits[start:])
+    v = np.array([b[0] for b in bits], np.uint64); n = np.array([b[1] for b in bits], np.int64)
+    k = np.arange(58)[None, :]
+    on = k < n[:, None]                                                  # bit k of entry i, most significant first
+    shift = np.where(on, n[:, None] - 1 - k, 0).astype(np.uint64)
+    stream = ((v[:, None] >> shift) & np.uint64(1)).astype(np.uint8)[on]
+    payload = np.packbits(stream).tobytes()                              # zero-padded to a byte boundary
+    return struct.pack("<IIIII", im, iM, (table_bits + 7) // 8, data_bits, 0) + payload
+
+
+def piz_block(lines, words_per_pixel, use_rle=True):
+    """lines: list (one per scanline) of lists (one per channel, file order) of uint16 word arrays (FLOAT / UINT pixels = 2 words,
+    low word first) -> the block's compressed bytes"""
+    planes = [np.stack([np.asarray(l[c], np.uint16) for l in lines]) for c in range(len(words_per_pixel))]   # (ny, nx * words per pixel)
+    allw = np.concatenate([p.reshape(-1) for p in planes])
+    used = np.zeros(65536, bool); used[allw] = True; used[0] = False                                # zero is always in the table, never in the bitmap
+    bitmap = np.packbits(used.reshape(-1, 8)[:, ::-1], axis=1).reshape(-1)                          # bit (v & 7) of byte (v >> 3)
+    nz = np.flatnonzero(bitmap)
+    mn, mx = (int(nz[0]), int(nz[-1])) if len(nz) else (8191, 0)
+    present = used.copy(); present[0] = True
+    lut = np.zeros(65536, np.int64); lut[present] = np.arange(int(present.sum()))
+    max_value = int(present.sum()) - 1
+    coded = []
+    for p, wpp in zip(planes, words_per_pixel):
+        ny, n = p.shape
+        t = lut[p].reshape(ny, n // wpp, wpp)
+        for j in range(wpp):                        # the low and the high words of a wide channel are transformed as separate images
+            t[:, :, j] = _piz_wavelet(t[:, :, j], max_value)
+        coded.append(t.reshape(-1))
+    huf = _piz_huffman(np.concatenate(coded), use_rle)
+    return struct.pack("<HH", mn, mx) + (bitmap[mn:mx + 1].tobytes() if mn <= mx else b"") + struct.pack("<i", len(huf)) + huf
+
+
+def exr_bytes(rgba, channels="RGB", pixel_type="float", compression="none", piz_rle=True):
     """(H, W, 4) float32 -> scanline OpenEXR bytes.  channels: subset of 'ABGR' letters; pixel_type float|half;
-    compression none|zips|zip.  Written from the OpenEXR file-layout document, independently of the C++ reader."""
+    compression none|zips|zip|piz.  Written from the OpenEXR file-layout document, independently of the C++ reader."""
     a = np.asarray(rgba, np.float32)
     h, w, _ = a.shape
     names = sorted(channels)
     ptype = {"float": 2, "half": 1}[pixel_type]
-    comp = {"none": 0, "zips": 2, "zip": 3}[compression]
+    comp = {"none": 0, "zips": 2, "zip": 3, "piz": 4}[compression]
 
     def attr(name, typ, data):
         return name.encode() + b"\0" + typ.encode() + b"\0" + struct.pack("<I", len(data)) + data
@@ -182,17 +310,25 @@ def exr_bytes(rgba, channels="RGB", pixel_type="float", compression="none"):
         + attr("dataWindow", "box2i", box) + attr("displayWindow", "box2i", box) + attr("lineOrder", "lineOrder", b"\0") \
         + attr("pixelAspectRatio", "float", struct.pack("<f", 1.0)) + attr("screenWindowCenter", "v2f", struct.pack("<ff", 0, 0)) \
         + attr("screenWindowWidth", "float", struct.pack("<f", 1.0)) + b"\0"
-    lines = {0: 1, 2: 1, 3: 16}[comp]
+    lines = {0: 1, 2: 1, 3: 16, 4: 32}[comp]
     col = {"R": 0, "G": 1, "B": 2, "A": 3}
     blocks = []
     for y0 in range(0, h, lines):
         raw = bytearray()
+        rows = []
         for y in range(y0, min(y0 + lines, h)):
+            rows.append([])
             for n in names:
                 v = a[y, :, col[n]]
-                raw += (v.astype(np.float16) if ptype == 1 else v).tobytes()
+                enc = (v.astype(np.float16) if ptype == 1 else v).tobytes()
+                raw += enc
+                rows[-1].append(np.frombuffer(enc, "<u2"))
         data = bytes(raw)
-        if comp:
+        if comp == 4:
+            z = piz_block(rows, [1 if ptype == 1 else 2] * len(names), piz_rle)
+            if len(z) < len(data):
+                data = z
+        elif comp:
             b = np.frombuffer(data, np.uint8)
             half = (len(b) + 1) // 2
             t = np.concatenate([b[0::2], b[1::2]]).astype(np.int16)

@@ -29,6 +29,8 @@ void launch_account(hipStream_t, const BounceCounters*, uint32_t, Totals*);
 void launch_light_tris(hipStream_t, const SceneView&, uint32_t, uint32_t, LightTri*);
 void launch_film(hipStream_t, int, const ShardView&, const PipelineOpts&, const float4*, uint32_t, uint32_t, int, int, uint32_t, float4*, float4*);
 void launch_unpack_film(hipStream_t, int, const ShardView&, const float4*, uint32_t, uint32_t, size_t, float4*);
+bool shade_probe_widths(int, uint32_t&, uint32_t&);
+void launch_shade_probe(hipStream_t, const SceneView&, int, const float*, uint32_t, float*);
 void launch_env_build(hipStream_t, const float4*, uint32_t, uint32_t, float4*, float*, const uint32_t*, uint32_t, uint32_t);
 struct BlasGeo { const float* positions; const uint32_t* indices; uint32_t tri_offset, tri_count, geo, inst; };
 struct BuildScratch;   // per-context build buffers (bvh_build.hip)
@@ -138,6 +140,7 @@ struct HdMoonshine {
     };
     static constexpr int MAX_PIPES = 4;
     Pipe pipes[MAX_PIPES];
+    bool serial_streams = false;                   // $MSNE_SERIAL=1: k_trace_shadow runs in stream order on s0 instead of overlapping the next bounce's k_trace_closest (profiling: per-kernel times without co-residency)
     int n_pipes = 1;                               // $MSNE_PIPES (measured on S1: more pipes never won — bigger batches beat overlapped smaller ones)
     size_t single_pipe_paths = 48u << 20;          // batches at least this large run on one pipe (tails are negligible there)
     DevBuf<float4> d_lbuf;
@@ -642,6 +645,7 @@ bool HdMoonshine::render(uint32_t sensor, uint32_t lens, uint32_t launches, bool
         CHECK_HIP(this, hipMemsetAsync(cnt, 0, ((size_t)max_iter + 2) * sizeof(BounceCounters), pp.s0));
         launch_raygen(pp.s0, shade_grid, s->shard, cam, opts, first_sample, ns, st[0], cnt);
         hipEvent_t shadow_done = nullptr;
+        const hipStream_t sh_stream = serial_streams ? pp.s0 : pp.s1;
         for (uint32_t b = 0; b < max_iter; b++) {
             const PathState& cur = st[b & 1]; const PathState& nxt = st[(b + 1) & 1];
             timed2(0, pp.s0, [&] { launch_trace_closest(pp.s0, trace_grid, trace_stats, sv, cur, hits, cnt + b, pp.spill.p, d_overflow.p, d_trace_stats.p, refill); });
@@ -651,11 +655,11 @@ bool HdMoonshine::render(uint32_t sensor, uint32_t lens, uint32_t launches, bool
             hipEvent_t shade_done = next_event();
             if (!shade_done) { fail("hipEventCreate failed"); return false; }
             CHECK_HIP(this, hipEventRecord(shade_done, pp.s0));
-            CHECK_HIP(this, hipStreamWaitEvent(pp.s1, shade_done, 0));
-            timed2(1, pp.s1, [&] { launch_trace_shadow(pp.s1, trace_grid, trace_stats, sv, shq, cnt + b + 1, pp.spill2.p, d_overflow.p, d_trace_stats.p, std::max(1u, refill / 2)); });   // the shadow queue has unused entries (light samples with pdf 0): refill sooner
+            CHECK_HIP(this, hipStreamWaitEvent(sh_stream, shade_done, 0));
+            timed2(1, sh_stream, [&] { launch_trace_shadow(sh_stream, trace_grid, trace_stats, sv, shq, cnt + b + 1, pp.spill2.p, d_overflow.p, d_trace_stats.p, std::max(1u, refill / 2)); });   // the shadow queue has unused entries (light samples with pdf 0): refill sooner
             shadow_done = next_event();
             if (!shadow_done) { fail("hipEventCreate failed"); return false; }
-            CHECK_HIP(this, hipEventRecord(shadow_done, pp.s1));
+            CHECK_HIP(this, hipEventRecord(shadow_done, sh_stream));
             if (b >= 15 && (b & 3) == 3) {   // long tails (max_bounces = 1024 offline): poll the queue length every 4 bounces
                 uint32_t n_next = 0;
                 CHECK_HIP(this, hipMemcpyAsync(&n_next, &cnt[b + 1].n_paths, 4, hipMemcpyDeviceToHost, pp.s0));
@@ -713,7 +717,9 @@ bool HdMoonshine::render(uint32_t sensor, uint32_t lens, uint32_t launches, bool
     if (ev_begin && ev_end && hipEventElapsedTime(&ms, ev_begin, ev_end) == hipSuccess) stats.render_ms += ms;
     for (const Span& sp : spans) {
         if (hipEventElapsedTime(&ms, events[sp.a], events[sp.b]) != hipSuccess) continue;
-        if (sp.kind == 0) { stats.trace_closest_ms += ms; stats.trace_closest_launches++; } else if (sp.kind == 1) stats.trace_shadow_ms += ms; else stats.shade_ms += ms;
+        if (sp.kind == 0) { stats.trace_closest_ms += ms; stats.trace_closest_launches++; }
+        else if (sp.kind == 1) { stats.trace_shadow_ms += ms; stats.trace_shadow_launches++; }
+        else { stats.shade_ms += ms; stats.shade_launches++; }
     }
     return true;
 }
@@ -756,6 +762,7 @@ HdMoonshine* MsneCreate(const MsneConfig* cfg_in) {
     { c->trace_grid = prop.multiProcessorCount * trace_blocks_per_cu(); c->shade_grid = prop.multiProcessorCount * 8; c->shade_k_grid = prop.multiProcessorCount * 96; }   // k_shade: workgroups differ in cost (what their 256 paths hit); 96 per CU instead of 8 evens the CUs out (-6 %)
     if (const char* e = getenv("MSNE_SHADE_BLOCKS_PER_CU")) c->shade_k_grid = prop.multiProcessorCount * std::max(1, atoi(e));
     if (const char* e = getenv("MSNE_MAX_INFLIGHT")) c->max_inflight = (size_t)atoll(e);
+    if (const char* e = getenv("MSNE_SERIAL")) c->serial_streams = atoi(e) != 0;
     if (const char* e = getenv("MSNE_PIPES")) c->n_pipes = std::max(1, std::min((int)HdMoonshine::MAX_PIPES, atoi(e)));
     if (const char* e = getenv("MSNE_SINGLE_PIPE_PATHS")) c->single_pipe_paths = (size_t)atoll(e);
     if (const char* e = getenv("MSNE_REFILL")) c->refill = (uint32_t)std::max(1, std::min(64, atoi(e)));
@@ -981,6 +988,29 @@ int MsneTraceRays(HdMoonshine* c, const float* rays, uint32_t n, int any_hit, ui
     if (hipMemcpyAsync(out_tuv, dt.p, 12 * (size_t)n, hipMemcpyDeviceToHost, c->stream) != hipSuccess) return -1;
     if (hipStreamSynchronize(c->stream) != hipSuccess) { c->fail("probe failed"); return -1; }
     return c->check_overflow() ? 0 : -1;
+}
+// queue lengths of the last batch traced on pipe 0, per bounce: {paths, of which zombies, shadow entries, shadow rays traced}
+int MsneGetBounceCounters(HdMoonshine* c, uint32_t* out, uint32_t max_bounces) {
+    LOCK(c);
+    if (!c->bind() || !out || !c->pipes[0].counters.p) return -1;
+    const uint32_t n = (uint32_t)std::min<size_t>(max_bounces, c->pipes[0].counters.n);
+    std::vector<BounceCounters> h(n);
+    if (hipMemcpy(h.data(), c->pipes[0].counters.p, n * sizeof(BounceCounters), hipMemcpyDeviceToHost) != hipSuccess) return -1;
+    for (uint32_t b = 0; b < n; b++) { out[4 * b] = h[b].n_paths; out[4 * b + 1] = h[b].zombies; out[4 * b + 2] = h[b].n_shadow_in; out[4 * b + 3] = h[b].n_shadow_traced; }
+    return (int)n;
+}
+// batch probe of the device shading functions (material / light / mapping code of k_shade), see k_shade_probe
+int MsneShadeProbe(HdMoonshine* c, int fn, const float* in, uint32_t n, float* out) {
+    LOCK(c);
+    uint32_t win = 0, wout = 0;
+    if (!c->bind() || !in || !out || !shade_probe_widths(fn, win, wout)) { c->fail("shade probe: bad arguments"); return -1; }
+    if (n == 0) return 0;
+    DevBuf<float> di, dout;
+    if (!di.alloc((size_t)n * win) || !dout.alloc((size_t)n * wout)) { c->fail("out of device memory (probe)"); return -1; }
+    if (hipMemcpyAsync(di.p, in, (size_t)n * win * 4, hipMemcpyHostToDevice, c->stream) != hipSuccess) return -1;
+    launch_shade_probe(c->stream, c->scene_view(), fn, di.p, n, dout.p);
+    if (hipMemcpyAsync(out, dout.p, (size_t)n * wout * 4, hipMemcpyDeviceToHost, c->stream) != hipSuccess || hipStreamSynchronize(c->stream) != hipSuccess) { c->fail("shade probe failed"); return -1; }
+    return 0;
 }
 int MsnePick(HdMoonshine* c, SensorHandle sensor, LensHandle lens, F32x2 nc, MsneClickData* out) {
     if (!c || !out) return -1;

@@ -398,6 +398,51 @@ __global__ __launch_bounds__(SHADE_BLOCK) void k_unpack_film(ShardView sh, const
     }
 }
 
+// Batch probe of the shading functions for parity tests (MsneShadeProbe): the SAME device functions k_shade runs, one record
+// per thread.  The table (function codes, record widths) is the test oracle's OrcProbeBatch.
+__constant__ uint32_t c_probe_in[17]  = { 15, 2, 3, 3, 2, 3, 2, 2, 2, 3, 6, 3, 12, 7, 7, 4, 9 };
+__constant__ uint32_t c_probe_out[17] = {  8, 7, 4, 3, 3, 2, 2, 2, 3, 1, 3, 6,  1, 3, 3, 1, 6 };
+__global__ void k_shade_probe(SceneView sc, int fn, const float* in, uint32_t n, float* out) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float* a = in + (size_t)i * c_probe_in[fn]; float* o = out + (size_t)i * c_probe_out[fn];
+    switch (fn) {
+        case 0: {
+            Mat m; m.type = (uint32_t)a[0]; m.color = F3(a[1], a[2], a[3]); m.metalness = a[4]; m.alpha = maxf(a[5] * a[5], 0.001f); m.ior = a[6];
+            const f3 wi = F3(a[7], a[8], a[9]), wo = F3(a[10], a[11], a[12]);
+            o[0] = material_pdf(m, wi, wo);
+            const f3 e = material_eval(m, wi, wo); o[1] = e.x; o[2] = e.y; o[3] = e.z;
+            const MSample s = material_sample(m, wo, F2(a[13], a[14])); o[4] = s.dirFs.x; o[5] = s.dirFs.y; o[6] = s.dirFs.z; o[7] = s.pdf;
+            break; }
+        case 1: { const LSample s = env_sample_unoccluded(sc.env, F2(a[0], a[1])); o[0] = s.dirWs.x; o[1] = s.dirWs.y; o[2] = s.dirWs.z; o[3] = s.radiance.x; o[4] = s.radiance.y; o[5] = s.radiance.z; o[6] = s.pdf; break; }
+        case 2: { f3 r; float p; env_eval(sc.env, F3(a[0], a[1], a[2]), r, p); o[0] = r.x; o[1] = r.y; o[2] = r.z; o[3] = p; break; }
+        case 3: { const f3 r = env_incoming_radiance(sc.env, F3(a[0], a[1], a[2])); o[0] = r.x; o[1] = r.y; o[2] = r.z; break; }
+        case 4: { const f3 d = square_to_equal_area_sphere(F2(a[0], a[1])); o[0] = d.x; o[1] = d.y; o[2] = d.z; break; }
+        case 5: { const f2 u = square_to_equal_area_sphere_inverse(F3(a[0], a[1], a[2])); o[0] = u.x; o[1] = u.y; break; }
+        case 6: { const f2 u = square_to_triangle(F2(a[0], a[1])); o[0] = u.x; o[1] = u.y; break; }
+        case 7: { const f2 u = square_to_gaussian(F2(a[0], a[1])); o[0] = u.x; o[1] = u.y; break; }
+        case 8: { const f3 d = square_to_cosine_hemisphere(F2(a[0], a[1])); o[0] = d.x; o[1] = d.y; o[2] = d.z; break; }
+        case 9: o[0] = fresnel_dielectric(a[0], a[1], a[2]); break;
+        case 10: { const f3 r = offset_along_normal(F3(a[0], a[1], a[2]), F3(a[3], a[4], a[5])); o[0] = r.x; o[1] = r.y; o[2] = r.z; break; }
+        case 11: { f3 p, q; coordinate_system(F3(a[0], a[1], a[2]), p, q); o[0] = p.x; o[1] = p.y; o[2] = p.z; o[3] = q.x; o[4] = q.y; o[5] = q.z; break; }
+        case 12: o[0] = area_to_solid_angle(F3(a[0], a[1], a[2]), F3(a[3], a[4], a[5]), F3(a[6], a[7], a[8]), F3(a[9], a[10], a[11])); break;
+        case 13: o[0] = ggx_D(a[0], F3(a[1], a[2], a[3])); o[1] = ggx_Lambda(a[0], F3(a[1], a[2], a[3])); o[2] = ggx_G(a[0], F3(a[1], a[2], a[3]), F3(a[4], a[5], a[6])); break;
+        case 14: { const f3 r = refract_dir(F3(a[0], a[1], a[2]), F3(a[3], a[4], a[5]), a[6]); o[0] = r.x; o[1] = r.y; o[2] = r.z; break; }
+        case 15: o[0] = power_heuristic((uint32_t)a[0], a[1], (uint32_t)a[2], a[3]); break;
+        case 16: { Frame f; f.n = F3(a[0], a[1], a[2]); f.s = F3(a[3], a[4], a[5]); f.t = F3(0.0f, 0.0f, 0.0f); frame_reorthogonalize(f);
+                   const f3 p = frame_world_to_frame(f, F3(a[6], a[7], a[8])), q = frame_frame_to_world(f, F3(a[6], a[7], a[8]));
+                   o[0] = p.x; o[1] = p.y; o[2] = p.z; o[3] = q.x; o[4] = q.y; o[5] = q.z; break; }
+    }
+}
+bool shade_probe_widths(int fn, uint32_t& win, uint32_t& wout) {
+    static const uint32_t pin[17]  = { 15, 2, 3, 3, 2, 3, 2, 2, 2, 3, 6, 3, 12, 7, 7, 4, 9 }, pout[17] = { 8, 7, 4, 3, 3, 2, 2, 2, 3, 1, 3, 6, 1, 3, 3, 1, 6 };
+    if (fn < 0 || fn > 16) return false;
+    win = pin[fn]; wout = pout[fn]; return true;
+}
+void launch_shade_probe(hipStream_t s, const SceneView& sc, int fn, const float* in, uint32_t n, float* out) {
+    hipLaunchKernelGGL(k_shade_probe, dim3((n + 63) / 64), dim3(64), 0, s, sc, fn, in, n, out);
+}
+
 // ---------------- host launch wrappers ----------------
 void launch_raygen(hipStream_t s, int grid, const ShardView& sh, const CameraConsts& cam, const PipelineOpts& o, uint32_t sample_base, uint32_t s_count, const PathState& st, BounceCounters* cnt) {
     hipLaunchKernelGGL(k_raygen, dim3(grid), dim3(SHADE_BLOCK), 0, s, sh, cam, o, sample_base, s_count, st, cnt);

@@ -2,7 +2,7 @@
 // which wraps syoyo/tinyexr — un-vendored in the reference, deps/tinyexr is empty; this is a from-scratch codec of
 // the published OpenEXR 2 file layout).
 //   load: RGBA f32, like tinyexr's LoadEXRFromMemory (exr.zig:208-229): channels R,G,B,(A) by name, HALF or FLOAT
-//         or UINT pixels, compression NONE / RLE / ZIPS / ZIP, single-part scanline files, any line order.
+//         or UINT pixels, compression NONE / RLE / ZIPS / ZIP / PIZ (tinyexr's set), single-part scanline files, any line order.
 //   save: three FLOAT channels in header order B,G,R, scanline, ZIP (exr.zig:137-206 with tinyexr's header defaults; alpha is dropped).
 #include "host.h"
 #include <zlib.h>
@@ -60,6 +60,199 @@ static bool rle_decode(const uint8_t* src, size_t n, std::vector<uint8_t>& dst, 
     return dst.size() == expect;
 }
 
+// ---------------- PIZ (OpenEXR ImfPizCompressor / ImfHuf / ImfWav; a from-scratch decoder of the published scheme) ----------------
+// A PIZ block holds up to 32 scanlines.  The encoder regroups the block channel by channel as 16-bit words (HALF = 1 word per
+// pixel, FLOAT / UINT = 2), maps the words that occur onto 0..k through a bitmap-derived table, applies a 2-D Haar-style
+// wavelet per channel (and per 16-bit half of wide types), and Huffman-codes all words with canonical codes + a run-length
+// escape.  Decoding runs those four steps backwards.
+namespace piz {
+
+constexpr int ENC_SIZE = (1 << 16) + 1;         // symbols 0..65535 + the run-length escape
+constexpr int SHORT_ZEROCODE_RUN = 59, LONG_ZEROCODE_RUN = 63, SHORTEST_LONG_RUN = 2 + LONG_ZEROCODE_RUN - SHORT_ZEROCODE_RUN;
+
+struct BitReader {
+    const uint8_t* p; size_t n; size_t pos = 0;   // pos in bits, MSB first
+    bool get(int nbits, uint64_t& out) {
+        if (nbits < 0 || nbits > 57 || pos + (size_t)nbits > n * 8) return false;
+        uint64_t v = 0;
+        for (int i = 0; i < nbits; i++, pos++) v = (v << 1) | ((p[pos >> 3] >> (7 - (pos & 7))) & 1u);
+        out = v; return true;
+    }
+};
+
+// code lengths of symbols im..iM: 6 bits each, 59..62 = a run of 2..5 zero lengths, 63 + 8 bits = a run of 6..261
+static bool unpack_lengths(BitReader& br, uint32_t im, uint32_t iM, std::vector<uint8_t>& len) {
+    len.assign(ENC_SIZE, 0);
+    for (uint32_t s = im; s <= iM; s++) {
+        uint64_t l;
+        if (!br.get(6, l)) return false;
+        if (l == (uint64_t)LONG_ZEROCODE_RUN) {
+            uint64_t r; if (!br.get(8, r)) return false;
+            const uint64_t run = r + SHORTEST_LONG_RUN;
+            if (s + run > (uint64_t)iM + 1) return false;
+            s += (uint32_t)run - 1;
+        } else if (l >= (uint64_t)SHORT_ZEROCODE_RUN) {
+            const uint64_t run = l - SHORT_ZEROCODE_RUN + 2;
+            if (s + run > (uint64_t)iM + 1) return false;
+            s += (uint32_t)run - 1;
+        } else len[s] = (uint8_t)l;
+    }
+    return true;
+}
+
+// canonical codes: per length the first code value (longer codes take the numerically smaller values) and the symbols in index order
+struct Canon { uint64_t first[59]; uint32_t count[59]; uint32_t offset[59]; std::vector<uint32_t> syms; int min_len = 59, max_len = 0; };
+static bool build_canon(const std::vector<uint8_t>& len, Canon& c) {
+    uint64_t n[59] = { 0 };
+    for (int s = 0; s < ENC_SIZE; s++) { if (len[s] > 58) return false; n[len[s]]++; }
+    for (int l = 0; l < 59; l++) c.count[l] = (uint32_t)n[l];
+    uint64_t code = 0;
+    for (int l = 58; l >= 1; l--) { const uint64_t next = (code + n[l]) >> 1; c.first[l] = code; code = next; }
+    uint32_t off = 0;
+    for (int l = 1; l <= 58; l++) { c.offset[l] = off; off += c.count[l]; if (c.count[l]) { c.min_len = std::min(c.min_len, l); c.max_len = std::max(c.max_len, l); } }
+    c.syms.resize(off);
+    uint32_t fill[59] = { 0 };
+    for (int s = 0; s < ENC_SIZE; s++) if (len[s]) c.syms[c.offset[len[s]] + fill[len[s]]++] = (uint32_t)s;
+    return true;
+}
+
+static bool huf_uncompress(const uint8_t* src, size_t n, std::vector<uint16_t>& out, size_t n_raw) {
+    out.assign(n_raw, 0);
+    if (n == 0) return n_raw == 0;
+    if (n < 20) return false;
+    uint32_t im, iM, nbits; memcpy(&im, src, 4); memcpy(&iM, src + 4, 4); memcpy(&nbits, src + 12, 4);
+    if (im >= (uint32_t)ENC_SIZE || iM >= (uint32_t)ENC_SIZE || im > iM) return false;
+    BitReader tb{ src + 20, n - 20 };
+    std::vector<uint8_t> len;
+    if (!unpack_lengths(tb, im, iM, len)) return false;
+    const size_t table_bytes = (tb.pos + 7) / 8;
+    if (20 + table_bytes > n || (size_t)nbits > 8 * (n - 20 - table_bytes)) return false;
+    Canon c;
+    if (!build_canon(len, c) || c.max_len == 0) return false;
+    // fast table for codes of up to 12 bits; longer ones continue bit by bit
+    constexpr int FAST = 12;
+    std::vector<uint32_t> fast((size_t)1 << FAST, 0);          // (symbol << 6) | length, 0 = not a short code
+    for (int l = c.min_len; l <= std::min(FAST, c.max_len); l++)
+        for (uint32_t k = 0; k < c.count[l]; k++) {
+            const uint64_t code = c.first[l] + k;
+            if (code >> l) return false;
+            const uint32_t e = (c.syms[c.offset[l] + k] << 6) | (uint32_t)l;
+            for (uint64_t f = code << (FAST - l), end = (code + 1) << (FAST - l); f < end; f++) fast[(size_t)f] = e;
+        }
+    BitReader br{ src + 20 + table_bytes, (size_t)(nbits + 7) / 8 };
+    const size_t total = nbits;
+    size_t o = 0;
+    auto bit_at = [&](size_t pos) -> uint32_t { return pos < total ? (br.p[pos >> 3] >> (7 - (pos & 7))) & 1u : 0u; };
+    while (br.pos < total) {
+        uint32_t sym = 0; int l = 0;
+        uint32_t peek = 0;
+        for (int i = 0; i < FAST; i++) peek = (peek << 1) | bit_at(br.pos + (size_t)i);
+        const uint32_t e = fast[peek];
+        if (e && br.pos + (e & 63u) <= total) { sym = e >> 6; l = (int)(e & 63u); }
+        else {
+            uint64_t v = 0; bool found = false;
+            for (l = 1; l <= c.max_len && br.pos + (size_t)l <= total; l++) {
+                v = (v << 1) | bit_at(br.pos + (size_t)l - 1);
+                if (c.count[l] && v >= c.first[l] && v - c.first[l] < c.count[l]) { sym = c.syms[c.offset[l] + (uint32_t)(v - c.first[l])]; found = true; break; }
+            }
+            if (!found) return false;
+        }
+        br.pos += (size_t)l;
+        if (sym == iM) {                      // run-length escape: repeat the previous word
+            uint64_t run;
+            if (br.pos + 8 > total || !br.get(8, run) || o == 0 || o + run > n_raw) return false;
+            const uint16_t prev = out[o - 1];
+            for (uint64_t k = 0; k < run; k++) out[o++] = prev;
+        } else {
+            if (o >= n_raw || sym > 0xffffu) return false;
+            out[o++] = (uint16_t)sym;
+        }
+    }
+    return o == n_raw;
+}
+
+// inverse wavelet.  14-bit variant (all values < 2^14): signed arithmetic; 16-bit variant: modulo arithmetic
+static inline void wdec14(uint16_t l, uint16_t h, uint16_t& a, uint16_t& b) {
+    const int ls = (int16_t)l, hs = (int16_t)h;
+    const int ai = ls + (hs & 1) + (hs >> 1);
+    a = (uint16_t)(int16_t)ai; b = (uint16_t)(int16_t)(ai - hs);
+}
+static inline void wdec16(uint16_t l, uint16_t h, uint16_t& a, uint16_t& b) {
+    const int m = l, d = h;
+    const int bb = (m - (d >> 1)) & 0xffff;
+    a = (uint16_t)((d + bb - 0x8000) & 0xffff); b = (uint16_t)bb;
+}
+static void wav2_decode(uint16_t* in, int nx, int ox, int ny, int oy, uint16_t mx) {
+    const bool w14 = mx < (1 << 14);
+    const int n = nx > ny ? ny : nx;
+    int p = 1;
+    while (p <= n) p <<= 1;
+    p >>= 1;
+    int p2 = p; p >>= 1;
+    while (p >= 1) {
+        uint16_t* py = in; uint16_t* const ey = in + (ptrdiff_t)oy * (ny - p2);
+        const ptrdiff_t oy1 = (ptrdiff_t)oy * p, oy2 = (ptrdiff_t)oy * p2, ox1 = (ptrdiff_t)ox * p, ox2 = (ptrdiff_t)ox * p2;
+        uint16_t i00, i01, i10, i11;
+        for (; py <= ey; py += oy2) {
+            uint16_t* px = py; uint16_t* const ex = py + (ptrdiff_t)ox * (nx - p2);
+            for (; px <= ex; px += ox2) {
+                uint16_t* p01 = px + ox1; uint16_t* p10 = px + oy1; uint16_t* p11 = p10 + ox1;
+                if (w14) { wdec14(*px, *p10, i00, i10); wdec14(*p01, *p11, i01, i11); wdec14(i00, i01, *px, *p01); wdec14(i10, i11, *p10, *p11); }
+                else { wdec16(*px, *p10, i00, i10); wdec16(*p01, *p11, i01, i11); wdec16(i00, i01, *px, *p01); wdec16(i10, i11, *p10, *p11); }
+            }
+            if (nx & p) { uint16_t* p10 = px + oy1; if (w14) wdec14(*px, *p10, i00, *p10); else wdec16(*px, *p10, i00, *p10); *px = i00; }
+        }
+        if (ny & p) {
+            uint16_t* px = py; uint16_t* const ex = py + (ptrdiff_t)ox * (nx - p2);
+            for (; px <= ex; px += ox2) { uint16_t* p01 = px + ox1; if (w14) wdec14(*px, *p01, i00, *p01); else wdec16(*px, *p01, i00, *p01); *px = i00; }
+        }
+        p2 = p; p >>= 1;
+    }
+}
+
+// one block -> raw scanline layout (per line: the channels in file order, each W pixels)
+static bool decode_block(const uint8_t* src, size_t n, const std::vector<int>& words_per_pixel, size_t W, size_t nlines, std::vector<uint8_t>& raw) {
+    size_t total = 0;
+    for (int wpp : words_per_pixel) total += (size_t)wpp * W * nlines;
+    if (n < 4) return false;
+    uint16_t min_nz, max_nz; memcpy(&min_nz, src, 2); memcpy(&max_nz, src + 2, 2);
+    size_t pos = 4;
+    std::vector<uint8_t> bitmap(8192, 0);
+    if (max_nz >= 8192) return false;
+    if (min_nz <= max_nz) {
+        const size_t k = (size_t)max_nz - min_nz + 1;
+        if (pos + k > n) return false;
+        memcpy(&bitmap[min_nz], src + pos, k); pos += k;
+    }
+    std::vector<uint16_t> lut(65536, 0);
+    uint32_t k = 0;
+    for (uint32_t i = 0; i < 65536; i++) if (i == 0 || (bitmap[i >> 3] & (1u << (i & 7)))) lut[k++] = (uint16_t)i;
+    const uint16_t max_value = (uint16_t)(k - 1);
+    if (pos + 4 > n) return false;
+    int32_t hlen; memcpy(&hlen, src + pos, 4); pos += 4;
+    if (hlen < 0 || (size_t)hlen > n - pos) return false;
+    std::vector<uint16_t> buf;
+    if (!huf_uncompress(src + pos, (size_t)hlen, buf, total)) return false;
+    size_t at = 0;
+    std::vector<size_t> start(words_per_pixel.size());
+    for (size_t c = 0; c < words_per_pixel.size(); c++) {
+        start[c] = at;
+        for (int j = 0; j < words_per_pixel[c]; j++) wav2_decode(buf.data() + at + j, (int)W, words_per_pixel[c], (int)nlines, (int)(W * (size_t)words_per_pixel[c]), max_value);
+        at += (size_t)words_per_pixel[c] * W * nlines;
+    }
+    for (auto& v : buf) v = lut[v];
+    raw.resize(total * 2);
+    size_t o = 0;
+    for (size_t y = 0; y < nlines; y++)
+        for (size_t c = 0; c < words_per_pixel.size(); c++) {
+            const size_t cnt = (size_t)words_per_pixel[c] * W;
+            memcpy(&raw[o], buf.data() + start[c] + y * cnt, cnt * 2); o += cnt * 2;
+        }
+    return true;
+}
+
+}  // namespace piz
+
 bool exr_load(const std::string& path, Image& img, std::string& err) {
     std::vector<uint8_t> file;
     if (!read_file(path, file)) { err = "cannot read " + path; return false; }
@@ -96,7 +289,8 @@ bool exr_load(const std::string& path, Image& img, std::string& err) {
     switch (compression) {
         case 0: case 1: case 2: lines_per_block = 1; break;
         case 3: lines_per_block = 16; break;
-        default: err = "EXR compression " + std::to_string(compression) + " is not supported (NONE, RLE, ZIPS, ZIP are)"; return false;
+        case 4: lines_per_block = 32; break;
+        default: err = "EXR compression " + std::to_string(compression) + " is not supported (NONE, RLE, ZIPS, ZIP, PIZ are)"; return false;
     }
     const size_t nblocks = (size_t)((H + lines_per_block - 1) / lines_per_block);
     if (r.pos > file.size() || nblocks > (file.size() - r.pos) / 8) { err = "truncated EXR offset table"; return false; }   // before anything is sized by the header
@@ -131,6 +325,10 @@ bool exr_load(const std::string& path, Image& img, std::string& err) {
         if ((size_t)dsize == expect) { raw.assign(data, data + expect); }      // stored uncompressed (also when compression did not help)
         else if (compression == 1) { if (!rle_decode(data, (size_t)dsize, tmp, expect)) { err = "bad RLE data"; return false; } undo_predictor_and_interleave(tmp, raw); }
         else if (compression == 2 || compression == 3) { if (!inflate_all(data, (size_t)dsize, tmp, expect)) { err = "bad ZIP data"; return false; } undo_predictor_and_interleave(tmp, raw); }
+        else if (compression == 4) {
+            std::vector<int> wpp; for (auto& ch : channels) wpp.push_back(ch.type == 1 ? 1 : 2);
+            if (!piz::decode_block(data, (size_t)dsize, wpp, (size_t)W, nlines, raw) || raw.size() != expect) { err = "bad PIZ data"; return false; }
+        }
         else { err = "EXR chunk size mismatch"; return false; }
         for (size_t l = 0; l < nlines; l++) {
             const uint8_t* line = raw.data() + l * line_bytes;

@@ -72,6 +72,32 @@ def furnace_white_sphere(ctx, extent=(32, 32), order=5):
     return sensor, lens
 
 
+def furnace_sphere(ctx, kind, extent=(32, 32), order=5, color=(1.0, 1.0, 1.0), metalness=0.0, roughness=0.5, ior=1.5, env="white"):
+    """The reference's furnace shape (tests.zig:257-344: unit icosphere(5), lens at (-3,0,0), 1x1 white environment) with the
+    sphere's material swapped: the reference only runs Lambert through it; mirror and glass have f*|cos|/pdf == 1, so every
+    pixel must still come out as the environment's 1.0, and StandardPBR must not exceed it (energy conservation)."""
+    P, I = icosphere(order, False)
+    mesh = ctx.create_mesh(P, I)
+    normal = ctx.solid_texture(0.5, 0.5)
+    black = ctx.solid_texture(0.0, 0.0, 0.0)
+    if kind == STANDARD_PBR:
+        mat = ctx.create_material(STANDARD_PBR, normal, black, color=ctx.solid_texture(*color), metalness=ctx.solid_texture(metalness),
+                                  roughness=ctx.solid_texture(roughness), ior=ior)
+    elif kind == LAMBERT:
+        mat = ctx.create_material(LAMBERT, normal, black, color=ctx.solid_texture(*color))
+    else:
+        mat = ctx.create_material(kind, normal, black, ior=ior)
+    ctx.create_instance([(mesh, mat, False)])
+    lens = ctx.create_lens(ctx.make_lens(**_lens((-3, 0, 0), (1, 0, 0), (0, 0, 1), math.pi / 4.0)))
+    sensor = ctx.create_sensor(*extent)
+    if env == "white":
+        ctx.set_background(np.array([1, 1, 1, 1], np.float32), 1, 1)
+    else:
+        img = sky_sun_equirect()
+        ctx.set_background(img, img.shape[1], img.shape[0])
+    return sensor, lens
+
+
 def furnace_inside_sphere(ctx, extent=(32, 32), order=5, sampled=False):
     """tests.zig:366-455: camera inside a reversed-winding icosphere, albedo 0.5, emissive 0.5, black env.
     sampled=True: the sphere is a mesh light (the reference's disabled variant, tests.zig:457-487)."""

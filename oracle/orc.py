@@ -122,6 +122,7 @@ def lib():
         L.OrcPcg.restype = u32; L.OrcPcg.argtypes = [u32]
         L.OrcBuildAliasTable.argtypes = [vp, u32, vp, vp, vp]
         L.OrcBsdfProbe.argtypes = [u32, vp, vp, vp, vp, vp]
+        L.OrcProbeBatch.restype = C.c_int; L.OrcProbeBatch.argtypes = [vp, C.c_int, vp, u32, vp]
         _LIB = L
     return _LIB
 
@@ -333,3 +334,19 @@ def bsdf_probe(type, color, metalness, roughness, ior, wi, wo, sq):
     params = _f32(list(color) + [metalness, roughness, ior]); out = np.zeros(8, np.float32)
     lib().OrcBsdfProbe(type, _ptr(params), _ptr(_f32(wi)), _ptr(_f32(wo)), _ptr(_f32(sq)), _ptr(out))
     return {"pdf": float(out[0]), "eval": out[1:4].copy(), "dir": out[4:7].copy(), "sample_pdf": float(out[7])}
+
+
+# batch probes (oracle/orc_core.c OrcProbeBatch; the product mirrors the table in MsneShadeProbe)
+PROBES = {"bsdf": (0, 15, 8), "env_sample": (1, 2, 7), "env_eval": (2, 3, 4), "env_incoming": (3, 3, 3), "equal_area": (4, 2, 3),
+          "equal_area_inverse": (5, 3, 2), "triangle": (6, 2, 2), "gaussian": (7, 2, 2), "cosine_hemisphere": (8, 2, 3),
+          "fresnel_dielectric": (9, 3, 1), "offset_along_normal": (10, 6, 3), "coordinate_system": (11, 3, 6),
+          "area_to_solid_angle": (12, 12, 1), "ggx": (13, 7, 3), "refract": (14, 7, 3), "power_heuristic": (15, 4, 1), "frame": (16, 9, 6)}
+
+
+def probe(name, x, ctx=None):
+    """x: (n, in_width) float32 -> (n, out_width) float32.  env_* probes need a context (its environment map)."""
+    fn, wi, wo = PROBES[name]
+    x = _f32(x, (-1, wi)); out = np.zeros((len(x), wo), np.float32)
+    if lib().OrcProbeBatch(ctx.h if ctx is not None else None, fn, _ptr(x), len(x), _ptr(out)) != 0:
+        raise RuntimeError("OrcProbeBatch(%s) failed" % name)
+    return out

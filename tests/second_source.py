@@ -1,0 +1,438 @@
+"""SECOND SOURCE for the shading math of the hot path — test infrastructure.
+
+An independent restatement, in vectorised numpy FLOAT64, of the reference's HLSL, written from the shader text itself
+(shaders/hrtsystem/material.hlsl, light.hlsl, reflection_frame.hlsl, integrator.hlsl:10-16; shaders/utils/mappings.hlsl,
+math.hlsl) — not from oracle/orc_*.h and not from moonshine_amd/csrc/*.h, which restate the same shaders in scalar f32 C
+and share most of their text with each other.  A misreading of the HLSL that both of those carry shows up as a difference
+against this file (tests/test_second_source.py compares all three on the same inputs through the batch probes
+OrcProbeBatch / MsneShadeProbe, whose record layouts are the PROBES table below).
+
+Everything takes and returns arrays whose LAST axis is the vector component; leading axes broadcast.  Where the HLSL
+branches, both branches are evaluated and selected with np.where (inputs may therefore produce harmless warnings in the
+unselected branch; callers wrap in np.errstate).
+"""
+import numpy as np
+
+PI = float(np.float32(3.14159265))        # math.hlsl:3 (a float literal)
+AIR_IOR = float(np.float32(1.000277))     # math.hlsl:7
+GLASS, LAMBERT, PERFECT_MIRROR, STANDARD_PBR = 0, 1, 2, 3   # world.hlsl:31-36 MaterialType
+
+# record layouts of the batch probes: name -> (function code, floats in, floats out)
+PROBES = {"bsdf": (0, 15, 8), "env_sample": (1, 2, 7), "env_eval": (2, 3, 4), "env_incoming": (3, 3, 3), "equal_area": (4, 2, 3),
+          "equal_area_inverse": (5, 3, 2), "triangle": (6, 2, 2), "gaussian": (7, 2, 2), "cosine_hemisphere": (8, 2, 3),
+          "fresnel_dielectric": (9, 3, 1), "offset_along_normal": (10, 6, 3), "coordinate_system": (11, 3, 6),
+          "area_to_solid_angle": (12, 12, 1), "ggx": (13, 7, 3), "refract": (14, 7, 3), "power_heuristic": (15, 4, 1), "frame": (16, 9, 6)}
+
+
+DTYPE = np.float64
+
+
+class precision:
+    """`with precision(np.float32):` runs the same formulas in float32 — used by the tests only to MEASURE how much of a
+    difference is rounding (|f32 - f64| of this file) before blaming the code under test; the reference values are float64."""
+
+    def __init__(self, dtype):
+        self.dtype = dtype
+
+    def __enter__(self):
+        global DTYPE
+        self.old, DTYPE = DTYPE, self.dtype
+
+    def __exit__(self, *a):
+        global DTYPE
+        DTYPE = self.old
+
+
+def _a(x):
+    return np.asarray(x, dtype=DTYPE)
+
+
+def vec(*c):
+    return np.stack(np.broadcast_arrays(*[_a(x) for x in c]), axis=-1)
+
+
+def dot(a, b):
+    return (a * b).sum(-1)
+
+
+def normalize(v):
+    return v / np.sqrt(dot(v, v))[..., None]
+
+
+def cross(a, b):
+    return np.cross(a, b)
+
+
+def lerp(x, y, s):
+    """HLSL lerp(x, y, s) = x + s * (y - x)"""
+    return x + s * (y - x)
+
+
+# ------------------------------------------------------------------ reflection_frame.hlsl:48-83 (local z-up helpers)
+def cos_theta(v):
+    return v[..., 2]
+
+
+def cos2_theta(v):
+    return v[..., 2] * v[..., 2]
+
+
+def sin2_theta(v):
+    return np.maximum(0.0, 1.0 - cos2_theta(v))
+
+
+def tan2_theta(v):
+    return sin2_theta(v) / cos2_theta(v)
+
+
+def same_hemisphere(a, b):
+    return a[..., 2] * b[..., 2] > 0.0
+
+
+# ------------------------------------------------------------------ reflection_frame.hlsl:32-46
+def reorthogonalize(n, s):
+    """Gram-Schmidt: returns (s', t')"""
+    s2 = normalize(s - n * dot(n, s)[..., None])
+    t2 = normalize(cross(n, s2))
+    return s2, t2
+
+
+def world_to_frame(n, s, t, v):
+    return vec(dot(s, v), dot(t, v), dot(n, v))     # mul({s, t, n}, v)
+
+
+def frame_to_world(n, s, t, v):
+    return s * v[..., 0:1] + t * v[..., 1:2] + n * v[..., 2:3]   # mul(transpose({s, t, n}), v)
+
+
+# ------------------------------------------------------------------ math.hlsl
+def luminance(c):
+    return 0.2126 * c[..., 0] + 0.7152 * c[..., 1] + 0.0722 * c[..., 2]
+
+
+def face_forward(n, d):
+    return np.where((dot(n, d) > 0)[..., None], n, -n)
+
+
+def coordinate_system(v1):
+    x, y, z = v1[..., 0], v1[..., 1], v1[..., 2]
+    zero = np.zeros_like(x)
+    a = vec(-z, zero, x) / np.sqrt(x * x + z * z)[..., None]
+    b = vec(zero, z, -y) / np.sqrt(y * y + z * z)[..., None]
+    v2 = np.where((np.abs(x) > np.abs(y))[..., None], a, b)
+    return v2, cross(v2, v1)
+
+
+def offset_along_normal(p, n):
+    """math.hlsl:32-42 — integer arithmetic on float BIT PATTERNS: done in float32 / int32 exactly as written"""
+    p = np.asarray(p, np.float32); n = np.asarray(n, np.float32)
+    origin, float_scale, int_scale = np.float32(1.0 / 32.0), np.float32(1.0 / 65536.0), np.float32(256.0)
+    of_i = np.trunc(n * int_scale).astype(np.int32)                       # int3 of_i = n * int_scale (conversion truncates)
+    p_i = (p.view(np.int32) + np.where(p < 0, -of_i, of_i)).view(np.float32)
+    return np.where(np.abs(p) < origin, p + n * float_scale, p_i)
+
+
+# ------------------------------------------------------------------ mappings.hlsl
+def coin_flip_remap(p, rand):
+    """returns (chosen, remapped rand)"""
+    take = rand < p
+    return take, np.where(take, rand / p, (rand - p) / (1.0 - p))
+
+
+def square_to_triangle(sq):
+    a = 1 - np.sqrt(1 - sq[..., 0])
+    b = sq[..., 1] * np.sqrt(1 - sq[..., 0])
+    return vec(a, b)
+
+
+def square_to_gaussian(sq):
+    u1, u2 = 1.0 - sq[..., 0], sq[..., 1]
+    r = np.sqrt(-2.0 * np.log(u1))
+    theta = 2 * PI * u2
+    return vec(r * np.cos(theta), r * np.sin(theta))
+
+
+def square_to_uniform_disk_concentric(sq):
+    u = 2.0 * sq - 1.0
+    ux, uy = u[..., 0], u[..., 1]
+    wide = np.abs(ux) > np.abs(uy)
+    r = np.where(wide, ux, uy)
+    theta = np.where(wide, (PI / 4) * (uy / np.where(ux == 0, 1, ux)), (PI / 2) - (PI / 4) * (ux / np.where(uy == 0, 1, uy)))
+    out = vec(r * np.cos(theta), r * np.sin(theta))
+    return np.where(((ux == 0) & (uy == 0))[..., None], 0.0, out)
+
+
+def square_to_cosine_hemisphere(sq):
+    d = square_to_uniform_disk_concentric(sq)
+    z = np.sqrt(np.maximum(0.0, 1.0 - dot(d, d)))
+    return vec(d[..., 0], d[..., 1], z)
+
+
+def spherical_to_cartesian(sin_t, cos_t, phi):
+    return vec(sin_t * np.cos(phi), sin_t * np.sin(phi), cos_t)
+
+
+def square_to_equal_area_sphere(sq):
+    """mappings.hlsl:67-83 (PBRT-v4 3.8.3)"""
+    uv = 2.0 * sq - 1.0
+    uvp = np.abs(uv)
+    signed_distance = 1.0 - (uvp[..., 0] + uvp[..., 1])
+    d = np.abs(signed_distance)
+    r = 1.0 - d
+    phi = np.where(r == 0.0, 1.0, (uvp[..., 1] - uvp[..., 0]) / np.where(r == 0, 1, r) + 1.0) * PI / 4.0
+    signs = np.sign(vec(uv[..., 0], uv[..., 1], signed_distance))
+    k = r * np.sqrt(2.0 - r * r)
+    return signs * vec(np.cos(phi) * k, np.sin(phi) * k, 1.0 - r * r)
+
+
+def square_to_equal_area_sphere_inverse(d):
+    """mappings.hlsl:85-99"""
+    a = np.abs(d)
+    r = np.sqrt(1.0 - a[..., 2])
+    lo, hi = np.minimum(a[..., 0], a[..., 1]), np.maximum(a[..., 0], a[..., 1])
+    phi = np.where((a[..., 0] == 0) & (a[..., 1] == 0), 0.0, np.arctan2(lo, hi) * 2.0 / PI)
+    phi = np.where(a[..., 0] < a[..., 1], 1.0 - phi, phi)
+    uv = vec(r - phi * r, phi * r)
+    uv = np.where((d[..., 2] < 0)[..., None], 1.0 - uv[..., ::-1], uv)
+    uv = uv * np.sign(d[..., :2])
+    return (uv + 1.0) / 2.0
+
+
+# ------------------------------------------------------------------ material.hlsl:20-67 GGX
+def ggx_D(alpha, m):
+    a2 = alpha ** 2
+    return a2 / (PI * (cos_theta(m) ** 2 * (a2 - 1) + 1) ** 2)
+
+
+def ggx_Lambda(alpha, v):
+    t2 = tan2_theta(v)
+    return np.where(np.isinf(t2), 0.0, (np.sqrt(1.0 + alpha ** 2 * np.where(np.isinf(t2), 0, t2)) - 1.0) / 2.0)
+
+
+def ggx_G(alpha, wi, wo):
+    return 1.0 / (1.0 + ggx_Lambda(alpha, wi) + ggx_Lambda(alpha, wo))
+
+
+def ggx_sample(alpha, wo, sq):
+    tan2 = alpha * alpha * sq[..., 0] / (1 - sq[..., 0])
+    cos2 = 1 / (1 + tan2)
+    sin_t = np.sqrt(np.maximum(0, 1 - cos2))
+    cos_t = np.sqrt(cos2)
+    phi = 2 * PI * sq[..., 1]
+    h = spherical_to_cartesian(sin_t, cos_t, phi)
+    return np.where(same_hemisphere(wo, h)[..., None], h, -h)
+
+
+def ggx_pdf(alpha, m):
+    return ggx_D(alpha, m) * np.abs(cos_theta(m))
+
+
+# ------------------------------------------------------------------ material.hlsl:71-123 Fresnel
+def schlick_weight(c):
+    return (1 - c) ** 5
+
+
+def schlick(c, r0):
+    return lerp(schlick_weight(c), 1.0, r0)
+
+
+def fresnel_dielectric(cos_i, eta_i, eta_t):
+    cos_i = np.clip(_a(cos_i), -1, 1)
+    eta_i, eta_t = np.broadcast_arrays(_a(eta_i), _a(eta_t))
+    entering = cos_i > 0
+    ei, et = np.where(entering, eta_i, eta_t), np.where(entering, eta_t, eta_i)
+    cos_i = np.where(entering, cos_i, np.abs(cos_i))
+    sin_i = np.sqrt(np.maximum(0, 1 - cos_i * cos_i))
+    sin_t = ei / et * sin_i
+    cos_t = np.sqrt(np.maximum(0, 1 - sin_t * sin_t))
+    r_parl = ((et * cos_i) - (ei * cos_t)) / ((et * cos_i) + (ei * cos_t))
+    r_perp = ((ei * cos_i) - (et * cos_t)) / ((ei * cos_i) + (et * cos_t))
+    return np.where(sin_t >= 1, 1.0, (r_parl * r_parl + r_perp * r_perp) / 2)
+
+
+# ------------------------------------------------------------------ material.hlsl:137-175 Lambert
+def lambert_pdf(wi, wo):
+    return np.where(same_hemisphere(wi, wo), np.abs(cos_theta(wi)) / PI, 0.0)
+
+
+def lambert_eval(color, wi, wo):
+    return color / PI + 0.0 * wi[..., :1]
+
+
+def lambert_sample(wo, sq):
+    wi = square_to_cosine_hemisphere(sq)
+    wi = np.where((wo[..., 2] < 0.0)[..., None], wi * _a([1.0, 1.0, -1.0]), wi)
+    return wi, lambert_pdf(wi, wo)
+
+
+# ------------------------------------------------------------------ material.hlsl:179-270 StandardPBR
+def alpha_from_roughness(roughness):
+    return np.maximum(_a(roughness) ** 2, 0.001)     # :196
+
+
+def pbr_microfacet_pdf(alpha, wi, wo):
+    h = normalize(wi + wo)
+    return np.where(same_hemisphere(wo, wi), ggx_pdf(alpha, h) / (4.0 * dot(wo, h)), 0.0)
+
+
+def pbr_p_specular(metalness):
+    return 1.0 / (1.0 + (1.0 - metalness))
+
+
+def pbr_pdf(alpha, metalness, wi, wo):
+    return lerp(lambert_pdf(wi, wo), pbr_microfacet_pdf(alpha, wi, wo), pbr_p_specular(metalness))
+
+
+def pbr_eval(color, metalness, alpha, ior, wi, wo):
+    h = normalize(wi + wo)
+    c = dot(wi, h)
+    f_dielectric = fresnel_dielectric(c, AIR_IOR, ior)[..., None]
+    f_metallic = schlick(c[..., None], color)
+    F = lerp(f_dielectric, f_metallic, _a(metalness)[..., None])
+    G, D = ggx_G(alpha, wi, wo), ggx_D(alpha, h)
+    spec = np.where(same_hemisphere(wo, wi)[..., None], (F * (G * D)[..., None]) / (4.0 * np.abs(cos_theta(wi)) * np.abs(cos_theta(wo)))[..., None], 0.0)
+    return spec + (1.0 - _a(metalness))[..., None] * (color / PI)
+
+
+def pbr_sample(alpha, metalness, wo, sq):
+    p_spec = pbr_p_specular(metalness)
+    take, x = coin_flip_remap(p_spec, sq[..., 0])          # inout: the remapped number is what both branches consume
+    sq2 = vec(x, sq[..., 1])
+    # specular branch: microfacetSample
+    h = ggx_sample(alpha, wo, sq2)
+    wi_s = -(wo - 2.0 * h * dot(wo, h)[..., None])          # -reflect(w_o, h)
+    pdf_micro = np.where(same_hemisphere(wo, wi_s), ggx_pdf(alpha, h) / (4.0 * dot(wo, h)), 0.0)
+    pdf_s = lerp(lambert_pdf(wi_s, wo), pdf_micro, p_spec)
+    # diffuse branch
+    wi_d, pdf_l = lambert_sample(wo, sq2)
+    pdf_d = lerp(pdf_l, pbr_microfacet_pdf(alpha, wi_d, wo), p_spec)
+    return np.where(take[..., None], wi_s, wi_d), np.where(take, pdf_s, pdf_d)
+
+
+# ------------------------------------------------------------------ material.hlsl:313-393 mirror, glass
+def mirror_sample(wo):
+    return wo * _a([-1.0, -1.0, 1.0]), _a(np.ones(wo.shape[:-1]))
+
+
+def mirror_eval(wi):
+    return (1.0 / np.abs(cos_theta(wi)))[..., None] * _a(np.ones(3))
+
+
+def refract_dir(wi, n, eta):
+    eta = _a(eta)
+    cos_i = dot(n, wi)
+    sin2_i = np.maximum(0, 1 - cos_i * cos_i)
+    sin2_t = eta * eta * sin2_i
+    cos_t = np.sqrt(np.maximum(0, 1 - sin2_t))
+    out = eta[..., None] * -wi + (eta * cos_i - cos_t)[..., None] * n
+    return np.where((sin2_t >= 1)[..., None], 0.0, out)
+
+
+def glass_sample(ior, wo, sq):
+    ior = _a(ior) + 0.0 * wo[..., 0]
+    fr = fresnel_dielectric(cos_theta(wo), AIR_IOR, ior)
+    up = cos_theta(wo) > 0
+    eta_i, eta_t = np.where(up, AIR_IOR, ior), np.where(up, ior, AIR_IOR)
+    refr = refract_dir(wo, face_forward(np.broadcast_to(_a([0.0, 0.0, 1.0]), wo.shape), wo), eta_i / eta_t)
+    pdf_r = np.where((refr == 0.0).all(-1), 0.0, 1.0 - fr)
+    reflect = sq[..., 0] < fr
+    return np.where(reflect[..., None], wo * _a([-1.0, -1.0, 1.0]), refr), np.where(reflect, fr, pdf_r)
+
+
+def glass_eval(ior, wi, wo):
+    fr = fresnel_dielectric(cos_theta(wo), AIR_IOR, _a(ior) + 0.0 * wo[..., 0])
+    return (np.where(same_hemisphere(wi, wo), fr, 1.0 - fr) / np.abs(cos_theta(wi)))[..., None] * _a(np.ones(3))
+
+
+# ------------------------------------------------------------------ material.hlsl:395-487 MaterialVariant
+def material(type_, color, metalness, roughness, ior, wi, wo, sq):
+    """-> dict(pdf, eval, dir, sample_pdf) for arrays of inputs sharing one material TYPE (a python int)"""
+    color, wi, wo, sq = _a(color), _a(wi), _a(wo), _a(sq)
+    alpha = alpha_from_roughness(roughness)
+    zero = 0.0 * wi[..., 0]
+    if type_ == STANDARD_PBR:
+        d, sp = pbr_sample(alpha, _a(metalness), wo, sq)
+        return dict(pdf=pbr_pdf(alpha, _a(metalness), wi, wo), eval=pbr_eval(color, _a(metalness), alpha, _a(ior), wi, wo), dir=d, sample_pdf=sp)
+    if type_ == LAMBERT:
+        d, sp = lambert_sample(wo, sq)
+        return dict(pdf=lambert_pdf(wi, wo), eval=lambert_eval(color, wi, wo), dir=d, sample_pdf=sp)
+    if type_ == PERFECT_MIRROR:
+        d, sp = mirror_sample(wo)
+        return dict(pdf=zero, eval=mirror_eval(wi), dir=d, sample_pdf=sp + zero)
+    d, sp = glass_sample(ior, wo, sq)
+    return dict(pdf=zero, eval=glass_eval(ior, wi, wo), dir=d, sample_pdf=sp)
+
+
+# ------------------------------------------------------------------ integrator.hlsl:10-16
+def power_heuristic(numf, f_pdf, numg, g_pdf):
+    f, g = numf * f_pdf, numg * g_pdf
+    return (f * f) / (f * f + g * g)
+
+
+# ------------------------------------------------------------------ light.hlsl:105-110
+def area_to_solid_angle(pos1, pos2, dir1, dir2):
+    r2 = dot(pos1 - pos2, pos1 - pos2)
+    light_cos = dot(-dir1, dir2)
+    return np.where(light_cos > 0.0, r2 / np.where(light_cos > 0, light_cos, 1), 0.0)
+
+
+# ------------------------------------------------------------------ light.hlsl:34-103 EnvMap
+class EnvMap:
+    """rgb: (S, S, >=3) equal-area map; lum: list of luminance levels, lum[l] is (S>>l, S>>l) — the textures the reference's
+    background pre-pass produces (shaders/background/*.hlsl).  Texture2D.Load(uint3(x, y, level)) = lum[level][y, x], 0 outside."""
+
+    def __init__(self, rgb, lum):
+        self.rgb = _a(rgb)[..., :3]
+        self.lum = [_a(l) for l in lum]
+        self.size = self.rgb.shape[0]
+        self.mip_count = int(np.log2(self.size)) + 1
+        assert len(self.lum) == self.mip_count
+
+    def load(self, x, y, level):
+        t = self.lum[level]; s = t.shape[0]
+        ok = (x >= 0) & (y >= 0) & (x < s) & (y < s)
+        return np.where(ok, t[np.clip(y, 0, s - 1), np.clip(x, 0, s - 1)], 0.0)
+
+    def load_rgb(self, x, y):
+        s = self.size
+        ok = (x >= 0) & (y >= 0) & (x < s) & (y < s)
+        return np.where(ok[..., None], self.rgb[np.clip(y, 0, s - 1), np.clip(x, 0, s - 1)], 0.0)
+
+    def integral(self):
+        return self.lum[self.mip_count - 1][0, 0]
+
+    def sample(self, rand):
+        """-> (dir, radiance, pdf, texel index) without the shadow ray (light.hlsl:47-73)"""
+        rx, ry = _a(rand)[..., 0].copy(), _a(rand)[..., 1].copy()
+        ix = np.zeros(rx.shape, np.int64); iy = np.zeros(rx.shape, np.int64)
+        with np.errstate(all="ignore"):
+            for level in range(self.mip_count - 1, -1, -1):
+                ix, iy = ix * 2, iy * 2
+                px = self.load(ix, iy, level) + self.load(ix, iy + 1, level)
+                py = self.load(ix + 1, iy, level) + self.load(ix + 1, iy + 1, level)
+                take, rx = coin_flip_remap(py / (px + py), rx)
+                ix = ix + take
+                qx, qy = self.load(ix, iy, level), self.load(ix, iy + 1, level)
+                take, ry = coin_flip_remap(qy / (qx + qy), ry)
+                iy = iy + take
+        s = self.size
+        discrete = self.load(ix, iy, 0) * float(s * s) / self.integral()
+        uv = vec((ix + rx) / s, (iy + ry) / s)
+        return square_to_equal_area_sphere(uv), self.load_rgb(ix, iy), discrete / (4.0 * PI), (ix, iy)
+
+    def eval(self, d):
+        """-> (radiance, pdf) (light.hlsl:83-97)"""
+        s = self.size
+        uv = square_to_equal_area_sphere_inverse(_a(d))
+        idx = np.clip(np.trunc(uv * s).astype(np.int64), 0, s)
+        discrete = self.load(idx[..., 0], idx[..., 1], 0) * float(s * s) / self.integral()
+        return self.load_rgb(idx[..., 0], idx[..., 1]), discrete / (4.0 * PI)
+
+
+def fold_pyramid(level0):
+    """shaders/background/fold.hlsl: each level is the 2x2 SUM of the one below"""
+    out = [_a(level0)]
+    while out[-1].shape[0] > 1:
+        t = out[-1]
+        out.append(t[0::2, 0::2] + t[0::2, 1::2] + t[1::2, 0::2] + t[1::2, 1::2])
+    return out

@@ -30,6 +30,52 @@ def test_exr_reader_against_independent_writer(tmp_path, channels, ptype, comp):
     assert np.array_equal(bits(got), bits(ref))
 
 
+def _piz_images():
+    rs = np.random.default_rng(4)
+    yy, xx = np.mgrid[0:70, 0:45]
+    smooth = np.stack([np.sin(xx / 9.0) * 0.5 + 0.5, (yy / 70.0) ** 2, np.exp(-((xx - 20) ** 2 + (yy - 30) ** 2) / 90.0) * 40.0, np.ones_like(xx, float)], -1).astype(np.float32)
+    flat = np.zeros((33, 17, 4), np.float32); flat[..., 0] = 0.25; flat[10:20, 5:9, 1] = 3.0; flat[..., 3] = 1.0        # long runs, few distinct words (14-bit wavelet)
+    noisy = (rs.random((64, 64, 4)) * 1000.0).astype(np.float32)                                                         # > 2^14 distinct words (16-bit wavelet), incompressible
+    tiny = rs.random((1, 1, 4)).astype(np.float32)
+    odd = (rs.random((35, 3, 4)) * rs.choice([0.0, 1.0, 8.0], (35, 3, 1))).astype(np.float32)                           # narrower than tall: few wavelet levels, odd remainders
+    # smooth high words, random low mantissa words: > 2^14 distinct words per block (the 16-bit wavelet variant) AND compressible
+    xs = np.linspace(0.5, 2.0, 1024, dtype=np.float32)[None, :, None] * np.linspace(1.0, 1.5, 40, dtype=np.float32)[:, None, None] * np.float32([1.0, 0.7, 0.4, 1.0])
+    wide = (xs.view(np.uint32) & np.uint32(0xffff0000) | rs.integers(0, 65536, xs.shape).astype(np.uint32)).view(np.float32)
+    return {"smooth": smooth, "flat": flat, "noisy": noisy, "tiny": tiny, "odd": odd, "wide": wide}
+
+
+def test_exr_piz_16_bit_wavelet_variant(tmp_path):
+    img = _piz_images()["wide"]
+    data = assets.exr_bytes(img, "RGB", "float", "piz")
+    block_words = np.frombuffer(img[:32, :, :3].tobytes(), "<u2")
+    assert len(np.unique(block_words)) >= (1 << 14) and len(data) < 0.9 * img.shape[0] * img.shape[1] * 12      # many distinct words, and stored compressed
+    p = str(tmp_path / "w.exr"); open(p, "wb").write(data)
+    ref = img.copy(); ref[..., 3] = 1.0
+    assert np.array_equal(bits(api.exr_load(p)), bits(ref))
+
+
+@pytest.mark.parametrize("name", ["smooth", "flat", "noisy", "tiny", "odd"])
+@pytest.mark.parametrize("channels,ptype", [("RGB", "half"), ("RGBA", "float"), ("G", "half")])
+def test_exr_piz_reader_against_independent_encoder(tmp_path, name, channels, ptype):
+    """PIZ (tinyexr reads it, exr.zig:109-110; the default of most HDRI tools): files from the independent numpy encoder in
+    moonshine_amd/assets.py — bitmap/LUT, wavelet (14- and 16-bit variants, odd sizes, partial last block of 32 lines), Huffman
+    with and without the run-length escape, and blocks stored raw because they did not shrink"""
+    img = _piz_images()[name]
+    p = str(tmp_path / "p.exr")
+    for rle in (True, False):
+        data = assets.exr_bytes(img, channels, ptype, "piz", piz_rle=rle)
+        open(p, "wb").write(data)
+        got = api.exr_load(p)
+        ref = img.astype(np.float16).astype(np.float32) if ptype == "half" else img.copy()
+        if "A" not in channels:
+            ref[..., 3] = 1.0
+        if channels == "G":
+            ref[..., 0] = ref[..., 2] = 0.0
+        assert np.array_equal(bits(got), bits(ref)), (name, channels, ptype, rle)
+    if name in ("smooth", "flat"):
+        assert len(data) < 0.8 * len(assets.exr_bytes(img, channels, ptype, "none"))     # ... and the encoder does compress
+
+
 def test_exr_writer_layout_and_roundtrip(tmp_path):
     rs = np.random.default_rng(1)
     img = rs.normal(size=(9, 13, 4)).astype(np.float32)
@@ -285,6 +331,7 @@ def test_parsers_survive_mutated_files_under_sanitizers(tmp_path, orc):
     exr_rgba = np.random.default_rng(3).random((9, 13, 4)).astype(np.float32)
     for comp in ("none", "zips", "zip"):
         seeds["exr_" + comp] = assets.exr_bytes(exr_rgba, "RGBA", "half" if comp == "zips" else "float", comp)
+    seeds["exr_piz"] = assets.exr_bytes(_piz_images()["smooth"][:40, :23], "RGB", "half", "piz")
     seeds["png"] = open(os.path.join(THIRD, "python_logo.png"), "rb").read()
     seeds["png2"] = _png_adam7(13, 9, 6, 8, np.random.default_rng(1).integers(0, 256, (9, 13, 4)).astype(np.uint32))
     rs = np.random.default_rng(2024)

@@ -1,0 +1,94 @@
+"""Turns the scratch output of tools/profile_round2.sh TAG SCENE (gpurun_out/TAG_SCENE_{trace,fetch,write,sq}) into the files
+committed under profiles/ and read by bench.py:   python tools/profile_counters.py TAG SCENE
+
+  profiles/TAG_kernel_stats_SCENE.txt   rocprofv3 --kernel-trace --stats table of the bench command + its JSON line
+  profiles/TAG_counters_SCENE.json      per kernel and PER UNIT (ray / shaded path), so the figures hold at any --steps:
+      hbm_bytes_per_unit                (2 x FETCH_SIZE + WRITE_SIZE) / units — FETCH_SIZE x2 is the gfx950 correction of
+                                        /opt/skills/guides/MI355X_MICROARCH.md (both counters are in KB); an upper bound for 16-B gathers
+      valu_wave_instructions_per_unit   SQ_INSTS_VALU / units          valu_thread_instructions_per_unit   SQ_THREAD_CYCLES_VALU / units
+      lanes_per_valu_instruction        SQ_THREAD_CYCLES_VALU / SQ_INSTS_VALU (of 64)
+      valu_issue_busy_frac              SQ_ACTIVE_INST_VALU (quad-cycles) x 4 / (1024 SIMDs x kernel time x 2.4 GHz)
+  Counters are summed over ALL dispatches of a kernel in the run (warm-up and every repeat) and divided by the units the same run
+  processed (bench.py's `profile_totals`).
+"""
+import csv
+import glob
+import json
+import os
+import sys
+from collections import defaultdict
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+tag, scene = sys.argv[1], sys.argv[2]
+G = os.path.join(ROOT, "gpurun_out", "%s_%s" % (tag, scene))
+KERNELS = ("k_trace_closest", "k_trace_shadow", "k_shade")
+
+
+def bench_line(log):
+    for line in open(log):
+        if line.startswith("{") and '"metric"' in line:
+            return json.loads(line)
+    raise SystemExit("no bench line in " + log)
+
+
+def which(name):
+    for k in KERNELS:
+        if "msne::" + k in name:
+            return k
+    return None
+
+
+def counters(sub):
+    """-> {kernel: {counter: sum}}, {kernel: total ns}, {kernel: dispatches}"""
+    val = defaultdict(lambda: defaultdict(float)); dur = defaultdict(float); seen = defaultdict(set)
+    for f in glob.glob(os.path.join(G + "_" + sub, "**", "*counter_collection.csv"), recursive=True):
+        for r in csv.DictReader(open(f)):
+            k = which(r["Kernel_Name"])
+            if not k:
+                continue
+            val[k][r["Counter_Name"]] += float(r["Counter_Value"])
+            if r["Dispatch_Id"] not in seen[k]:
+                seen[k].add(r["Dispatch_Id"]); dur[k] += int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
+    return val, dur, {k: len(v) for k, v in seen.items()}
+
+
+def short(n):
+    return n.split("(")[0].replace("void ", "")
+
+
+line = bench_line(G + "_trace.log")
+lines = ["# rocprofv3 --kernel-trace --stats --output-format csv -- python3 " + open(G + "_cmd.txt").read().strip() + "   (MI355X)",
+         "%-44s %6s %14s %12s %10s %12s %7s" % ("kernel", "calls", "total_ns", "avg_ns", "min_ns", "max_ns", "pct")]
+stats = glob.glob(os.path.join(G + "_trace", "**", "*kernel_stats.csv"), recursive=True)[0]
+for r in csv.DictReader(open(stats)):
+    lines.append("%-44s %6d %14d %12.0f %10d %12d %6.2f%%" % (short(r["Name"])[:44], int(r["Calls"]), int(r["TotalDurationNs"]), float(r["AverageNs"]),
+                                                          int(r["MinNs"]), int(r["MaxNs"]), float(r["Percentage"])))
+lines += ["", "# the command's own line (HIP-event kernel times inside the timed region; under the profiler)", json.dumps(line)]
+open(os.path.join(ROOT, "profiles", "%s_kernel_stats_%s.txt" % (tag, scene)), "w").write("\n".join(lines) + "\n")
+
+out = {"command": open(G + "_cmd.txt").read().strip(), "unit": {"k_trace_closest": "closest-hit ray", "k_trace_shadow": "shadow ray", "k_shade": "path shaded (= closest-hit ray)"},
+       "fetch_correction": "FETCH_SIZE x2 (gfx950 tallies 128-B requests at 64 B; MI355X_MICROARCH.md HBM section), KB -> B x1024", "clock_ghz_assumed": 2.4, "kernels": {}}
+per = {}
+for sub in ("fetch", "write", "sq"):
+    tot = bench_line(G + "_%s.log" % sub)["profile_totals"]
+    units = {"k_trace_closest": tot["closest_rays"], "k_trace_shadow": tot["shadow_rays"], "k_shade": tot["closest_rays"]}
+    val, dur, n = counters(sub)
+    per[sub] = (val, dur, n, units)
+for k in KERNELS:
+    fv, _, fn, fu = per["fetch"]; wv, _, _, wu = per["write"]; sv, sd, sn, su = per["sq"]
+    e = {"dispatches": sn.get(k, 0), "units": su[k]}
+    e["fetch_bytes_per_unit_raw"] = fv[k]["FETCH_SIZE"] * 1024.0 / fu[k]
+    e["write_bytes_per_unit_raw"] = wv[k]["WRITE_SIZE"] * 1024.0 / wu[k]
+    e["hbm_bytes_per_unit"] = 2.0 * e["fetch_bytes_per_unit_raw"] + e["write_bytes_per_unit_raw"]
+    c = sv[k]
+    e["valu_wave_instructions_per_unit"] = c["SQ_INSTS_VALU"] / su[k]
+    e["valu_thread_instructions_per_unit"] = c["SQ_THREAD_CYCLES_VALU"] / su[k]
+    e["lanes_per_valu_instruction"] = c["SQ_THREAD_CYCLES_VALU"] / max(c["SQ_INSTS_VALU"], 1.0)
+    e["valu_issue_busy_frac"] = c["SQ_ACTIVE_INST_VALU"] * 4.0 / (1024.0 * sd[k] * 2.4)
+    e["kernel_ms_under_pmc"] = sd[k] * 1e-6
+    e["vmem_rd_instructions_per_unit"] = c["SQ_INSTS_VMEM_RD"] / su[k]
+    e["wave_cycles_split"] = {"active": c["SQ_ACTIVE_INST_ANY"] / max(c["SQ_WAVE_CYCLES"], 1.0), "wait_inst": c["SQ_WAIT_INST_ANY"] / max(c["SQ_WAVE_CYCLES"], 1.0),
+                              "wait_any": c["SQ_WAIT_ANY"] / max(c["SQ_WAVE_CYCLES"], 1.0)}
+    out["kernels"][k] = e
+json.dump(out, open(os.path.join(ROOT, "profiles", "%s_counters_%s.json" % (tag, scene)), "w"), indent=1)
+print(json.dumps(out, indent=1))
