@@ -85,6 +85,7 @@ def main():
     ap.add_argument("--scene", default="s1", choices=["s1", "s2"])
     ap.add_argument("--env", default="constant", choices=["constant", "sky"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--dump-film", default=None, help="rank 0 saves the assembled film of the last repeat here (.npy): parity tests of the gather path")
     a = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -165,6 +166,10 @@ def main():
     rays = closest + shadow
     dt = statistics.median(times)
 
+    if rank == 0 and a.dump_film:
+        if world == 1:
+            ctx.render(sensor, lens, launches=0, readback=True)     # the gather already unpacked the film on rank 0 when world > 1
+        np.save(a.dump_film, ctx.sensor_data(sensor))
     if rank == 0:
         fx = json.load(open(os.path.join(ROOT, "tests", "golden", "roofline_%s.json" % a.scene)))
         # bytes per unit of each kernel: V_n * 80 + V_t * 48 + 48 with the kernel's OWN canonical visit counts;

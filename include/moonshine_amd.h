@@ -208,6 +208,8 @@ void* MsneGetPackedFilmDevicePtr(const HdMoonshine*, SensorHandle);            /
  * from device memory into the sensor's full row-major film and its host buffer.  The gathered buffer must be complete
  * when this is called (the library's streams are non-blocking: synchronise the stream that filled it first). */
 int MsneUnpackGatheredFilm(HdMoonshine*, SensorHandle, const void* gathered_device_ptr, uint32_t shard_count);
+uint64_t MsneGetPackedFilmStride(const HdMoonshine*, SensorHandle);   /* float4 per shard in a gathered buffer: the largest shard's tiles * tile_size^2 */
+
 
 /* ObjectPicker.getClickedObject (ObjectPicker.zig:89-128) = the raygen of shaders/hrtsystem/input.hlsl:24-69: ONE closest-hit
  * ray through `normalized_coords` (0..1 across the sensor, y down: uv = (x, 1 - y)), lens sample (0,0), lens used as given
@@ -232,6 +234,32 @@ int MsneSaveSensorExr(HdMoonshine*, SensorHandle, Extent2D, const char* exr_path
 int MsneExrLoad(const char* exr_path, float* rgba_out, Extent2D* extent_inout);
 int MsneExrSave(const char* exr_path, const float* rgba, Extent2D extent);
 const char* MsneGetIoError(void);
+
+/* ---- native multi-GPU rendering: one context per GPU in ONE process (no reference equivalent: VulkanContext.zig:313-326 picks one
+ * device).  Image tiles shard over the members (tile t -> member t mod n), every member holds the whole scene, the only collective
+ * in the data path is ONE ncclGather (RCCL over xGMI) of the packed films to member 0, followed by k_unpack_film there.  Members on
+ * the same GPU (tests, one-GPU machines) gather with a device copy instead.  Scene calls go to every member — directly through
+ * MsneGroupContext(g, i), or through the replicating wrappers below, which run the members' calls on one host thread each. ---- */
+typedef struct MsneGroup MsneGroup;
+MsneGroup* MsneGroupCreate(const int32_t* devices /* HIP ordinals, NULL = 0..n-1 modulo the device count */, uint32_t n, uint32_t tile_size /* 0 = default */);
+void MsneGroupDestroy(MsneGroup*);
+uint32_t MsneGroupSize(const MsneGroup*);
+HdMoonshine* MsneGroupContext(MsneGroup*, uint32_t member);
+int MsneGroupLoadGlb(MsneGroup*, const char* glb_path, MsneGlbInfo* info_out);              /* Scene.fromGlbExr on every member (Scene.zig:28-62) */
+int MsneGroupSetBackgroundExr(MsneGroup*, const char* exr_path);
+int MsneGroupSetPipeline(MsneGroup*, const MsnePipelineOpts*);
+int64_t MsneGroupCreateSensor(MsneGroup*, Extent2D);
+/* offline/main.zig:131-203: `launches` launches on every member's tiles, concurrently; gather; unpack.  The full image is then in
+ * HdMoonshineGetSensorData(MsneGroupContext(g, 0), sensor). */
+int MsneGroupRender(MsneGroup*, SensorHandle, LensHandle, uint32_t launches);
+/* The frame loop of `online` without a window (online/main.zig:287-305,415-416): per frame, clear the sensor when it is past
+ * max_sample_count, launch samples_per_run samples while it is below (always when max_sample_count == 0), present, count.  Presenting
+ * = gather + unpack + `present(user, frame, rgba float4[w*h], sample_count)`, every `gather_every` frames and after the last one. */
+typedef int (*MsnePresentFn)(void* user, uint32_t frame, const float* rgba, uint32_t sample_count);
+int MsneGroupRenderProgressive(MsneGroup*, SensorHandle, LensHandle, uint32_t frames, uint32_t max_sample_count, uint32_t gather_every, MsnePresentFn present, void* user);
+int MsneGroupGetStats(MsneGroup*, MsneStats* summed_out, double* gather_ms_out, uint64_t* gathers_out);   /* render_ms = the slowest member's */
+const char* MsneGroupTransport(const MsneGroup*);        /* "rccl" | "copy" | "none": what the last gather used */
+const char* MsneGroupGetLastError(const MsneGroup*);     /* NULL group -> last creation error */
 
 /* ------------------------------------------------------------------ */
 /* Part 3 — diagnostics for parity tests and profiling (no reference   */

@@ -75,6 +75,8 @@ class MsneStats(C.Structure):
                 ("trace_closest_launches", C.c_uint64), ("trace_shadow_launches", C.c_uint64), ("shade_launches", C.c_uint64)]
 
 
+PRESENT_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_uint32, C.POINTER(C.c_float), C.c_uint32)   # MsnePresentFn
+
 GLASS, LAMBERT, PERFECT_MIRROR, STANDARD_PBR = 0, 1, 2, 3
 FORMATS = {"r8g8b8a8_srgb": 0, "r8g8_unorm": 1, "r8_unorm": 2, "r32g32b32a32_sfloat": 3,
            "r32g32_sfloat": 4, "r32_sfloat": 5, "r16g16b16a16_sfloat": 6}
@@ -137,6 +139,20 @@ SYMBOLS = [
     ("MsneReadEnv", C.c_int, [_vp, _vp, _vp]),
     ("MsneGetAliasTable", _u32, [_vp, _vp, _u32]),
     ("MsneGetBounceCounters", C.c_int, [_vp, _vp, _u32]),
+    ("MsneGetPackedFilmStride", C.c_uint64, [_vp, _u32]),
+    ("MsneGroupCreate", _vp, [_vp, _u32, _u32]),
+    ("MsneGroupDestroy", None, [_vp]),
+    ("MsneGroupSize", _u32, [_vp]),
+    ("MsneGroupContext", _vp, [_vp, _u32]),
+    ("MsneGroupLoadGlb", C.c_int, [_vp, C.c_char_p, _vp]),
+    ("MsneGroupSetBackgroundExr", C.c_int, [_vp, C.c_char_p]),
+    ("MsneGroupSetPipeline", C.c_int, [_vp, _vp]),
+    ("MsneGroupCreateSensor", C.c_int64, [_vp, Extent2D]),
+    ("MsneGroupRender", C.c_int, [_vp, _u32, _u32, _u32]),
+    ("MsneGroupRenderProgressive", C.c_int, [_vp, _u32, _u32, _u32, _u32, _u32, _vp, _vp]),
+    ("MsneGroupGetStats", C.c_int, [_vp, _vp, _vp, _vp]),
+    ("MsneGroupTransport", C.c_char_p, [_vp]),
+    ("MsneGroupGetLastError", C.c_char_p, [_vp]),
     ("MsneShadeProbe", C.c_int, [_vp, C.c_int, _vp, _u32, _vp]),
     ("MsneReadBvh", C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
 ]
@@ -226,7 +242,8 @@ class Context:
 
     def close(self):
         if getattr(self, "h", None):
-            self.L.HdMoonshineDestroy(self.h)
+            if not getattr(self, "_borrowed", False):      # a group's members are destroyed by the group
+                self.L.HdMoonshineDestroy(self.h)
             self.h = None
 
     def __del__(self):
@@ -443,3 +460,69 @@ class Context:
         if self.L.MsneReadBvh(self.h, _ptr(nodes), C.byref(nn), _ptr(tris), C.byref(nt), C.byref(root), _ptr(items), C.byref(ni)) != 0:
             self._err("MsneReadBvh")
         return nodes.reshape(-1, 80), tris.reshape(-1, 12), int(root.value), items[:ni.value]
+
+
+class Group:
+    """MsneGroup: one context per GPU in this process, tiles sharded over them, one gather of the films (csrc/group.hip).
+    `members` are Context objects that share the group's handles (scene calls go to every one of them)."""
+
+    def __init__(self, devices, tile_size=0):
+        self.L = load_library()
+        d = (C.c_int32 * len(devices))(*devices)
+        self.h = self.L.MsneGroupCreate(d, len(devices), tile_size)
+        if not self.h:
+            raise MoonshineError("MsneGroupCreate failed: %s" % (self.L.MsneGroupGetLastError(None) or b"").decode())
+        self.members = []
+        for i in range(len(devices)):
+            c = Context.__new__(Context)
+            c.L = self.L; c.h = self.L.MsneGroupContext(self.h, i); c._extents = {}; c._borrowed = True
+            c.tile_size, c.shard_index, c.shard_count = tile_size or tiles.DEFAULT_TILE, i, len(devices)
+            self.members.append(c)
+
+    def _err(self, what):
+        raise MoonshineError("%s: %s" % (what, (self.L.MsneGroupGetLastError(self.h) or b"").decode()))
+
+    def build(self, builder, **kw):
+        """run a scenes.* builder on every member; returns the (sensor, lens) handles (equal on all members)"""
+        out = [builder(c, **kw) for c in self.members]
+        assert all(o == out[0] for o in out)
+        return out[0]
+
+    def set_pipeline(self, **kw):
+        for c in self.members:
+            c.set_pipeline(**kw)
+
+    def render(self, sensor, lens, launches=1):
+        if self.L.MsneGroupRender(self.h, sensor, lens, launches) != 0:
+            self._err("MsneGroupRender")
+
+    def render_progressive(self, sensor, lens, frames, max_sample_count=0, gather_every=1, present=None):
+        seen = []
+
+        def cb(user, frame, rgba, count):
+            w, h = self.members[0]._extents[sensor]
+            img = np.ctypeslib.as_array(rgba, shape=(h, w, 4)).copy()
+            seen.append((frame, count, img))
+            return int(present(frame, count, img) or 0) if present else 0
+        fn = PRESENT_FN(cb)
+        if self.L.MsneGroupRenderProgressive(self.h, sensor, lens, frames, max_sample_count, gather_every, fn, None) != 0:
+            self._err("MsneGroupRenderProgressive")
+        return seen
+
+    def sensor_data(self, sensor):
+        return self.members[0].sensor_data(sensor)
+
+    def transport(self):
+        return (self.L.MsneGroupTransport(self.h) or b"").decode()
+
+    def close(self):
+        if getattr(self, "h", None):
+            for c in self.members:
+                c.h = None
+            self.L.MsneGroupDestroy(self.h); self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -10,7 +10,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 HOST = os.path.join(HERE, "host")
-SOURCES = ["context.hip", "bvh_build.hip", "trace.hip", "integrator.hip", "env.hip"]
+SOURCES = ["context.hip", "bvh_build.hip", "trace.hip", "integrator.hip", "env.hip", "group.hip"]
 HOST_SOURCES = ["exr.cpp", "png.cpp", "glb.cpp", "scene_io.cpp"]      # plain C++ above the C ABI
 LIB = os.path.join(HERE, "libmoonshine_amd.so")
 OFFLINE = os.path.join(HERE, "offline")
@@ -57,7 +57,7 @@ def build(force=False, verbose=False, variant=None, extra_flags=()):
         if p.wait() != 0:
             raise RuntimeError("compile failed on %s" % src)
     if force or procs or _stale(lib, objs):
-        subprocess.check_call([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib] + objs + ["-lz"])
+        subprocess.check_call([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib] + objs + ["-lz", "-ldl", "-lpthread"])
     if variant is not None:
         return lib
     cli = os.path.join(HOST, "offline.cpp")

@@ -929,6 +929,12 @@ bool HdMoonshineRender(HdMoonshine* c, SensorHandle s, LensHandle l) { return Ms
 
 uint64_t MsneGetShardTileCount(const HdMoonshine* c, SensorHandle s) { return s < c->sensors.size() ? c->sensors[s]->shard.local_tiles : 0; }
 void* MsneGetPackedFilmDevicePtr(const HdMoonshine* c, SensorHandle s) { return s < c->sensors.size() ? (void*)c->sensors[s]->film_packed.p : nullptr; }
+uint64_t MsneGetPackedFilmStride(const HdMoonshine* c, SensorHandle sh) {
+    if (!c || sh >= c->sensors.size()) return 0;
+    const ShardView& v = c->sensors[sh]->shard;
+    const uint32_t total = v.tiles_x * v.tiles_y;
+    return (uint64_t)((total + v.shard_count - 1) / v.shard_count) * v.tile_size * v.tile_size;
+}
 int MsneUnpackGatheredFilm(HdMoonshine* c, SensorHandle sh, const void* gathered, uint32_t shard_count) {
     LOCK(c);
     if (!c->bind() || sh >= c->sensors.size() || !gathered) return -1;
