@@ -197,6 +197,10 @@ int MsneRender(HdMoonshine*, SensorHandle, LensHandle, uint32_t launches, int re
 /* Pre-allocates the wavefront state for MsneRender calls of up to `launches` launches on this sensor (otherwise it is
  * allocated on first use, inside that call).  Up to $MSNE_MAX_INFLIGHT (default 160 Mi) paths are traced concurrently. */
 int MsneReserve(HdMoonshine*, SensorHandle, uint32_t launches);
+/* The in-flight budget itself, in paths (288 B of wavefront state each at one env + one mesh light sample).  Contexts that share one GPU
+ * share its memory: MsneGroupCreate divides the default among the members it places on the same device. */
+int MsneSetMaxInflight(HdMoonshine*, uint64_t paths);
+uint64_t MsneGetMaxInflight(const HdMoonshine*);
 void MsneClearSensor(HdMoonshine*, SensorHandle);                 /* Sensor.clear (core/Sensor.zig:81-83) */
 uint32_t MsneGetSampleCount(const HdMoonshine*, SensorHandle);    /* Sensor.sample_count (core/Sensor.zig:12) */
 

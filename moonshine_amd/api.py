@@ -140,6 +140,8 @@ SYMBOLS = [
     ("MsneGetAliasTable", _u32, [_vp, _vp, _u32]),
     ("MsneGetBounceCounters", C.c_int, [_vp, _vp, _u32]),
     ("MsneGetPackedFilmStride", C.c_uint64, [_vp, _u32]),
+    ("MsneSetMaxInflight", C.c_int, [_vp, C.c_uint64]),
+    ("MsneGetMaxInflight", C.c_uint64, [_vp]),
     ("MsneGroupCreate", _vp, [_vp, _u32, _u32]),
     ("MsneGroupDestroy", None, [_vp]),
     ("MsneGroupSize", _u32, [_vp]),

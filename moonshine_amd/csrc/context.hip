@@ -140,7 +140,11 @@ struct HdMoonshine {
     };
     static constexpr int MAX_PIPES = 4;
     Pipe pipes[MAX_PIPES];
-    bool serial_streams = false;                   // $MSNE_SERIAL=1: k_trace_shadow runs in stream order on s0 instead of overlapping the next bounce's k_trace_closest (profiling: per-kernel times without co-residency)
+    // k_trace_shadow(b) may overlap k_trace_closest(b+1) on a second stream.  Both kernels are VALU-issue bound, so while their queues are
+    // long the overlap buys nothing (S1 x 64 launches: 108.5 ms overlapped, 108.8 ms in stream order) and only blurs per-kernel timings;
+    // it pays in the thin tails of a batch, where neither kernel fills the chip.  $MSNE_SERIAL: 1 = always in stream order, 0 = always
+    // overlapped, unset = in stream order for the first `serial_bounces` bounces of batches of at least `serial_min_paths` paths.
+    int serial_mode = -1; uint32_t serial_bounces = 4; size_t serial_min_paths = 16u << 20;
     int n_pipes = 1;                               // $MSNE_PIPES (measured on S1: more pipes never won — bigger batches beat overlapped smaller ones)
     size_t single_pipe_paths = 48u << 20;          // batches at least this large run on one pipe (tails are negligible there)
     DevBuf<float4> d_lbuf;
@@ -645,8 +649,10 @@ bool HdMoonshine::render(uint32_t sensor, uint32_t lens, uint32_t launches, bool
         CHECK_HIP(this, hipMemsetAsync(cnt, 0, ((size_t)max_iter + 2) * sizeof(BounceCounters), pp.s0));
         launch_raygen(pp.s0, shade_grid, s->shard, cam, opts, first_sample, ns, st[0], cnt);
         hipEvent_t shadow_done = nullptr;
-        const hipStream_t sh_stream = serial_streams ? pp.s0 : pp.s1;
+        const size_t batch_paths = (size_t)ns * P;
         for (uint32_t b = 0; b < max_iter; b++) {
+            const bool in_order = serial_mode == 1 || (serial_mode < 0 && b < serial_bounces && batch_paths >= serial_min_paths);
+            const hipStream_t sh_stream = in_order ? pp.s0 : pp.s1;
             const PathState& cur = st[b & 1]; const PathState& nxt = st[(b + 1) & 1];
             timed2(0, pp.s0, [&] { launch_trace_closest(pp.s0, trace_grid, trace_stats, sv, cur, hits, cnt + b, pp.spill.p, d_overflow.p, d_trace_stats.p, refill); });
             if (shadow_done) CHECK_HIP(this, hipStreamWaitEvent(pp.s0, shadow_done, 0));   // k_shade(b) consumes the results of k_trace_shadow(b-1)
@@ -762,7 +768,7 @@ HdMoonshine* MsneCreate(const MsneConfig* cfg_in) {
     { c->trace_grid = prop.multiProcessorCount * trace_blocks_per_cu(); c->shade_grid = prop.multiProcessorCount * 8; c->shade_k_grid = prop.multiProcessorCount * 96; }   // k_shade: workgroups differ in cost (what their 256 paths hit); 96 per CU instead of 8 evens the CUs out (-6 %)
     if (const char* e = getenv("MSNE_SHADE_BLOCKS_PER_CU")) c->shade_k_grid = prop.multiProcessorCount * std::max(1, atoi(e));
     if (const char* e = getenv("MSNE_MAX_INFLIGHT")) c->max_inflight = (size_t)atoll(e);
-    if (const char* e = getenv("MSNE_SERIAL")) c->serial_streams = atoi(e) != 0;
+    if (const char* e = getenv("MSNE_SERIAL")) c->serial_mode = atoi(e) != 0 ? 1 : 0;
     if (const char* e = getenv("MSNE_PIPES")) c->n_pipes = std::max(1, std::min((int)HdMoonshine::MAX_PIPES, atoi(e)));
     if (const char* e = getenv("MSNE_SINGLE_PIPE_PATHS")) c->single_pipe_paths = (size_t)atoll(e);
     if (const char* e = getenv("MSNE_REFILL")) c->refill = (uint32_t)std::max(1, std::min(64, atoi(e)));
@@ -920,6 +926,13 @@ int MsneReserve(HdMoonshine* c, SensorHandle sh, uint32_t launches) {
     const size_t per_pipe = per_launch <= c->max_inflight ? per_launch * ((nbu + K - 1) / K) : n;
     return c->ensure_wavefront(per_pipe, n, K) ? 0 : -1;
 }
+int MsneSetMaxInflight(HdMoonshine* c, uint64_t paths) {
+    LOCK(c);
+    if (paths == 0) return -1;
+    c->max_inflight = (size_t)paths;
+    return 0;
+}
+uint64_t MsneGetMaxInflight(const HdMoonshine* c) { return c ? (uint64_t)c->max_inflight : 0; }
 int MsneRender(HdMoonshine* c, SensorHandle s, LensHandle l, uint32_t launches, int readback) {
     LOCK(c);
     if (!c->bind()) return -1;

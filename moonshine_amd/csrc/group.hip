@@ -13,6 +13,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <algorithm>
 #include <mutex>
 #include <set>
 #include <string>
@@ -154,6 +155,11 @@ MsneGroup* MsneGroupCreate(const int32_t* devices, uint32_t n, uint32_t tile_siz
         HdMoonshine* c = MsneCreate(&cfg);
         if (!c) { g_group_create_error = std::string("group member: ") + MsneGetLastError(nullptr); MsneGroupDestroy(g); return nullptr; }
         g->ctx.push_back(c); g->dev.push_back(d);
+    }
+    for (uint32_t i = 0; i < n; i++) {   // members that share a GPU share its memory: split the wavefront-state budget between them
+        uint32_t same = 0;
+        for (uint32_t k = 0; k < n; k++) same += g->dev[k] == g->dev[i] ? 1u : 0u;
+        if (same > 1) (void)MsneSetMaxInflight(g->ctx[i], std::max<uint64_t>(1u << 20, MsneGetMaxInflight(g->ctx[i]) / same));
     }
     return g;
 }

@@ -125,3 +125,75 @@ def write_cornell(path_glb, path_exr):
     b.node(camera=b.camera(0.69), matrix=assets.look_at_yup((0, 1.0, 3.9), (0, 1.0, 0)))
     open(path_glb, "wb").write(b.tobytes())
     open(path_exr, "wb").write(assets.exr_bytes(np.zeros((1, 1, 4), np.float32)))
+
+
+def write_bathroom_standin(path_glb, path_exr, spheres=48, order=5, tex=64, env=(2048, 1024)):
+    """Stand-in for BASELINE.json configs[2]/[3] ("Salle de bain": the asset is not in the reference tree nor on this machine):
+    about a million TEXTURED triangles with everything the importer handles on real assets (World.zig:44-363) — `spheres`
+    order-`order` icospheres (20 480 triangles each) with per-vertex normals and texcoords, each with its own PNG base colour,
+    metallic-roughness and normal map (3 x spheres textures + the room's), a three-level node hierarchy (room -> shelf -> object)
+    with TRS at every level and non-uniform scales, glass (KHR_materials_transmission + ior), an emissive-strength "Emitter" panel
+    (sampled) and an emissive TEXTURE, tiled room walls, and a 2048x1024 HDR environment stored as a PIZ-compressed HALF EXR."""
+    rs = np.random.default_rng(2024)
+    b = assets.GlbBuilder(interleaved=True)
+
+    def noise_tex(base, amp, size=tex, normal=False):
+        yy, xx = np.mgrid[0:size, 0:size].astype(np.float64) / size
+        f = sum(np.sin(2 * math.pi * (k * xx * rs.integers(1, 4) + k * yy * rs.integers(1, 4) + rs.random())) / k for k in (1, 2, 4))[..., None]
+        if normal:     # tangent-space normal map: x, y around 0.5, z near 1 (only RG are read, World.zig:57-62)
+            img = np.concatenate([0.5 + 0.12 * f, 0.5 + 0.12 * np.roll(f, size // 3, 0), np.ones_like(f)], -1)
+        else:
+            img = np.asarray(base)[None, None, :] + amp * f * np.asarray([1.0, 0.8, 0.6])
+        return (np.clip(img, 0, 1) * 255).astype(np.uint8)
+
+    P, I = scenes.icosphere(order)
+    Py = P[:, [0, 2, 1]] * [1, 1, -1]
+    N = Py / np.linalg.norm(Py, axis=1, keepdims=True)
+    UV = np.stack([np.arctan2(Py[:, 2], Py[:, 0]) / (2 * math.pi) + 0.5, np.arccos(np.clip(Py[:, 1], -1, 1)) / math.pi], -1) * [4.0, 2.0]   # tiles: repeat addressing
+    glass = b.material("Glass", transmission=1.0, ior=1.52)
+    chrome = b.material("Chrome", metallic=1.0, roughness=0.0)
+    objects = []
+    for k in range(spheres):
+        if k % 8 == 6:
+            mat = glass
+        elif k % 8 == 7:
+            mat = chrome
+        else:
+            col = b.texture_png(noise_tex(rs.uniform(0.2, 0.9, 3), 0.25))
+            mr = b.texture_png(noise_tex((0.5 * (k % 3 == 0), rs.uniform(0.15, 0.9), 0.0), 0.2))          # R = metalness, G = roughness (World.zig:171-174)
+            nm = b.texture_png(noise_tex(None, None, normal=True))
+            mat = b.material("Ceramic %d" % k, base_color_texture=col, metallic_roughness_texture=mr, normal_texture=nm, ior=1.45 + 0.01 * (k % 5))
+        objects.append(b.mesh([dict(positions=Py, indices=I, material=mat, normals=N, texcoords=UV, u32=(k % 2 == 0))]))
+    # the room (Y up): tiled floor and walls, a ceiling light panel, a glowing sign (emissive texture)
+    tile = b.material("Tiles", base_color_texture=b.texture_png(noise_tex((0.8, 0.85, 0.9), 0.1)), metallic_roughness_texture=b.texture_png(noise_tex((0.0, 0.35, 0.0), 0.15)),
+                      normal_texture=b.texture_png(noise_tex(None, None, normal=True)))
+    W, H, D = 7.0, 3.2, 5.0
+
+    def quad(p0, p1, p2, p3, mat, rep):
+        n = np.cross(np.subtract(p1, p0), np.subtract(p3, p0)); n = n / np.linalg.norm(n)
+        return b.mesh([dict(positions=[p0, p1, p2, p3], indices=[0, 1, 2, 0, 2, 3], material=mat, normals=[n] * 4, texcoords=[(0, 0), (rep, 0), (rep, rep), (0, rep)])])
+    room = [b.node(mesh=quad((-W, 0, D), (W, 0, D), (W, 0, -D), (-W, 0, -D), tile, 12), root=False),
+            b.node(mesh=quad((-W, 0, -D), (W, 0, -D), (W, H, -D), (-W, H, -D), tile, 8), root=False),
+            b.node(mesh=quad((-W, 0, D), (-W, 0, -D), (-W, H, -D), (-W, H, D), tile, 8), root=False),
+            b.node(mesh=quad((W, 0, -D), (W, 0, D), (W, H, D), (W, H, -D), tile, 8), root=False)]
+    lamp = b.material("Emitter panel", base_color=(0, 0, 0), emissive=(1.0, 0.95, 0.85), emissive_strength=18.0)
+    room.append(b.node(mesh=quad((-1.5, H - 0.01, -1.0), (1.5, H - 0.01, -1.0), (1.5, H - 0.01, 1.0), (-1.5, H - 0.01, 1.0), lamp, 1), root=False))
+    sign = b.material("Sign", base_color=(0.02, 0.02, 0.02), emissive_texture=b.texture_png(noise_tex((0.9, 0.2, 0.1), 0.5, 32)), emissive=(1, 1, 1))
+    room.append(b.node(mesh=quad((-2, 1.6, -D + 0.02), (2, 1.6, -D + 0.02), (2, 2.4, -D + 0.02), (-2, 2.4, -D + 0.02), sign, 1), root=False))
+    # shelves: room -> shelf (rotated, non-uniformly scaled) -> object (own TRS)
+    per = 8
+    for sidx in range((spheres + per - 1) // per):
+        kids = []
+        for j, m in enumerate(objects[sidx * per:(sidx + 1) * per]):
+            r = 0.28 + 0.05 * ((sidx + j) % 3)
+            kids.append(b.node(mesh=m, translation=((j - (per - 1) / 2) * 0.9, r, 0.15 * ((j % 2) * 2 - 1)), scale=(r, r * (1.0 + 0.2 * (j % 2)), r),
+                               rotation=(0, math.sin(0.3 * j), 0, math.cos(0.3 * j)), root=False))
+        ang = 0.12 * (sidx - 2.5)
+        room.append(b.node(children=kids, translation=(0.0, 0.02 + 0.01 * sidx, -D + 1.0 + 1.3 * sidx), rotation=(0, math.sin(ang / 2), 0, math.cos(ang / 2)),
+                           scale=(1.0, 1.0 + 0.05 * sidx, 1.0), root=False))
+    b.node(children=room, translation=(0.0, -0.5, 0.0))
+    b.node(camera=b.camera(0.75, 16.0 / 9.0), matrix=assets.look_at_yup((0.0, 2.3, 9.5), (0.0, 0.6, 0.0)))
+    open(path_glb, "wb").write(b.tobytes())
+    sky = scenes.sky_sun_equirect(*env)
+    open(path_exr, "wb").write(assets.exr_bytes(sky, "RGB", "half", "piz"))
+    return dict(triangles=spheres * len(I) + 2 * 6, textures=len(b.j["textures"]), nodes=len(b.j["nodes"]))

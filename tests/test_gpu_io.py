@@ -94,3 +94,56 @@ def test_config1_cornell_glb_offline_64spp(tmp_path, orc):
     assert np.array_equal(bits(got[..., :3]), bits(ref[..., :3]))
     a, b_ = ref[256, 40], ref[256, 471]      # the two side walls (the importer's Z-up row order mirrors the glTF scene, World.zig:339-346)
     assert 0.05 < float(ref[..., :3].mean()) < 2.0 and (a[0] - a[1]) * (b_[0] - b_[1]) < 0      # lit; one wall red, the other green
+
+
+# ---- BASELINE.json configs[2] and configs[3]: "Salle de bain" at 1080p / 256 spp on one GPU, and at 4K sharded 8 ways.  The asset
+# is not available ("asset substituted"): tests/io_common.py:write_bathroom_standin writes a ~1 M-triangle TEXTURED
+# interior (196 PNG textures, normal maps, metallic-roughness maps, node hierarchy, glass, emissive strength + emissive texture)
+# and a 2048x1024 PIZ-compressed HDR environment. ----
+def _oracle_tiles(orc, glb, exr, extent, spp, tiles, film, pipe):
+    tx, ty = (extent[0] + 63) // 64, (extent[1] + 63) // 64
+    for t in tiles:
+        oc = orc.Context(threads=os.cpu_count(), shard_index=t, shard_count=tx * ty)
+        ol, _ = io.oracle_load(orc, oc, glb, exr)
+        s = oc.create_sensor(*extent)
+        oc.set_pipeline(**pipe)
+        oc.render(s, ol, launches=spp)
+        x0, y0 = (t % tx) * 64, (t // tx) * 64
+        a, b = film[y0:y0 + 64, x0:x0 + 64, :3], oc.sensor_data(s)[y0:y0 + 64, x0:x0 + 64, :3]
+        assert a.size and np.array_equal(bits(a), bits(b)), "tile %d of %s differs from the oracle" % (t, extent)
+
+
+@pytest.mark.skipif((os.cpu_count() or 1) < 64, reason="the oracle needs a many-core host for 256-spp tiles (the GPU box has 256 threads)")
+def test_config2_textured_interior_1080p_256spp(tmp_path, orc):
+    """configs[2] (asset substituted): `offline` renders the textured interior at 1920x1080, 256 spp, full MIS, max_bounces 1024
+    (the CLI's defaults, offline/main.zig:106-111); three 64x64 tiles of the EXR are bit-identical to the oracle fed the same files"""
+    glb, exr, out = str(tmp_path / "bath.glb"), str(tmp_path / "sky.exr"), str(tmp_path / "out.exr")
+    meta = io.write_bathroom_standin(glb, exr)
+    assert meta["triangles"] > 900000 and meta["textures"] >= 64
+    exe = os.path.join(ROOT, "moonshine_amd", "offline")
+    r = subprocess.run([exe, glb, exr, out, "256", "--width", "1920", "--height", "1080"], capture_output=True, text=True, timeout=1200)
+    assert r.returncode == 0, r.stdout + r.stderr
+    from moonshine_amd import api
+    film = api.exr_load(out)
+    assert film.shape == (1080, 1920, 4) and np.isfinite(film).all() and 0.05 < float(film[..., :3].mean()) < 5.0
+    _oracle_tiles(orc, glb, exr, (1920, 1080), 256, (8 * 30 + 14, 11 * 30 + 9, 14 * 30 + 22), film,
+                  dict(samples_per_run=1, max_bounces=1024, env_samples_per_bounce=1, mesh_samples_per_bounce=1))
+    print(r.stdout)
+
+
+@pytest.mark.skipif((os.cpu_count() or 1) < 64, reason="the oracle needs a many-core host (the GPU box has 256 threads)")
+def test_config3_4k_sharded_eight_ways(tmp_path, orc):
+    """configs[3] (asset substituted, and 8 members on this box's ONE GPU instead of 8 GPUs — the gather is a device copy here, ncclGather
+    on distinct GPUs): `offline --devices 0,0,0,0,0,0,0,0` at 3840x2160; tiles of the assembled EXR are bit-identical to the oracle"""
+    glb, exr, out = str(tmp_path / "bath.glb"), str(tmp_path / "sky.exr"), str(tmp_path / "out.exr")
+    io.write_bathroom_standin(glb, exr)
+    exe = os.path.join(ROOT, "moonshine_amd", "offline")
+    r = subprocess.run([exe, glb, exr, out, "32", "--width", "3840", "--height", "2160", "--max-bounces", "8", "--devices", "0,0,0,0,0,0,0,0"],
+                       capture_output=True, text=True, timeout=1200)
+    assert r.returncode == 0 and "on 8 GPUs (film gather: copy, 1 x" in r.stdout, r.stdout + r.stderr
+    from moonshine_amd import api
+    film = api.exr_load(out)
+    assert film.shape == (2160, 3840, 4) and np.isfinite(film).all()
+    _oracle_tiles(orc, glb, exr, (3840, 2160), 32, (17 * 60 + 28, 25 * 60 + 41, 33 * 60 + 59), film,
+                  dict(samples_per_run=1, max_bounces=8, env_samples_per_bounce=1, mesh_samples_per_bounce=1))
+    print(r.stdout)
