@@ -132,7 +132,9 @@ def write_bathroom_standin(path_glb, path_exr, spheres=48, order=5, tex=64, env=
     about a million TEXTURED triangles with everything the importer handles on real assets (World.zig:44-363) — `spheres`
     order-`order` icospheres (20 480 triangles each) with per-vertex normals and texcoords, each with its own PNG base colour,
     metallic-roughness and normal map (3 x spheres textures + the room's), a three-level node hierarchy (room -> shelf -> object)
-    with TRS at every level and non-uniform scales, glass (KHR_materials_transmission + ior), an emissive-strength "Emitter" panel
+    with TRS at every level (uniform scales only: under a NON-uniform scale the reference's Frame::inSpace, reflection_frame.hlsl:24-30,
+    yields non-orthogonal shading frames, hence non-unit bounce directions and, about once in 3e6 samples, a NaN from the environment
+    lookup's sqrt(1 - |z|), mappings.hlsl:87 — faithfully reproduced by the oracle and the HIP path alike, but useless in a fixture), glass (KHR_materials_transmission + ior), an emissive-strength "Emitter" panel
     (sampled) and an emissive TEXTURE, tiled room walls, and a 2048x1024 HDR environment stored as a PIZ-compressed HALF EXR."""
     rs = np.random.default_rng(2024)
     b = assets.GlbBuilder(interleaved=True)
@@ -186,11 +188,11 @@ def write_bathroom_standin(path_glb, path_exr, spheres=48, order=5, tex=64, env=
         kids = []
         for j, m in enumerate(objects[sidx * per:(sidx + 1) * per]):
             r = 0.28 + 0.05 * ((sidx + j) % 3)
-            kids.append(b.node(mesh=m, translation=((j - (per - 1) / 2) * 0.9, r, 0.15 * ((j % 2) * 2 - 1)), scale=(r, r * (1.0 + 0.2 * (j % 2)), r),
+            kids.append(b.node(mesh=m, translation=((j - (per - 1) / 2) * 0.9, r, 0.15 * ((j % 2) * 2 - 1)), scale=(r, r, r),
                                rotation=(0, math.sin(0.3 * j), 0, math.cos(0.3 * j)), root=False))
         ang = 0.12 * (sidx - 2.5)
         room.append(b.node(children=kids, translation=(0.0, 0.02 + 0.01 * sidx, -D + 1.0 + 1.3 * sidx), rotation=(0, math.sin(ang / 2), 0, math.cos(ang / 2)),
-                           scale=(1.0, 1.0 + 0.05 * sidx, 1.0), root=False))
+                           scale=(1.0 + 0.05 * sidx,) * 3, root=False))
     b.node(children=room, translation=(0.0, -0.5, 0.0))
     b.node(camera=b.camera(0.75, 16.0 / 9.0), matrix=assets.look_at_yup((0.0, 2.3, 9.5), (0.0, 0.6, 0.0)))
     open(path_glb, "wb").write(b.tobytes())
