@@ -394,7 +394,7 @@ class Context:
     def traversal_counters(self):
         out = (C.c_uint64 * 20)()
         self.L.MsneGetTraversalCounters(self.h, out)
-        names = ("pop", "refill", "vote", "node", "tri", "active_lanes", "node_lane_steps", "iterations")
+        names = ("pop", "refill", "space_changes", "node", "tri", "active_lanes", "node_lane_steps", "iterations")
         return {"closest_node_visits": int(out[0]), "closest_tri_tests": int(out[1]),
                 "shadow_node_visits": int(out[2]), "shadow_tri_tests": int(out[3]),
                 "closest_profile": {n: int(out[4 + i]) for i, n in enumerate(names)},

@@ -36,12 +36,17 @@ __device__ __forceinline__ uint32_t expand_bits10(uint32_t v) {
 // `geo` = geometry index inside its instance; `inst` = owning instance for triangles of the merged world BLAS (else unused)
 struct BlasGeo { const float* positions; const uint32_t* indices; uint32_t tri_offset, tri_count, geo, inst; };
 
+// geometry that owns triangle i of the concatenated list (tri_offset ascending): binary search — a world BLAS can merge 10^5 geometries
+__device__ __forceinline__ uint32_t geo_of(const BlasGeo* geos, uint32_t ngeo, uint32_t i) {
+    uint32_t lo = 0, hi = ngeo;
+    while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (geos[mid].tri_offset <= i) lo = mid; else hi = mid; }
+    return lo;
+}
+
 __global__ void k_prim_boxes_tris(const BlasGeo* geos, uint32_t ngeo, uint32_t n, Box* boxes) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    uint32_t g = 0;
-    while (g + 1 < ngeo && i >= geos[g + 1].tri_offset) g++;
-    const BlasGeo ge = geos[g];
+    const BlasGeo ge = geos[geo_of(geos, ngeo, i)];
     const uint32_t p = i - ge.tri_offset;
     const uint32_t i0 = ge.indices[3 * p], i1 = ge.indices[3 * p + 1], i2 = ge.indices[3 * p + 2];
     Box b;
@@ -381,9 +386,7 @@ __global__ void k_emit_tris(const BlasGeo* geos, uint32_t ngeo, const uint32_t* 
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const uint32_t src = item_src[item_begin + i];
-    uint32_t g = 0;
-    while (g + 1 < ngeo && src >= geos[g + 1].tri_offset) g++;
-    const BlasGeo ge = geos[g];
+    const BlasGeo ge = geos[geo_of(geos, ngeo, src)];
     const uint32_t p = src - ge.tri_offset;
     const uint32_t i0 = ge.indices[3 * p], i1 = ge.indices[3 * p + 1], i2 = ge.indices[3 * p + 2];
     const float* P = ge.positions;

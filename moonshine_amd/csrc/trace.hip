@@ -432,7 +432,7 @@ __device__ __forceinline__ void trace_wave_loop(const SceneView& sc, uint32_t n,
         // it or nothing else can be done.
         const unsigned long long ms = INSTANCED ? __ballot(want_s) : 0ull;
         const bool do_s = INSTANCED && ms != 0ull && ((uint32_t)__popcll(ms) >= SPACE_MIN_LANES || (!do_n && !do_t));
-        lap(2);
+        if (STATS && do_s) cyc[2] += __popcll(ms);   // lanes that change space (slot 2 of the profile: the vote itself is timed with the node section)
         if (INSTANCED && do_s && want_s) {
             const bool enter = (L.g1 & GRP_KIND_MASK) == GRP_INST;
             bool need_ray = !enter;
