@@ -39,7 +39,10 @@ MSNE_HD f3 neg(f3 a) { return F3(-a.x, -a.y, -a.z); }
 MSNE_HD float dot(f3 a, f3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
 MSNE_HD f3 cross(f3 a, f3 b) { return F3(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x); }
 MSNE_HD float length(f3 a) { return __builtin_sqrtf(dot(a, a)); }
-MSNE_HD f3 normalize(f3 a) { return divs(a, length(a)); }
+// normalize(v) = v * (1 / |v|): ONE IEEE reciprocal and three multiplications (HLSL's normalize is precision-unspecified; three IEEE
+// divisions per call cost k_shade ~20 % of its vector instructions — a hit evaluates about twenty normalisations).  The test oracle
+// computes the same expression.
+MSNE_HD f3 normalize(f3 a) { const float r = 1.0f / length(a); return F3(a.x * r, a.y * r, a.z * r); }
 MSNE_HD float minf(float a, float b) { return a < b ? a : b; }
 MSNE_HD float maxf(float a, float b) { return a > b ? a : b; }
 MSNE_HD float clampf(float x, float lo, float hi) { return minf(maxf(x, lo), hi); }

@@ -112,8 +112,9 @@ __device__ __forceinline__ Attrs mesh_attributes_world(const SceneView& sc, bool
     // inWorld
     const m34 toWorld = inst->transform, toMesh = inst->world_to_instance;
     a.position = m34_mul_point(toWorld, a.position);
+    const bool own_frame = mesh.normals != nullptr;   // without vertex normals the two frames are the same vectors: the same operations give the same bits
     a.triangleFrame = frame_in_space(a.triangleFrame, toMesh);
-    a.frame = frame_in_space(a.frame, toMesh);
+    a.frame = own_frame ? frame_in_space(a.frame, toMesh) : a.triangleFrame;
     return a;
 }
 

@@ -51,7 +51,9 @@ static inline v3 v3cross(v3 a, v3 b) {
     return V3(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x);
 }
 static inline float v3length(v3 a) { return sqrtf(v3dot(a, a)); }
-static inline v3 v3normalize(v3 a) { return v3div(a, v3length(a)); }
+/* normalize(v) = v * (1 / |v|): one IEEE reciprocal, three multiplications — the expression the product computes (csrc/msne_math.h);
+ * HLSL leaves normalize's precision unspecified */
+static inline v3 v3normalize(v3 a) { const float r = 1.0f / v3length(a); return V3(a.x * r, a.y * r, a.z * r); }
 static inline float orc_minf(float a, float b) { return a < b ? a : b; }
 static inline float orc_maxf(float a, float b) { return a > b ? a : b; }
 static inline float orc_clampf(float x, float lo, float hi) { return orc_minf(orc_maxf(x, lo), hi); }

@@ -10,7 +10,7 @@ reference's own shape (engine/tests.zig:257-344) with the sphere's material swap
 NEE-on vs NEE-off agreement under a non-constant environment.
 
 Tolerance of (1): the implementations compute in f32, the second source in f64.  A record passes when
-|got - ref| <= 1e-5 |ref| + 4 |ref32 - ref| + 1e-7, where ref32 is the second source evaluated in float32: that term is the
+|got - ref| <= 1e-5 |ref| + 8 |ref32 - ref| + 1e-7, where ref32 is the second source evaluated in float32: that term is the
 rounding noise of the FORMULA ITSELF at that input (e.g. GGX's D near its peak cancels catastrophically in f32 for small alpha
 — a property of the reference's expression, not of anybody's restatement).  On the well-conditioned records (ref32 within
 1e-6 of ref) the plain 1e-5 relative bound holds and is asserted separately.  Records where a DISCRETE decision (a coin flip,
@@ -226,7 +226,7 @@ def check_values(name, got, x, env=None, rel=1e-5):
     use = finite & ~skip
     noise = np.abs(ref32 - ref)
     mag = magnitude(name, ref)
-    tol = rel * mag + 4.0 * noise + 1e-7
+    tol = rel * mag + 8.0 * noise + 1e-7
     err = np.abs(got - ref)
     badrec = (err > tol).any(1) & use
     if badrec.any():

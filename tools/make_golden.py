@@ -99,3 +99,16 @@ c.set_background(img, 32, 16)
 rgb, lum = c.env()
 np.savez(os.path.join(G, "env_32x16.npz"), src=img, rgb=rgb, **{"lum%d" % i: l for i, l in enumerate(lum)})
 print("golden fixtures written to", G)
+
+# (4) the import-rule gallery (tests/io_common.py:write_gallery, every rule of World.zig:44-363 in one GLB) rendered by the oracle
+import tempfile  # noqa: E402
+from tests import io_common as io  # noqa: E402
+d = tempfile.mkdtemp()
+io.write_gallery(os.path.join(d, "gallery.glb"), os.path.join(d, "sky.exr"))
+c = orc.Context(threads=os.cpu_count())
+lens, _ = io.oracle_load(orc, c, os.path.join(d, "gallery.glb"), os.path.join(d, "sky.exr"))
+s = c.create_sensor(96, 64)
+c.set_pipeline(samples_per_run=4, max_bounces=6, env_samples_per_bounce=1, mesh_samples_per_bounce=1)
+c.render(s, lens)
+np.save(os.path.join(G, "gallery_96x64_4spp.npy"), c.sensor_data(s))
+print("gallery golden written")
