@@ -173,7 +173,12 @@ __device__ __forceinline__ float box_area(const Box& b) {
 constexpr int PLOC_RADIUS = 16;
 constexpr int PLOC_BLOCK = 256;
 
-__global__ __launch_bounds__(PLOC_BLOCK) void k_ploc_nn(const Box* cbox, uint32_t c, uint32_t radius, uint32_t* nn) {
+// Round state lives on the device so that the host can queue several rounds without reading anything back: round r reads slot r & 1
+// and writes the other one.  c = clusters left, node_base = binary nodes made so far, stuck = a round merged nothing (cannot happen).
+struct PlocState { uint32_t c, node_base, stuck, pad; };
+
+__global__ __launch_bounds__(PLOC_BLOCK) void k_ploc_nn(const Box* cbox, const PlocState* st, uint32_t radius, uint32_t* nn) {
+    const uint32_t c = st->c;
     const uint32_t i = blockIdx.x * PLOC_BLOCK + threadIdx.x;
     if (i >= c) return;
     const Box bi = cbox[i];
@@ -192,8 +197,10 @@ __global__ __launch_bounds__(PLOC_BLOCK) void k_ploc_nn(const Box* cbox, uint32_
 }
 
 // flags per cluster: bit 0 = survives into the next round (alone, or as the owner of a merge), bit 16 = owner of a merge
-__global__ __launch_bounds__(PLOC_BLOCK) void k_ploc_mark(const uint32_t* nn, uint32_t c, uint32_t* flags, uint32_t* block_sums) {
+__global__ __launch_bounds__(PLOC_BLOCK) void k_ploc_mark(const uint32_t* nn, const PlocState* st, uint32_t* flags, uint32_t* block_sums) {
     __shared__ uint32_t wsum[PLOC_BLOCK / 64];
+    const uint32_t c = st->c;
+    if (blockIdx.x * PLOC_BLOCK >= c) return;     // (the grid is sized for the cluster count of an earlier round)
     const uint32_t i = blockIdx.x * PLOC_BLOCK + threadIdx.x;
     uint32_t f = 0;
     if (i < c) {
@@ -210,8 +217,9 @@ __global__ __launch_bounds__(PLOC_BLOCK) void k_ploc_mark(const uint32_t* nn, ui
 }
 
 // exclusive scan of the per-block sums (both 16-bit halves at once would overflow: they are widened to two words here)
-__global__ __launch_bounds__(1024) void k_ploc_scan(const uint32_t* block_sums, uint32_t nblocks, uint2* block_base, uint32_t* totals) {
+__global__ __launch_bounds__(1024) void k_ploc_scan(const uint32_t* block_sums, const PlocState* st, PlocState* st_next, uint2* block_base) {
     __shared__ uint2 part[1024];
+    const uint32_t nblocks = (st->c + PLOC_BLOCK - 1) / PLOC_BLOCK;
     const uint32_t per = (nblocks + 1023u) / 1024u;
     const uint32_t a = threadIdx.x * per, b = a + per < nblocks ? a + per : nblocks;
     uint2 s = make_uint2(0, 0);
@@ -221,7 +229,8 @@ __global__ __launch_bounds__(1024) void k_ploc_scan(const uint32_t* block_sums, 
     if (threadIdx.x == 0) {
         uint2 run = make_uint2(0, 0);
         for (int i = 0; i < 1024; i++) { const uint2 v = part[i]; part[i] = run; run.x += v.x; run.y += v.y; }
-        totals[0] = run.x; totals[1] = run.y;
+        st_next->c = run.x; st_next->node_base = st->node_base + run.y;
+        st_next->stuck = st->stuck | ((st->c > 1u && run.y == 0u) ? 1u : 0u);
     }
     __syncthreads();
     uint2 run = part[threadIdx.x];
@@ -229,8 +238,10 @@ __global__ __launch_bounds__(1024) void k_ploc_scan(const uint32_t* block_sums, 
 }
 
 __global__ __launch_bounds__(PLOC_BLOCK) void k_ploc_merge(const uint32_t* cref, const Box* cbox, const uint32_t* nn, const uint32_t* flags, const uint2* block_base,
-                                                        uint32_t c, uint32_t node_base, BinTree t, uint32_t* oref, Box* obox) {
+                                                        const PlocState* st, BinTree t, uint32_t* oref, Box* obox) {
     __shared__ uint2 wbase[PLOC_BLOCK / 64];
+    const uint32_t c = st->c, node_base = st->node_base;
+    if (blockIdx.x * PLOC_BLOCK >= c) return;
     const uint32_t i = blockIdx.x * PLOC_BLOCK + threadIdx.x;
     const uint32_t f = i < c ? flags[i] : 0u;
     const unsigned long long keep = __ballot(f & 1u), own = __ballot(f >> 16);
@@ -413,7 +424,7 @@ struct BuildScratch {
     CollapseWork *wa = nullptr, *wb = nullptr;
     uint32_t* next_count = nullptr;
     Box *cba = nullptr, *cbb = nullptr;                                       // PLOC cluster boxes (ping-pong)
-    uint32_t *cra = nullptr, *crb = nullptr, *nn = nullptr, *pflags = nullptr, *bsum = nullptr, *totals = nullptr;
+    uint32_t *cra = nullptr, *crb = nullptr, *nn = nullptr, *pflags = nullptr, *bsum = nullptr; PlocState* totals = nullptr;
     uint2* bbase = nullptr;
     void release() {
         void* p[] = { boxes, sorted, ibox, keys, keys2, idx, idx2, ghist, bounds, left, right, cost, split, wa, wb, next_count,
@@ -435,7 +446,7 @@ struct BuildScratch {
         const size_t nb = (N + PLOC_BLOCK - 1) / PLOC_BLOCK;
         HIPCHK(hipMalloc(&cba, N * sizeof(Box))); HIPCHK(hipMalloc(&cbb, N * sizeof(Box)));
         HIPCHK(hipMalloc(&cra, N * 4)); HIPCHK(hipMalloc(&crb, N * 4)); HIPCHK(hipMalloc(&nn, N * 4)); HIPCHK(hipMalloc(&pflags, N * 4));
-        HIPCHK(hipMalloc(&bsum, nb * 4)); HIPCHK(hipMalloc(&bbase, nb * sizeof(uint2))); HIPCHK(hipMalloc(&totals, 8));
+        HIPCHK(hipMalloc(&bsum, nb * 4)); HIPCHK(hipMalloc(&bbase, nb * sizeof(uint2))); HIPCHK(hipMalloc(&totals, 2 * sizeof(PlocState)));
         cap = n;
         return true;
     }
@@ -473,21 +484,30 @@ static bool build_from_boxes(BuildScratch& S, hipStream_t s, uint32_t n, Node8* 
     if (n >= 2) {
         HIPCHK(hipMemcpyAsync(S.cba, S.sorted, (size_t)n * sizeof(Box), hipMemcpyDeviceToDevice, s));
         hipLaunchKernelGGL(k_ploc_init, dim3((n + 255) / 256), dim3(256), 0, s, n, S.cra);
-        uint32_t c = n, node_base = 0;
         static const uint32_t radius = [] { const char* e = getenv("MSNE_PLOC_RADIUS"); return e ? (uint32_t)atoi(e) : (uint32_t)PLOC_RADIUS; }();
         uint32_t *ra = S.cra, *rb = S.crb; Box *ba = S.cba, *bb = S.cbb;
+        // Rounds are queued in groups of PLOC_GROUP without a host round trip: every kernel reads the cluster count of its round from
+        // the device (slot r & 1 of S.totals) and runs on a grid sized for the count at the start of the group; a round that starts
+        // with one cluster copies it through unchanged.  One read-back per group instead of one per round (1 M triangles: ~56 rounds).
+        constexpr uint32_t PLOC_GROUP = 8;
+        PlocState st0{ n, 0u, 0u, 0u };
+        HIPCHK(hipMemcpyAsync(S.totals, &st0, sizeof st0, hipMemcpyHostToDevice, s));
+        uint32_t c = n, round = 0;
         while (c > 1) {
             const uint32_t nb = (c + PLOC_BLOCK - 1) / PLOC_BLOCK;
-            hipLaunchKernelGGL(k_ploc_nn, dim3(nb), dim3(PLOC_BLOCK), 0, s, ba, c, radius, S.nn);
-            hipLaunchKernelGGL(k_ploc_mark, dim3(nb), dim3(PLOC_BLOCK), 0, s, S.nn, c, S.pflags, S.bsum);
-            hipLaunchKernelGGL(k_ploc_scan, dim3(1), dim3(1024), 0, s, S.bsum, nb, S.bbase, S.totals);
-            hipLaunchKernelGGL(k_ploc_merge, dim3(nb), dim3(PLOC_BLOCK), 0, s, ra, ba, S.nn, S.pflags, S.bbase, c, node_base, t, rb, bb);
-            uint32_t tot[2] = { 0, 0 };
-            HIPCHK(hipMemcpyAsync(tot, S.totals, 8, hipMemcpyDeviceToHost, s));
+            for (uint32_t g = 0; g < PLOC_GROUP; g++, round++) {
+                const PlocState* cur = S.totals + (round & 1u); PlocState* nxt = S.totals + ((round + 1u) & 1u);
+                hipLaunchKernelGGL(k_ploc_nn, dim3(nb), dim3(PLOC_BLOCK), 0, s, ba, cur, radius, S.nn);
+                hipLaunchKernelGGL(k_ploc_mark, dim3(nb), dim3(PLOC_BLOCK), 0, s, S.nn, cur, S.pflags, S.bsum);
+                hipLaunchKernelGGL(k_ploc_scan, dim3(1), dim3(1024), 0, s, S.bsum, cur, nxt, S.bbase);
+                hipLaunchKernelGGL(k_ploc_merge, dim3(nb), dim3(PLOC_BLOCK), 0, s, ra, ba, S.nn, S.pflags, S.bbase, cur, t, rb, bb);
+                std::swap(ra, rb); std::swap(ba, bb);
+            }
+            PlocState now{};
+            HIPCHK(hipMemcpyAsync(&now, S.totals + (round & 1u), sizeof now, hipMemcpyDeviceToHost, s));
             HIPCHK(hipStreamSynchronize(s));
-            if (tot[1] == 0 || tot[0] >= c) { fprintf(stderr, "moonshine_amd: PLOC made no progress\n"); return false; }
-            c = tot[0]; node_base += tot[1];
-            std::swap(ra, rb); std::swap(ba, bb);
+            if (now.stuck || now.c >= c) { fprintf(stderr, "moonshine_amd: PLOC made no progress\n"); return false; }
+            c = now.c;
         }
         HIPCHK(hipMemcpyAsync(&root_ref, ra, 4, hipMemcpyDeviceToHost, s));
         HIPCHK(hipMemcpyAsync(root_box, ba, sizeof(Box), hipMemcpyDeviceToHost, s));
@@ -543,17 +563,66 @@ bool bvh_build_blas(BuildScratch* scratch, hipStream_t s, const std::vector<Blas
     return ok;
 }
 
-// TLAS over instance world boxes (Accel.zig:484).  host_boxes: n x {lo[3],hi[3]}, ids: instance index per box.
-bool bvh_build_tlas(BuildScratch* scratch, hipStream_t s, const float* host_boxes, const uint32_t* host_ids, uint32_t n, Node8* nodes, uint32_t* node_counter, uint32_t node_capacity,
-                    uint32_t* tlas_items, uint32_t* item_counter, uint32_t* item_src, uint32_t* root_out) {
+// ---------------- TLAS (Accel.zig:484): instance world boxes on the GPU, then the same builder ----------------
+// A TLAS leaf is the world box of the instance's TRANSFORMED VERTICES, not of the transformed corners of its BLAS root box (up to 1.7x
+// wider per axis under rotation; every false TLAS hit costs a change of space in the traversal).  One workgroup per instance reduces
+// min / max over the vertices of its meshes; an instance without a finite vertex, or flagged `exact = 0`, takes the corner box.
+struct TlasInst { float T[12]; float blas_box[6]; uint32_t mesh_begin, mesh_end, exact, pad; };   // mesh_begin..mesh_end index TlasMesh
+struct TlasMesh { const float* positions; uint32_t count, pad; };
+
+__global__ __launch_bounds__(256) void k_instance_boxes(const TlasInst* insts, const TlasMesh* meshes, uint32_t n, Box* boxes) {
+    __shared__ float s_lo[3][256 / 64], s_hi[3][256 / 64];
+    const uint32_t i = blockIdx.x;
+    if (i >= n) return;
+    const TlasInst in = insts[i];
+    m34 T;
+    for (int r = 0; r < 3; r++) for (int c = 0; c < 4; c++) T.m[r][c] = in.T[4 * r + c];
+    float lo[3] = { 3e38f, 3e38f, 3e38f }, hi[3] = { -3e38f, -3e38f, -3e38f };
+    if (in.exact) {
+        for (uint32_t m = in.mesh_begin; m < in.mesh_end; m++) {
+            const TlasMesh me = meshes[m];
+            for (uint32_t v = threadIdx.x; v < me.count; v += 256) {
+                const f3 q = m34_mul_point(T, F3(me.positions[3 * (size_t)v], me.positions[3 * (size_t)v + 1], me.positions[3 * (size_t)v + 2]));
+                if (!(q.x == q.x && q.y == q.y && q.z == q.z)) continue;   // NaN vertices belong to inactive triangles
+                lo[0] = fminf(lo[0], q.x); lo[1] = fminf(lo[1], q.y); lo[2] = fminf(lo[2], q.z);
+                hi[0] = fmaxf(hi[0], q.x); hi[1] = fmaxf(hi[1], q.y); hi[2] = fmaxf(hi[2], q.z);
+            }
+        }
+    }
+    for (int k = 0; k < 3; k++) {
+        for (int o = 32; o >= 1; o >>= 1) { lo[k] = fminf(lo[k], __shfl_xor(lo[k], o)); hi[k] = fmaxf(hi[k], __shfl_xor(hi[k], o)); }
+        if ((threadIdx.x & 63) == 0) { s_lo[k][threadIdx.x >> 6] = lo[k]; s_hi[k][threadIdx.x >> 6] = hi[k]; }
+    }
+    __syncthreads();
+    if (threadIdx.x != 0) return;
+    for (int k = 0; k < 3; k++) for (int w = 0; w < 256 / 64; w++) { lo[k] = fminf(lo[k], s_lo[k][w]); hi[k] = fmaxf(hi[k], s_hi[k][w]); }
+    if (lo[0] > hi[0]) for (int k = 0; k < 8; k++) {   // no vertex seen: the transformed corners of the BLAS root box
+        const f3 q = m34_mul_point(T, F3((k & 1) ? in.blas_box[3] : in.blas_box[0], (k & 2) ? in.blas_box[4] : in.blas_box[1], (k & 4) ? in.blas_box[5] : in.blas_box[2]));
+        lo[0] = fminf(lo[0], q.x); lo[1] = fminf(lo[1], q.y); lo[2] = fminf(lo[2], q.z);
+        hi[0] = fmaxf(hi[0], q.x); hi[1] = fmaxf(hi[1], q.y); hi[2] = fmaxf(hi[2], q.z);
+    }
+    float pad = 1e-30f;
+    for (int k = 0; k < 3; k++) pad += 1e-6f * (fabsf(hi[k] - lo[k]) + fabsf(hi[k]) + fabsf(lo[k]));
+    Box b;
+    for (int k = 0; k < 3; k++) { b.lo[k] = lo[k] - pad; b.hi[k] = hi[k] + pad; }
+    boxes[i] = b;
+}
+
+// insts / meshes: host arrays describing the n visible instances (ids: instance index per entry)
+bool bvh_build_tlas(BuildScratch* scratch, hipStream_t s, const TlasInst* insts, const uint32_t* host_ids, uint32_t n, const TlasMesh* meshes, uint32_t nmeshes,
+                    Node8* nodes, uint32_t* node_counter, uint32_t node_capacity, uint32_t* tlas_items, uint32_t* item_counter, uint32_t* item_src, uint32_t* root_out) {
     if (n == 0) { *root_out = MAX_UINT; return true; }
     if (!scratch) return false;
     BuildScratch& g_scratch = *scratch;
     if (!g_scratch.reserve(n)) return false;
-    HIPCHK(hipMemcpyAsync(g_scratch.boxes, host_boxes, (size_t)n * sizeof(Box), hipMemcpyHostToDevice, s));
-    uint32_t* dids = nullptr;
+    TlasInst* dinst = nullptr; TlasMesh* dmesh = nullptr; uint32_t* dids = nullptr;
+    HIPCHK(hipMalloc(&dinst, (size_t)n * sizeof(TlasInst)));
+    HIPCHK(hipMalloc(&dmesh, (size_t)std::max(nmeshes, 1u) * sizeof(TlasMesh)));
     HIPCHK(hipMalloc(&dids, (size_t)n * 4));
+    HIPCHK(hipMemcpyAsync(dinst, insts, (size_t)n * sizeof(TlasInst), hipMemcpyHostToDevice, s));
+    if (nmeshes) HIPCHK(hipMemcpyAsync(dmesh, meshes, (size_t)nmeshes * sizeof(TlasMesh), hipMemcpyHostToDevice, s));
     HIPCHK(hipMemcpyAsync(dids, host_ids, (size_t)n * 4, hipMemcpyHostToDevice, s));
+    hipLaunchKernelGGL(k_instance_boxes, dim3(n), dim3(256), 0, s, dinst, dmesh, n, g_scratch.boxes);
     uint32_t item_begin = 0;
     HIPCHK(hipMemcpyAsync(&item_begin, item_counter, 4, hipMemcpyDeviceToHost, s));
     Box rb;
@@ -562,7 +631,7 @@ bool bvh_build_tlas(BuildScratch* scratch, hipStream_t s, const float* host_boxe
         hipLaunchKernelGGL(k_emit_items, dim3((n + 255) / 256), dim3(256), 0, s, item_src, item_begin, n, dids, tlas_items);
         HIPCHK(hipStreamSynchronize(s));
     }
-    (void)hipFree(dids);
+    (void)hipFree(dinst); (void)hipFree(dmesh); (void)hipFree(dids);
     return ok;
 }
 

@@ -39,7 +39,9 @@ void bvh_scratch_destroy(BuildScratch*);
 void bvh_scratch_release(BuildScratch*);
 size_t bvh_scratch_capacity(const BuildScratch*);
 bool bvh_build_blas(BuildScratch*, hipStream_t, const std::vector<BlasGeo>&, uint32_t, Node8*, uint32_t*, uint32_t, TriRec*, uint32_t*, uint32_t*, uint32_t*, float[6]);
-bool bvh_build_tlas(BuildScratch*, hipStream_t, const float*, const uint32_t*, uint32_t, Node8*, uint32_t*, uint32_t, uint32_t*, uint32_t*, uint32_t*, uint32_t*);
+struct TlasInst { float T[12]; float blas_box[6]; uint32_t mesh_begin, mesh_end, exact, pad; };
+struct TlasMesh { const float* positions; uint32_t count, pad; };
+bool bvh_build_tlas(BuildScratch*, hipStream_t, const TlasInst*, const uint32_t*, uint32_t, const TlasMesh*, uint32_t, Node8*, uint32_t*, uint32_t, uint32_t*, uint32_t*, uint32_t*, uint32_t*);
 }  // namespace msne
 
 using namespace msne;
@@ -65,8 +67,7 @@ struct MeshH {
     std::vector<float> h_positions; std::vector<uint32_t> h_indices;   // host copies for the alias-table areas (Accel.zig:503-519)
     uint32_t position_count = 0, attribute_count = 0, index_count = 0, max_index = 0; bool has_normals = false, has_texcoords = false;
 };
-struct InstanceH { m34 transform; bool visible; std::vector<GeometryRec> geos;
-                   float wbox[6]; m34 wbox_T; bool wbox_valid = false; };   // world box of the transformed vertices, and the transform it was computed for
+struct InstanceH { m34 transform; bool visible; std::vector<GeometryRec> geos; };
 struct BlasInfo { uint32_t root; float box[6]; uint32_t tris; };
 struct MaterialUpdate { bool has[6] = { false, false, false, false, false, false }; uint32_t tex[5] = { 0, 0, 0, 0, 0 }; float ior = 0.0f; };
 
@@ -389,43 +390,18 @@ bool HdMoonshine::rebuild_accel() {
 
     // instance records + TLAS over the transformed visible instances and the world pseudo-instance (Accel.zig:394-484)
     std::vector<InstanceRec> irec(N + 1);
-    std::vector<float> boxes; std::vector<uint32_t> ids;
-    // The world box of an instance: the box of its TRANSFORMED VERTICES while that is affordable (a rotated box of a box is up to
-    // 1.7x wider per axis than the geometry — every false TLAS hit costs a change of space in the traversal), else the transformed
-    // corners of the BLAS root box.  Host work, once per TLAS build: budget of 64 M vertex transforms (~0.1 s).
-    size_t exact_budget = 64u << 20;
+    std::vector<TlasInst> tinst; std::vector<TlasMesh> tmesh; std::vector<uint32_t> ids;
+    // TLAS leaf boxes are computed on the GPU (k_instance_boxes) from the transformed vertices of every visible instance — up to 1.7x
+    // tighter per axis than the transformed corners of the BLAS root box under rotation — on every TLAS build (S2: 5 M vertex transforms,
+    // microseconds); MSNE_EXACT_INSTANCE_BOXES=0 selects the corner boxes.
     static const bool exact_boxes = [] { const char* e = getenv("MSNE_EXACT_INSTANCE_BOXES"); return !e || atoi(e) != 0; }();
     auto add_box = [&](const m34& T, const float box[6], uint32_t id, const std::vector<uint32_t>* mesh_ids) {
-        float lo[3] = { 3e38f, 3e38f, 3e38f }, hi[3] = { -3e38f, -3e38f, -3e38f };
-        size_t work = 0;
-        if (mesh_ids) for (uint32_t mi : *mesh_ids) work += meshes[mi]->position_count;
-        InstanceH* cache = mesh_ids ? &instances[id] : nullptr;   // only edited instances are recomputed when the TLAS is rebuilt
-        if (exact_boxes && cache && cache->wbox_valid && memcmp(&cache->wbox_T, &T, sizeof(m34)) == 0) {
-            for (int k = 0; k < 3; k++) { lo[k] = cache->wbox[k]; hi[k] = cache->wbox[3 + k]; }
-        } else if (exact_boxes && mesh_ids && work != 0 && work <= exact_budget) {
-            exact_budget -= work;
-            for (uint32_t mi : *mesh_ids) {
-                const MeshH* mh = meshes[mi];
-                for (uint32_t v = 0; v < mh->position_count; v++) {
-                    const f3 q = m34_mul_point(T, F3(mh->h_positions[3 * (size_t)v], mh->h_positions[3 * (size_t)v + 1], mh->h_positions[3 * (size_t)v + 2]));
-                    if (!(q.x == q.x && q.y == q.y && q.z == q.z)) continue;   // NaN vertices belong to inactive triangles
-                    lo[0] = std::min(lo[0], q.x); lo[1] = std::min(lo[1], q.y); lo[2] = std::min(lo[2], q.z);
-                    hi[0] = std::max(hi[0], q.x); hi[1] = std::max(hi[1], q.y); hi[2] = std::max(hi[2], q.z);
-                }
-            }
-            if (lo[0] <= hi[0]) { for (int k = 0; k < 3; k++) { cache->wbox[k] = lo[k]; cache->wbox[3 + k] = hi[k]; } cache->wbox_T = T; cache->wbox_valid = true; }
-        }
-        if (lo[0] > hi[0]) for (int k = 0; k < 8; k++) {
-            const f3 p = F3((k & 1) ? box[3] : box[0], (k & 2) ? box[4] : box[1], (k & 4) ? box[5] : box[2]);
-            const f3 q = m34_mul_point(T, p);
-            lo[0] = std::min(lo[0], q.x); lo[1] = std::min(lo[1], q.y); lo[2] = std::min(lo[2], q.z);
-            hi[0] = std::max(hi[0], q.x); hi[1] = std::max(hi[1], q.y); hi[2] = std::max(hi[2], q.z);
-        }
-        float pad = 1e-30f;
-        for (int k = 0; k < 3; k++) pad += 1e-6f * (fabsf(hi[k] - lo[k]) + fabsf(hi[k]) + fabsf(lo[k]));
-        for (int k = 0; k < 3; k++) boxes.push_back(lo[k] - pad);
-        for (int k = 0; k < 3; k++) boxes.push_back(hi[k] + pad);
-        ids.push_back(id);
+        TlasInst t{};
+        memcpy(t.T, &T, 48); memcpy(t.blas_box, box, 24);
+        t.mesh_begin = (uint32_t)tmesh.size();
+        if (mesh_ids && exact_boxes) for (uint32_t mi : *mesh_ids) tmesh.push_back(TlasMesh{ meshes[mi]->positions.p, meshes[mi]->position_count, 0u });
+        t.mesh_end = (uint32_t)tmesh.size(); t.exact = t.mesh_end > t.mesh_begin ? 1u : 0u;
+        tinst.push_back(t); ids.push_back(id);
     };
     for (size_t i = 0; i < N; i++) {
         InstanceRec& r = irec[i];
@@ -456,7 +432,7 @@ bool HdMoonshine::rebuild_accel() {
     if (ids.size() == 1 && ids[0] == (uint32_t)N) {
         tlas_root = irec[N].blas_root; root_in_blas = 1;     // nothing but static geometry: traversal starts inside the world BLAS
         const uint32_t zero = 0; CHECK_HIP(this, hipMemcpyAsync(d_build_counters.p + 2, &zero, 4, hipMemcpyHostToDevice, stream));
-    } else if (!bvh_build_tlas(build_scratch, stream, boxes.data(), ids.data(), (uint32_t)ids.size(), d_nodes.p, d_build_counters.p, (uint32_t)d_nodes.n, d_tlas_items.p, d_build_counters.p + 2, d_item_src.p, &tlas_root)) { fail("TLAS build failed (details on stderr)"); return false; }
+    } else if (!bvh_build_tlas(build_scratch, stream, tinst.data(), ids.data(), (uint32_t)ids.size(), tmesh.data(), (uint32_t)tmesh.size(), d_nodes.p, d_build_counters.p, (uint32_t)d_nodes.n, d_tlas_items.p, d_build_counters.p + 2, d_item_src.p, &tlas_root)) { fail("TLAS build failed (details on stderr)"); return false; }
 
     // emissive-triangle alias table (Accel.zig:491-539): entry 0 = {count, sum of areas}
     std::vector<float> w; h_alias.assign(1, AliasEntry{ 0u, 0.0f, 0u, 0u, 0u });
