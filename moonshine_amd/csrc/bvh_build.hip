@@ -86,6 +86,24 @@ __global__ void k_morton(const Box* boxes, uint32_t n, const uint32_t* bounds, u
     keys[i] = code; idx[i] = i;
 }
 
+// exclusive prefix sum over the 1024 threads of a workgroup (wave shuffles + one LDS hop); returns the thread's exclusive prefix, `total` = sum of all
+__device__ __forceinline__ uint32_t block_scan_1024(uint32_t v, uint32_t* s_wave /* [16] */, uint32_t& total) {
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    uint32_t inc = v;
+    for (int o = 1; o < 64; o <<= 1) { const uint32_t t = __shfl_up(inc, o); if (lane >= (uint32_t)o) inc += t; }
+    if (lane == 63u) s_wave[wave] = inc;
+    __syncthreads();
+    if (wave == 0) {
+        uint32_t w = lane < 16u ? s_wave[lane] : 0u, wi = w;
+        for (int o = 1; o < 16; o <<= 1) { const uint32_t t = __shfl_up(wi, o); if (lane >= (uint32_t)o) wi += t; }
+        if (lane < 16u) s_wave[lane] = wi - w;       // exclusive prefix of the wave totals
+        if (lane == 15u) s_wave[16] = wi;            // grand total
+    }
+    __syncthreads();
+    total = s_wave[16];
+    return s_wave[wave] + inc - v;
+}
+
 // ---------------- LSD radix sort (stable), 8 bits per pass ----------------
 constexpr int RS_TILE = 2048;
 __global__ __launch_bounds__(256) void k_radix_hist(const uint32_t* keys, uint32_t n, int shift, uint32_t* ghist, uint32_t ntiles) {
@@ -98,16 +116,13 @@ __global__ __launch_bounds__(256) void k_radix_hist(const uint32_t* keys, uint32
     ghist[threadIdx.x * ntiles + blockIdx.x] = h[threadIdx.x];
 }
 __global__ __launch_bounds__(1024) void k_radix_scan(uint32_t* ghist, uint32_t total) {
-    __shared__ uint32_t part[1024];
+    __shared__ uint32_t s_wave[17];
     const uint32_t per = (total + 1023u) / 1024u;
-    const uint32_t a = threadIdx.x * per, b = a + per < total ? a + per : total;
+    const uint32_t a = threadIdx.x * per < total ? threadIdx.x * per : total, b = a + per < total ? a + per : total;
     uint32_t s = 0;
     for (uint32_t i = a; i < b; i++) s += ghist[i];
-    part[threadIdx.x] = s;
-    __syncthreads();
-    if (threadIdx.x == 0) { uint32_t run = 0; for (int i = 0; i < 1024; i++) { uint32_t v = part[i]; part[i] = run; run += v; } }
-    __syncthreads();
-    uint32_t run = part[threadIdx.x];
+    uint32_t all;
+    uint32_t run = block_scan_1024(s, s_wave, all);
     for (uint32_t i = a; i < b; i++) { uint32_t v = ghist[i]; ghist[i] = run; run += v; }
 }
 // one wave per tile, elements scattered in order → stable
@@ -218,22 +233,20 @@ __global__ __launch_bounds__(PLOC_BLOCK) void k_ploc_mark(const uint32_t* nn, co
 
 // exclusive scan of the per-block sums (both 16-bit halves at once would overflow: they are widened to two words here)
 __global__ __launch_bounds__(1024) void k_ploc_scan(const uint32_t* block_sums, const PlocState* st, PlocState* st_next, uint2* block_base) {
-    __shared__ uint2 part[1024];
+    __shared__ uint32_t s_wave[17];
     const uint32_t nblocks = (st->c + PLOC_BLOCK - 1) / PLOC_BLOCK;
     const uint32_t per = (nblocks + 1023u) / 1024u;
-    const uint32_t a = threadIdx.x * per, b = a + per < nblocks ? a + per : nblocks;
+    const uint32_t a = threadIdx.x * per < nblocks ? threadIdx.x * per : nblocks, b = a + per < nblocks ? a + per : nblocks;
     uint2 s = make_uint2(0, 0);
     for (uint32_t i = a; i < b; i++) { const uint32_t v = block_sums[i]; s.x += v & 0xffffu; s.y += v >> 16; }
-    part[threadIdx.x] = s;
-    __syncthreads();
+    uint2 run, tot;
+    run.x = block_scan_1024(s.x, s_wave, tot.x);
+    __syncthreads();      // (s_wave is reused by the second scan)
+    run.y = block_scan_1024(s.y, s_wave, tot.y);
     if (threadIdx.x == 0) {
-        uint2 run = make_uint2(0, 0);
-        for (int i = 0; i < 1024; i++) { const uint2 v = part[i]; part[i] = run; run.x += v.x; run.y += v.y; }
-        st_next->c = run.x; st_next->node_base = st->node_base + run.y;
-        st_next->stuck = st->stuck | ((st->c > 1u && run.y == 0u) ? 1u : 0u);
+        st_next->c = tot.x; st_next->node_base = st->node_base + tot.y;
+        st_next->stuck = st->stuck | ((st->c > 1u && tot.y == 0u) ? 1u : 0u);
     }
-    __syncthreads();
-    uint2 run = part[threadIdx.x];
     for (uint32_t i = a; i < b; i++) { const uint32_t v = block_sums[i]; block_base[i] = run; run.x += v & 0xffffu; run.y += v >> 16; }
 }
 
