@@ -124,12 +124,18 @@ __global__ __launch_bounds__(SHADE_BLOCK, 3) void k_shade(SceneView sc, Pipeline
     __shared__ uint32_t s_cat[NCAT * (SHADE_BLOCK / 64) + 1];
     __shared__ uint32_t s_perm[SHADE_BLOCK];
     __shared__ uint4 s_hit[SHADE_BLOCK], s_geo[SHADE_BLOCK], s_mat[2][SHADE_BLOCK];   // what the sort already fetched: hit, geometry and material records
+    // the path state travels through LDS too: every thread loads the record of ITS queue entry (five coalesced wave-wide loads) and the
+    // thread that shades the path after the sort picks it up there, instead of gathering 16-B pieces from a permuted index
+    __shared__ float4 s_ro[SHADE_BLOCK], s_rd[SHADE_BLOCK], s_tp[SHADE_BLOCK], s_lr[SHADE_BLOCK];
+    __shared__ uint2 s_sq[SHADE_BLOCK];
     for (uint32_t base_i = blockIdx.x * SHADE_BLOCK; base_i < n_pad; base_i += gridDim.x * SHADE_BLOCK) {
         uint32_t cat = CAT_NONE;
         {
             const uint32_t i0 = base_i + threadIdx.x;
             if (i0 < n) {
-                const uint32_t fl = f2u(cur.ro[i0].w);
+                const float4 ro_own = cur.ro[i0];
+                s_ro[threadIdx.x] = ro_own; s_rd[threadIdx.x] = cur.rd[i0]; s_tp[threadIdx.x] = cur.tp[i0]; s_lr[threadIdx.x] = cur.lr[i0]; s_sq[threadIdx.x] = cur.sq[i0];
+                const uint32_t fl = f2u(ro_own.w);
                 if (!(fl & (PATH_FLAG_MASKED | PATH_FLAG_DEAD))) {
                     if (fl & PATH_FLAG_ZOMBIE) cat = 0u;
                     else {
@@ -167,7 +173,6 @@ __global__ __launch_bounds__(SHADE_BLOCK, 3) void k_shade(SceneView sc, Pipeline
         }
         const bool live = threadIdx.x < s_cat[NCAT * (SHADE_BLOCK / 64)];
         const uint32_t src = live ? s_perm[threadIdx.x] : 0u;   // the thread that classified this path
-        const uint32_t i = live ? base_i + src : n_pad;
         // ---- phase A: what the hit means for the path (pending light samples, miss epilogue, emission, termination) ----
         bool alive = false, nee = false, delta = false;
         f3 rayO = F3(0, 0, 0), rayD = F3(0, 0, 1), throughput = F3(0, 0, 0), L = F3(0, 0, 0), woSs = F3(0, 0, 1);
@@ -177,9 +182,9 @@ __global__ __launch_bounds__(SHADE_BLOCK, 3) void k_shade(SceneView sc, Pipeline
         attrs.position = F3(0, 0, 0); attrs.triangleFrame.n = F3(0, 0, 1); shadingFrame.n = F3(0, 0, 1); shadingFrame.s = F3(1, 0, 0); shadingFrame.t = F3(0, 1, 0);
         material.type = MAT_LAMBERT; material.color = F3(0, 0, 0); material.metalness = 0.0f; material.alpha = 0.0f; material.ior = 1.0f;
         if (live) {
-            const float4 ro4 = cur.ro[i];
-            { const float4 rd4 = cur.rd[i]; rayO = F3(ro4.x, ro4.y, ro4.z); rayD = F3(rd4.x, rd4.y, rd4.z); }
-            const float4 tp4 = cur.tp[i], lr4 = cur.lr[i]; const uint2 sq2 = cur.sq[i];
+            const float4 ro4 = s_ro[src];
+            { const float4 rd4 = s_rd[src]; rayO = F3(ro4.x, ro4.y, ro4.z); rayD = F3(rd4.x, rd4.y, rd4.z); }
+            const float4 tp4 = s_tp[src], lr4 = s_lr[src]; const uint2 sq2 = s_sq[src];
             throughput = F3(tp4.x, tp4.y, tp4.z); L = F3(lr4.x, lr4.y, lr4.z);
             lastPdf = tp4.w; rng = f2u(lr4.w); slot = sq2.x; flags = f2u(ro4.w);
             // light samples of the previous bounce, in the reference's order (env samples, then mesh samples): each was stored
