@@ -438,15 +438,21 @@ typedef struct { OrcContext *c; orc_sensor *s; const Lens *lens; volatile uint32
 static void *worker(void *p) {
     worker_arg *a = (worker_arg *)p;
     const uint32_t ts = a->c->tile_size;
+    /* work unit = a band of 4 rows of a tile (many more units than threads: the host may have 256 of them); counters are kept on the
+     * worker's own stack — neighbouring worker_arg records share cache lines, and a counter is bumped for every node visit */
+    const uint32_t band = 4, bands = (ts + band - 1) / band;
+    orc_counters cnt; memset(&cnt, 0, sizeof cnt);
     for (;;) {
-        uint32_t t = __atomic_fetch_add(a->next, 1, __ATOMIC_RELAXED);
+        uint32_t u = __atomic_fetch_add(a->next, 1, __ATOMIC_RELAXED);
+        uint32_t t = u / bands, b = u % bands;
         if (t >= a->ntiles) break;
         if (t % a->c->shard_count != a->c->shard_index) continue;          /* tile t -> shard t mod G */
         uint32_t tx = t % a->tiles_x, ty = t / a->tiles_x;
-        for (uint32_t y = ty * ts; y < (ty + 1) * ts && y < a->s->h; y++)
+        for (uint32_t y = ty * ts + b * band; y < ty * ts + (b + 1) * band && y < (ty + 1) * ts && y < a->s->h; y++)
             for (uint32_t x = tx * ts; x < (tx + 1) * ts && x < a->s->w; x++)
-                render_pixel(a->c, a->s, a->lens, x, y, &a->cnt);
+                render_pixel(a->c, a->s, a->lens, x, y, &cnt);
     }
+    a->cnt = cnt;
     return NULL;
 }
 
