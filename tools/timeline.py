@@ -1,21 +1,26 @@
-"""Timeline of the LAST render in a rocprofv3 --kernel-trace csv: per-kernel time, overlap and idle gaps.
-usage: python tools/timeline.py <kernel_trace.csv> [n_last_dispatches_of_k_shade=11]"""
-import csv, sys
-rows = list(csv.DictReader(open(sys.argv[1])))
-n_last = int(sys.argv[2]) if len(sys.argv) > 2 else 11
-ev = [(int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"].split("(")[0].replace("msne::", "")) for r in rows]
-ev.sort()
-shades = [i for i, e in enumerate(ev) if e[2].startswith("k_shade")]
-first = shades[-n_last]
-# the closest trace of bounce 0 and raygen come right before the first shade
-while first > 0 and (ev[first - 1][2].startswith("k_trace_closest") or ev[first - 1][2].startswith("k_raygen")): first -= 1
-sel = ev[first:]
-t0 = sel[0][0]; t1 = max(e[1] for e in sel)
-print("window %.3f ms, %d dispatches" % ((t1 - t0) / 1e6, len(sel)))
-busy = 0; cur_s, cur_e = sel[0][0], sel[0][1]
-for s, e, _ in sel[1:]:
-    if s > cur_e: busy += cur_e - cur_s; cur_s, cur_e = s, e
-    else: cur_e = max(cur_e, e)
-busy += cur_e - cur_s
-print("some kernel resident %.3f ms, idle gaps %.3f ms" % (busy / 1e6, (t1 - t0 - busy) / 1e6))
-for s, e, n in sel: print("%9.3f %9.3f %8.3f  %s" % ((s - t0) / 1e6, (e - t0) / 1e6, (e - s) / 1e6, n))
+"""Kernel timeline of the last batch in a rocprofv3 --kernel-trace CSV, with the rays of each trace launch when a bounce profile is given:
+    rocprofv3 --kernel-trace --output-format csv -d DIR -o p -- python3 tools/bounce_profile.py s1 64 8 > DIR/bounce.txt
+    python tools/timeline.py DIR/p_kernel_trace.csv [DIR/bounce.txt]"""
+import csv, re, sys
+rows = [r for r in csv.DictReader(open(sys.argv[1])) if "msne" in r["Kernel_Name"]]
+rows.sort(key=lambda r: int(r["Start_Timestamp"]))
+start = [i for i, r in enumerate(rows) if "k_raygen" in r["Kernel_Name"]][-1]
+paths, shadow = {}, {}
+if len(sys.argv) > 2:
+    for line in open(sys.argv[2]):
+        m = re.match(r"bounce\s+(\d+): paths\s+(\d+) \(no ray\s+(\d+)\)\s+shadow entries\s+(\d+) traced\s+(\d+)", line)
+        if m:
+            b = int(m.group(1)); paths[b] = int(m.group(2)) - int(m.group(3)); shadow[b] = int(m.group(5))
+t0 = int(rows[start]["Start_Timestamp"])
+nb = {"k_trace_closest": 0, "k_trace_shadow": 1, "k_shade": 0}
+prev_end = t0
+for r in rows[start:]:
+    name = r["Kernel_Name"].split("(")[0].replace("void ", "").replace("msne::", "").split("<")[0]
+    s, e = (int(r["Start_Timestamp"]) - t0) / 1e6, (int(r["End_Timestamp"]) - t0) / 1e6
+    extra = ""
+    if name in nb:
+        b = nb[name]; nb[name] += 1
+        n = paths.get(b) if name != "k_trace_shadow" else shadow.get(b)
+        if n:
+            extra = "  bounce %2d  %10d units  %7.2f G/s" % (b, n, n / (e - s) / 1e6)
+    print("%-18s %8.3f -> %8.3f  dur %7.3f%s" % (name, s, e, e - s, extra))
