@@ -528,3 +528,74 @@ def test_oracle_material_furnaces(orc):
 @pytest.mark.gpu
 def test_hip_material_furnaces(gpu_api):
     run_furnace(lambda: gpu_api.Context())
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# (5) direct lighting against quadrature: a Lambert floor under (a) an emissive quad sampled as a mesh light, (b) the sky+sun environment.
+# With max_bounces = 0 a path is: camera -> floor (light sample with MIS) -> BSDF-sampled ray (emission / environment with the
+# complementary MIS weight) -> end (integrator.hlsl:108-135,168-181), i.e. exactly the direct lighting, whose expectation is
+# rho / pi * integral of L cos(theta) dw — computed here by plain quadrature over the emitter's area / the environment's texels.
+def direct_light_scene(ctx, kind, extent=(24, 24)):
+    normal = ctx.solid_texture(0.5, 0.5); black = ctx.solid_texture(0.0, 0.0, 0.0)
+    floor = ctx.create_material(scenes.LAMBERT, normal, black, color=ctx.solid_texture(0.6, 0.5, 0.4))
+    P, I = scenes.quad((-40, -40, 0), (40, -40, 0), (40, 40, 0), (-40, 40, 0))
+    ctx.create_instance([(ctx.create_mesh(P, I), floor, False)])
+    if kind == "mesh":
+        # a 1 x 2 emitter 1.5 above the floor, facing down, tilted copies would break the closed form: kept parallel, offset from the view centre
+        lP, lI = scenes.quad((0.3, -0.2, 1.5), (0.3, 1.8, 1.5), (1.3, 1.8, 1.5), (1.3, -0.2, 1.5))      # cross(p0-p2, p1-p2) points down (-z)
+        emitter = ctx.create_material(scenes.LAMBERT, normal, ctx.solid_texture(7.0, 5.0, 3.0), color=black)
+        ctx.create_instance([(ctx.create_mesh(lP, lI), emitter, True)])
+        ctx.set_background(np.array([0, 0, 0, 1], np.float32), 1, 1)
+    else:
+        img = scenes.sky_sun_equirect()
+        ctx.set_background(img, img.shape[1], img.shape[0])
+    # a narrow lens straight down at the floor point (0.5, 0.4, 0): every pixel sees (nearly) the same irradiance
+    lens = ctx.create_lens(ctx.make_lens(origin=(0.5, 0.4, 0.9), forward=(0, 0, -1), up=(0, 1, 0), vfov=0.02))
+    return ctx.create_sensor(*extent), lens
+
+
+def run_direct_lighting(make_ctx):
+    rho = np.array([0.6, 0.5, 0.4])
+    x0 = np.array([0.5, 0.4, 0.0])
+    # (a) emissive quad: E = Le * integral over the quad of cos(theta_floor) cos(theta_light) / r^2 dA
+    n = 2000
+    ax = 0.3 + (np.arange(n) + 0.5) / n * 1.0; ay = -0.2 + (np.arange(n) + 0.5) / n * 2.0
+    AX, AY = np.meshgrid(ax, ay, indexing="ij")
+    d = np.stack([AX - x0[0], AY - x0[1], np.full_like(AX, 1.5)], -1)
+    r2 = (d * d).sum(-1)
+    form = ((1.5 * 1.5) / (r2 * r2)).sum() * (1.0 / n) * (2.0 / n)          # cos cos' / r^2 with cos = cos' = 1.5 / r
+    want_mesh = rho / math.pi * np.array([7.0, 5.0, 3.0]) * form
+    for nee in ((0, 1), (0, 0), (0, 4)):                                       # MIS with one light sample, no light sampling at all, four light samples
+        c = make_ctx()
+        s, l = direct_light_scene(c, "mesh")
+        c.set_pipeline(samples_per_run=1, max_bounces=0, env_samples_per_bounce=nee[0], mesh_samples_per_bounce=nee[1])
+        c.render(s, l, launches=2048 if nee[1] else 16384)
+        got = c.sensor_data(s)[..., :3].astype(np.float64).reshape(-1, 3).mean(0)
+        assert np.abs(got / want_mesh - 1).max() < (0.01 if nee[1] else 0.03), "mesh-light direct lighting, %d light samples: %s, quadrature %s" % (nee[1], got, want_mesh)
+    # (b) environment: E = sum over the equal-area map's texels of L cos(theta)+ * 4 pi / S^2 (the map the renderer samples, built by its own pre-pass)
+    c = make_ctx()
+    s, l = direct_light_scene(c, "env")
+    rgb, lum = c.env()
+    S = rgb.shape[0]
+    centres = (np.stack(np.meshgrid(np.arange(S), np.arange(S), indexing="xy"), -1).reshape(-1, 2) + 0.5) / S
+    dirs = ss.square_to_equal_area_sphere(centres)
+    L = np.asarray(rgb, np.float64)[..., :3].reshape(-1, 3)                    # texel (x, y) -> row y, column x: the same order as `centres`
+    E = (L * np.maximum(dirs[:, 2:3], 0.0)).sum(0) * 4 * math.pi / (S * S)
+    want_env = rho / math.pi * E
+    for env_n in (1, 0):
+        c = make_ctx()
+        s, l = direct_light_scene(c, "env")
+        c.set_pipeline(samples_per_run=1, max_bounces=0, env_samples_per_bounce=env_n, mesh_samples_per_bounce=0)
+        c.render(s, l, launches=4096 if env_n else 16384)
+        got = c.sensor_data(s)[..., :3].astype(np.float64).reshape(-1, 3).mean(0)
+        # point lookups (NEE / eval) against the bilinear lookup of incomingRadiance, and a 2e-3-steradian sun on a 256^2 map: 3 %
+        assert np.abs(got / want_env - 1).max() < 0.03, "environment direct lighting, %d env samples: %s, quadrature %s" % (env_n, got, want_env)
+
+
+def test_oracle_direct_lighting_matches_quadrature(orc):
+    run_direct_lighting(lambda: orc.Context(threads=os.cpu_count() or 1))
+
+
+@pytest.mark.gpu
+def test_hip_direct_lighting_matches_quadrature(gpu_api):
+    run_direct_lighting(lambda: gpu_api.Context())
