@@ -36,13 +36,31 @@ def build_scene(ctx, a):
     return scenes.s1(ctx, extent=(a.width, a.height), env=a.env)
 
 
+def usable_cores():
+    """hardware threads this process may actually use: the affinity mask, capped by the cgroup CPU quota (the GPU boxes show 256 logical
+    CPUs under a 16-CPU quota: 256 runnable threads there are throttled to 16 CPUs' worth of time)"""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except Exception:
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read()); p_ = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                n = min(n, max(1, q // p_))
+        except Exception:
+            pass
+    return n
+
+
 def cpu_baseline(a):
     """The oracle (a scalar C restatement, kind="port") timed on this host's cores on a bounded sample of the same
     workload (about 10-30 s of CPU work): all hardware threads at full resolution, and ONE thread at 480x270 (SURVEY.md
     §8(d) asks for both).  Reported baseline only — never the product path."""
     from oracle import orc
     orc.build()
-    cores = os.cpu_count() or 1
+    cores = usable_cores()
 
     def run(threads, W, H, spp):
         c = orc.Context(threads=threads)
@@ -56,7 +74,7 @@ def cpu_baseline(a):
         k = c.counters()
         return k["closest_rays"] + k["shadow_rays"], k["samples"], dt
 
-    W, H, SPP = a.width, a.height, 16 if cores >= 64 else 1
+    W, H, SPP = a.width, a.height, 16 if cores >= 64 else (4 if cores >= 12 else 1)
     rays, samples, dt = run(cores, W, H, SPP)
     rays1, samples1, dt1 = run(1, 480, 270, 1)
     return {"value": rays / dt / 1e6, "unit": "Mrays/s", "cores": cores, "kind": "port",
