@@ -145,7 +145,7 @@ struct HdMoonshine {
     // long the overlap buys nothing (S1 x 64 launches: 108.5 ms overlapped, 108.8 ms in stream order) and only blurs per-kernel timings;
     // it pays in the thin tails of a batch, where neither kernel fills the chip.  $MSNE_SERIAL: 1 = always in stream order, 0 = always
     // overlapped, unset = in stream order for the first `serial_bounces` bounces of batches of at least `serial_min_paths` paths.
-    int serial_mode = -1; uint32_t serial_bounces = 4; size_t serial_min_paths = 64u << 20;   // (an 8-way shard of the benchmark frame, 16.7 M paths: 16.6 ms overlapped, 17.6 ms in stream order)
+    int serial_mode = -1; uint32_t serial_bounces = 4; size_t serial_min_paths = 96u << 20;   // (overlap is worth 2.5 % on a 2-way shard = 67 M paths, 3.6 % at 20 launches = 41 M, 6 % on an 8-way shard)
     int n_pipes = 1;                               // $MSNE_PIPES (measured on S1: more pipes never won — bigger batches beat overlapped smaller ones)
     size_t single_pipe_paths = 48u << 20;          // batches at least this large run on one pipe (tails are negligible there)
     DevBuf<float4> d_lbuf;
