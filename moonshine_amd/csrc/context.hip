@@ -1000,6 +1000,10 @@ int MsneShadeProbe(HdMoonshine* c, int fn, const float* in, uint32_t n, float* o
     uint32_t win = 0, wout = 0;
     if (!c->bind() || !in || !out || !shade_probe_widths(fn, win, wout)) { c->fail("shade probe: bad arguments"); return -1; }
     if (n == 0) return 0;
+    if (fn == 17) {   // texture probe: the scene's textures must be on the device, and every index must name one
+        if (c->textures_dirty && !c->upload_textures()) return -1;
+        for (uint32_t i = 0; i < n; i++) if (!(in[3 * (size_t)i] >= 0.0f && in[3 * (size_t)i] < (float)c->textures.size())) { c->fail("shade probe: unknown texture"); return -1; }
+    }
     DevBuf<float> di, dout;
     if (!di.alloc((size_t)n * win) || !dout.alloc((size_t)n * wout)) { c->fail("out of device memory (probe)"); return -1; }
     if (hipMemcpyAsync(di.p, in, (size_t)n * win * 4, hipMemcpyHostToDevice, c->stream) != hipSuccess) return -1;

@@ -405,8 +405,8 @@ __global__ __launch_bounds__(SHADE_BLOCK) void k_unpack_film(ShardView sh, const
 
 // Batch probe of the shading functions for parity tests (MsneShadeProbe): the SAME device functions k_shade runs, one record
 // per thread.  The table (function codes, record widths) is the test oracle's OrcProbeBatch.
-__constant__ uint32_t c_probe_in[17]  = { 15, 2, 3, 3, 2, 3, 2, 2, 2, 3, 6, 3, 12, 7, 7, 4, 9 };
-__constant__ uint32_t c_probe_out[17] = {  8, 7, 4, 3, 3, 2, 2, 2, 3, 1, 3, 6,  1, 3, 3, 1, 6 };
+__constant__ uint32_t c_probe_in[18]  = { 15, 2, 3, 3, 2, 3, 2, 2, 2, 3, 6, 3, 12, 7, 7, 4, 9, 3 };
+__constant__ uint32_t c_probe_out[18] = {  8, 7, 4, 3, 3, 2, 2, 2, 3, 1, 3, 6,  1, 3, 3, 1, 6, 4 };
 __global__ void k_shade_probe(SceneView sc, int fn, const float* in, uint32_t n, float* out) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
@@ -437,11 +437,12 @@ __global__ void k_shade_probe(SceneView sc, int fn, const float* in, uint32_t n,
         case 16: { Frame f; f.n = F3(a[0], a[1], a[2]); f.s = F3(a[3], a[4], a[5]); f.t = F3(0.0f, 0.0f, 0.0f); frame_reorthogonalize(f);
                    const f3 p = frame_world_to_frame(f, F3(a[6], a[7], a[8])), q = frame_frame_to_world(f, F3(a[6], a[7], a[8]));
                    o[0] = p.x; o[1] = p.y; o[2] = p.z; o[3] = q.x; o[4] = q.y; o[5] = q.z; break; }
+        case 17: { const float4 t = tex_sample(sc, (uint32_t)a[0], F2(a[1], a[2])); o[0] = t.x; o[1] = t.y; o[2] = t.z; o[3] = t.w; break; }   // (the caller checked the index)
     }
 }
 bool shade_probe_widths(int fn, uint32_t& win, uint32_t& wout) {
-    static const uint32_t pin[17]  = { 15, 2, 3, 3, 2, 3, 2, 2, 2, 3, 6, 3, 12, 7, 7, 4, 9 }, pout[17] = { 8, 7, 4, 3, 3, 2, 2, 2, 3, 1, 3, 6, 1, 3, 3, 1, 6 };
-    if (fn < 0 || fn > 16) return false;
+    static const uint32_t pin[18]  = { 15, 2, 3, 3, 2, 3, 2, 2, 2, 3, 6, 3, 12, 7, 7, 4, 9, 3 }, pout[18] = { 8, 7, 4, 3, 3, 2, 2, 2, 3, 1, 3, 6, 1, 3, 3, 1, 6, 4 };
+    if (fn < 0 || fn > 17) return false;
     win = pin[fn]; wout = pout[fn]; return true;
 }
 void launch_shade_probe(hipStream_t s, const SceneView& sc, int fn, const float* in, uint32_t n, float* out) {

@@ -576,11 +576,12 @@ void OrcBsdfProbe(uint32_t type, const float params[6], const float wi[3], const
  * 12 areaMeasureToSolidAngleMeasure {pos1, pos2, dir1, dir2} -> {x}
  * 13 GGX {alpha, a xyz, b xyz} -> {D(a), Lambda(a), G(a, b)}
  * 14 refractDir {wi, n, eta} -> {dir}              15 powerHeuristic {numf, fPdf, numg, gPdf} -> {w}
- * 16 Frame: {n xyz, s xyz, v xyz} -> reorthogonalize(n, s) then {worldToFrame(v), frameToWorld(v)} */
-static const uint32_t PROBE_IN[17]  = { 15, 2, 3, 3, 2, 3, 2, 2, 2, 3, 6, 3, 12, 7, 7, 4, 9 };
-static const uint32_t PROBE_OUT[17] = {  8, 7, 4, 3, 3, 2, 2, 2, 3, 1, 3, 6,  1, 3, 3, 1, 6 };
+ * 16 Frame: {n xyz, s xyz, v xyz} -> reorthogonalize(n, s) then {worldToFrame(v), frameToWorld(v)}
+ * 17 dTextures[i].SampleLevel(dTextureSampler, uv, 0) {texture index, u, v} -> {rgba}   (context textures; linear, repeat) */
+static const uint32_t PROBE_IN[18]  = { 15, 2, 3, 3, 2, 3, 2, 2, 2, 3, 6, 3, 12, 7, 7, 4, 9, 3 };
+static const uint32_t PROBE_OUT[18] = {  8, 7, 4, 3, 3, 2, 2, 2, 3, 1, 3, 6,  1, 3, 3, 1, 6, 4 };
 int OrcProbeBatch(OrcContext *c, int fn, const float *in, uint32_t n, float *out) {
-    if (fn < 0 || fn > 16) return -1;
+    if (fn < 0 || fn > 17) return -1;
     orc_counters cnt; memset(&cnt, 0, sizeof cnt);
     for (uint32_t i = 0; i < n; i++) {
         const float *a = in + (size_t)i * PROBE_IN[fn]; float *o = out + (size_t)i * PROBE_OUT[fn];
@@ -605,6 +606,7 @@ int OrcProbeBatch(OrcContext *c, int fn, const float *in, uint32_t n, float *out
             case 16: { orc_frame f; f.n = V3(a[0], a[1], a[2]); f.s = V3(a[3], a[4], a[5]); f.t = V3(0, 0, 0); frame_reorthogonalize(&f);
                        v3 p = frame_world_to_frame(&f, V3(a[6], a[7], a[8])), q = frame_frame_to_world(&f, V3(a[6], a[7], a[8]));
                        o[0] = p.x; o[1] = p.y; o[2] = p.z; o[3] = q.x; o[4] = q.y; o[5] = q.z; break; }
+            case 17: { uint32_t t = (uint32_t)a[0]; if (!c || t >= c->texture_count) return -1; tex_sample_bilinear(&c->textures[t], a[1], a[2], 0, o); break; }
         }
     }
     return 0;

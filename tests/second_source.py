@@ -21,7 +21,7 @@ GLASS, LAMBERT, PERFECT_MIRROR, STANDARD_PBR = 0, 1, 2, 3   # world.hlsl:31-36 M
 PROBES = {"bsdf": (0, 15, 8), "env_sample": (1, 2, 7), "env_eval": (2, 3, 4), "env_incoming": (3, 3, 3), "equal_area": (4, 2, 3),
           "equal_area_inverse": (5, 3, 2), "triangle": (6, 2, 2), "gaussian": (7, 2, 2), "cosine_hemisphere": (8, 2, 3),
           "fresnel_dielectric": (9, 3, 1), "offset_along_normal": (10, 6, 3), "coordinate_system": (11, 3, 6),
-          "area_to_solid_angle": (12, 12, 1), "ggx": (13, 7, 3), "refract": (14, 7, 3), "power_heuristic": (15, 4, 1), "frame": (16, 9, 6)}
+          "area_to_solid_angle": (12, 12, 1), "ggx": (13, 7, 3), "refract": (14, 7, 3), "power_heuristic": (15, 4, 1), "frame": (16, 9, 6), "texture": (17, 3, 4)}
 
 
 DTYPE = np.float64
@@ -427,6 +427,32 @@ class EnvMap:
         idx = np.clip(np.trunc(uv * s).astype(np.int64), 0, s)
         discrete = self.load(idx[..., 0], idx[..., 1], 0) * float(s * s) / self.integral()
         return self.load_rgb(idx[..., 0], idx[..., 1]), discrete / (4.0 * PI)
+
+
+# ------------------------------------------------------------------ image.SampleLevel(sampler, uv, 0)
+# Written from the Vulkan specification's texel-coordinate rules ("Texel Coordinate Systems", "Texel Filtering": unnormalised
+# u = s * width, linear filter: i0 = floor(u - 1/2), alpha = frac(u - 1/2), tau = (1-a)(1-b) t00 + a(1-b) t10 + (1-a) b t01 + a b t11;
+# wrapping REPEAT: i mod size, MIRRORED_REPEAT: (size - 1) - mirror((i mod 2 size) - size), mirror(n) = n if n >= 0 else -(1 + n)) —
+# the samplers the reference creates: linear / repeat for material textures (MaterialManager.zig:428-433), linear / mirrored repeat
+# for the background (BackgroundManager.zig:83-85).  Real hardware computes the weights in fixed point (>= 8 fractional bits).
+def vk_wrap(i, size, mirrored):
+    if not mirrored:
+        return np.mod(i, size)
+    n = np.mod(i, 2 * size) - size
+    return (size - 1) - np.where(n >= 0, n, -(1 + n))
+
+
+def vk_sample_linear(img, uv, mirrored=False):
+    img = _a(img); uv = _a(uv)
+    h, w = img.shape[:2]
+    if w == 1 and h == 1:
+        return np.broadcast_to(img[0, 0], uv.shape[:-1] + (img.shape[2],)) + 0.0 * uv[..., :1]
+    u, v = uv[..., 0] * w - 0.5, uv[..., 1] * h - 0.5
+    i0, j0 = np.floor(u), np.floor(v)
+    a, b = (u - i0)[..., None], (v - j0)[..., None]
+    i0, j0 = i0.astype(np.int64), j0.astype(np.int64)
+    x0, x1, y0, y1 = vk_wrap(i0, w, mirrored), vk_wrap(i0 + 1, w, mirrored), vk_wrap(j0, h, mirrored), vk_wrap(j0 + 1, h, mirrored)
+    return (1 - a) * (1 - b) * img[y0, x0] + a * (1 - b) * img[y0, x1] + (1 - a) * b * img[y1, x0] + a * b * img[y1, x1]
 
 
 def fold_pyramid(level0):
