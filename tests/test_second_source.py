@@ -41,11 +41,6 @@ def unit_vectors(rs, n, grazing=0.15):
     return v.astype(np.float32)
 
 
-def make_env(api_ctx_cls=None):
-    """the sky+sun environment of SURVEY.md 8(d), 512x256 equirect -> 256^2 equal-area map"""
-    return scenes.sky_sun_equirect()
-
-
 def inputs(name, rs, n=N):
     f = np.float32
     if name == "bsdf":
@@ -201,8 +196,6 @@ def near_decision(name, x):
         c = np.clip(x[:, 0], -1, 1)
         ei, et = np.where(c > 0, x[:, 1], x[:, 2]), np.where(c > 0, x[:, 2], x[:, 1])
         bad |= np.abs(ei / et * np.sqrt(np.maximum(0, 1 - c * c)) - 1) < 1e-5
-    if name == "equal_area_inverse" or name in ("env_eval", "env_incoming"):
-        bad |= (np.abs(np.abs(x[:, 0]) - np.abs(x[:, 1])) < 1e-6) & False     # (continuous across the diagonal: nothing to exclude)
     if name == "coordinate_system":
         bad |= np.abs(np.abs(x[:, 0]) - np.abs(x[:, 1])) < 1e-6
     return bad
@@ -231,13 +224,8 @@ def check_values(name, got, x, env=None, rel=1e-5, images=None):
     skip = near_decision(name, x)
     if name == "env_sample":   # a different texel chosen where a coin flip sits on its threshold
         skip |= (np.abs(got[:, 6] - ref[:, 6]) > 1e-5 * np.abs(ref[:, 6])) & (np.abs(got[:, :3] - ref[:, :3]).max(1) < 3.0 / env.size)
-    if name in ("texture", "env_incoming"):   # floor(u - 1/2) sits on an integer: which texel pair is blended is a rounding matter (the blend is continuous there)
-        if name == "texture":
-            wh = np.array([[img.shape[1], img.shape[0]] for img in images], np.float64)[x[:, 0].astype(int)]
-            uvt = x[:, 1:3].astype(np.float64) * wh - 0.5
-        else:
-            uvt = ss.square_to_equal_area_sphere_inverse(x.astype(np.float64)) * env.size - 0.5
-        skip |= (np.abs(uvt - np.round(uvt)) < 2e-4).any(1) & False      # (continuous: nothing to exclude; kept for the record)
+    # ("texture" / "env_incoming": where floor(u - 1/2) sits on an integer the texel pair that is blended is a rounding matter, but the blend is
+    #  continuous there: nothing to exclude)
     if name in ("env_eval",):    # the direction falls on a texel border of the equal-area map
         uv = ss.square_to_equal_area_sphere_inverse(x.astype(np.float64)) * env.size
         skip |= (np.abs(uv - np.round(uv)) < 2e-4).any(1)
