@@ -16,9 +16,11 @@
 //  * every leaf holds one triangle; the hit leaves of a node form a triangle group {item base, hit bits | leaf mask}, two
 //    of which can wait per lane: node traversal runs ahead of the triangle tests (one per iteration), so both bodies
 //    run with more lanes; a node visited with a not yet shortened ray costs a few extra visits, never a wrong result;
-//  * entering and leaving an instance share one "space body" (reload the world-space ray, transform, shear constants) that a
-//    wave runs when SPACE_MIN_LANES lanes wait for it or nothing else can be done; the BLAS root is visited, and the TLAS group
-//    below the sentinel popped, in the iteration after.  Scenes without a TLAS level run an instantiation without any of it.
+//  * entering an instance (reload the world-space direction, transform, shear constants) is a "space body" that a wave runs when
+//    SPACE_MIN_LANES lanes wait for it or nothing else can be done; the lane puts the world-space half of its ray (origin, reciprocal
+//    direction, octant: 7 registers) aside and takes it back inline when it pops the instance's sentinel — leaving costs no body and no
+//    wait.  The two-level instantiations run 5 waves per SIMD (96 registers) for that; scenes without a TLAS level run an
+//    instantiation without any of it at 6 waves per SIMD (80 registers).
 // Box tests use fmaf and a relative slack (they only gate which triangles are tested); the triangle test is
 // the watertight Woop–Benthin–Wald test evaluated op-for-op like the test oracle, and equal-t ties resolve
 // to the smallest (instance, geometry, primitive), so results do not depend on BVH shape or visit order.
@@ -29,6 +31,9 @@ namespace msne {
 constexpr int TRACE_BLOCK = 256;
 #ifndef TRACE_WPS
 #define TRACE_WPS 6          // resident waves per SIMD the trace kernels are register-allocated for (= blocks of 256 per CU)
+#endif
+#ifndef TRACE_WPS_TLAS
+#define TRACE_WPS_TLAS 5     // two-level scenes: one wave per SIMD less buys 96 registers — room for the world-space half of the ray a lane keeps while inside an instance
 #endif
 #ifndef TRACE_SPACE_MIN_LANES
 #define TRACE_SPACE_MIN_LANES 16   // lanes that must wait for a change of space (instance entry / exit) before the wave runs that body
@@ -101,6 +106,7 @@ struct Lane {
     int sp, sb;        // stack entries live in rows [sb, sp): sb moves up when the bottom entry is handed to an idle lane (launch tails)
     uint32_t own;      // closest-hit tails: bits 0..5 = the lane that owns this ray (itself unless this lane searches a handed-over piece), bits 8.. = pieces still out
     bool in_blas;
+    f3 wo, wid; uint32_t woct;   // two-level scenes: the world-space origin / reciprocal direction / octant, put aside while the lane is inside an instance
 };
 
 struct StackRef { uint32_t* lds; uint32_t* spill; uint32_t spill_stride; uint32_t* overflow; };
@@ -325,8 +331,8 @@ __device__ __forceinline__ void trace_wave_loop(const SceneView& sc, uint32_t n,
                 lane_pop(L, S);
                 if (__builtin_expect((L.g1 & GRP_KIND_MASK) == GRP_SENTINEL, 0)) {   // leaving an instance: back to the world-space ray
                     if (has_t) { L.sp++; L.g1 = 0u; }   // ... but only once the triangles queued in instance space are done: un-pop
-                    else if (L.g0 & 1u) L.g1 = GRP_SENTINEL | 1u;   // the world-space ray has to be restored: in the space body of (c), with the lanes that enter instances
                     else {
+                        if (L.g0 & 1u) { L.o = L.wo; L.id = L.wid; L.octbase = L.woct; }   // back to the world-space ray kept aside at entry (the shear constants stay stale: every entry recomputes them)
                         L.in_blas = false; L.g1 = 0u;
                         if (L.sp == L.sb) { if (ANY_HIT || L.own == lane) { store(my, L); active = false; } }   // (sentinels only exist on owners' own stacks below sb... see (b'))
                         else lane_pop(L, S);   // what lies under a sentinel is a TLAS-level group (two levels only), never another sentinel
@@ -425,7 +431,7 @@ __device__ __forceinline__ void trace_wave_loop(const SceneView& sc, uint32_t n,
         const bool want_t = active && (L.ta1 & 0xffu);
         const bool has_g = active && (L.g1 & 0xffu);
         const bool want_n = has_g && (!INSTANCED || (L.g1 & GRP_KIND_MASK) == GRP_NODE) && !(L.tb1 & 0xffu);
-        const bool want_s = INSTANCED && has_g && (L.g1 & GRP_KIND_MASK) != GRP_NODE;   // enters an instance (GRP_INST) or leaves one (GRP_SENTINEL | 1): the ray changes space
+        const bool want_s = INSTANCED && has_g && (L.g1 & GRP_KIND_MASK) == GRP_INST;   // enters an instance: the ray changes space
         const bool do_n = __ballot(want_n) != 0ull, do_t = __ballot(want_t) != 0ull;
         // Changing space costs ~250 instructions (reload the world-space ray, transform, three IEEE divisions for the shear constants)
         // and few lanes need it in any one iteration: entering and leaving share one body, and it runs when enough lanes wait for
@@ -433,33 +439,24 @@ __device__ __forceinline__ void trace_wave_loop(const SceneView& sc, uint32_t n,
         const unsigned long long ms = INSTANCED ? __ballot(want_s) : 0ull;
         const bool do_s = INSTANCED && ms != 0ull && ((uint32_t)__popcll(ms) >= SPACE_MIN_LANES || (!do_n && !do_t));
         if (STATS && do_s) cyc[2] += __popcll(ms);   // lanes that change space (slot 2 of the profile: the vote itself is timed with the node section)
-        if (INSTANCED && do_s && want_s) {
-            const bool enter = (L.g1 & GRP_KIND_MASK) == GRP_INST;
-            bool need_ray = !enter;
+        if (INSTANCED && do_s && want_s) {   // entering an instance (leaving needs no body: the world-space half of the lane's ray was put aside)
             uint32_t root = MAX_UINT, new_inst = 0u;
-            float4 r0 = make_float4(1.0f, 0.0f, 0.0f, 0.0f), r1 = make_float4(0.0f, 1.0f, 0.0f, 0.0f), r2 = make_float4(0.0f, 0.0f, 1.0f, 0.0f);
-            if (enter) {   // TLAS leaf (one instance of the group; the rest of the group goes back on the stack)
-                const uint32_t item = group_take(L, S, lut);
-                const uint32_t ii = sc.tlas_items[item];
-                const InstanceRec* ir = sc.instances + ii;
-                const uint32_t flags = ir->flags;
-                root = ir->blas_root;
-                if (!(flags & INST_FLAG_VISIBLE)) root = MAX_UINT;
-                new_inst = (flags & INST_FLAG_WORLD) ? WORLD_INSTANCE : ii;
-                if (root != MAX_UINT) {
-                    if (flags & INST_FLAG_IDENTITY) lane_push(L, S, 0u, GRP_SENTINEL);   // M·(o,1) = o and M·d = d exactly: the ray is left as is
-                    else {
-                        const float4* mp = reinterpret_cast<const float4*>(&ir->world_to_instance);
-                        r0 = mp[0]; r1 = mp[1]; r2 = mp[2];
-                        lane_push(L, S, 1u, GRP_SENTINEL);
-                        need_ray = true;
-                    }
-                }
-            }
-            if (need_ray) {   // the world-space ray is not kept in registers
+            const uint32_t item = group_take(L, S, lut);   // TLAS leaf (one instance of the group; the rest of the group goes back on the stack)
+            const uint32_t ii = sc.tlas_items[item];
+            const InstanceRec* ir = sc.instances + ii;
+            const uint32_t flags = ir->flags;
+            root = ir->blas_root;
+            if (!(flags & INST_FLAG_VISIBLE)) root = MAX_UINT;
+            new_inst = (flags & INST_FLAG_WORLD) ? WORLD_INSTANCE : ii;
+            if (root != MAX_UINT) {
+                const bool ident = (flags & INST_FLAG_IDENTITY) != 0u;
+                const float4* mp = reinterpret_cast<const float4*>(&ir->world_to_instance);
+                const float4 r0 = mp[0], r1 = mp[1], r2 = mp[2];
                 f3 o, d; float tmax;
-                (void)load(my, o, d, tmax);
-                if (enter) {   // t is preserved: d is not renormalised
+                (void)load(my, o, d, tmax);   // the world-space direction is not kept in registers
+                L.wo = L.o; L.wid = L.id; L.woct = L.octbase;
+                lane_push(L, S, 1u, GRP_SENTINEL);
+                if (!ident) {   // t is preserved: d is not renormalised.  (Identity: M·(o,1) = o and M·d = d exactly — only the shear constants are recomputed)
                     m34 M;
                     M.m[0][0] = r0.x; M.m[0][1] = r0.y; M.m[0][2] = r0.z; M.m[0][3] = r0.w;
                     M.m[1][0] = r1.x; M.m[1][1] = r1.y; M.m[1][2] = r1.z; M.m[1][3] = r1.w;
@@ -468,12 +465,7 @@ __device__ __forceinline__ void trace_wave_loop(const SceneView& sc, uint32_t n,
                     o = oi; d = di;
                 }
                 lane_set_space(L, o, d);
-            }
-            if (enter) {
-                if (root != MAX_UINT) { L.in_blas = true; L.cur_inst = new_inst; L.g0 = root; L.g1 = GRP_NODE | 0x0101u; }   // a group of one: the BLAS root
-            } else {   // back in world space: take the TLAS group under the sentinel right away (a ray with nothing left is finished in (a))
-                L.in_blas = false; L.g1 = 0u;
-                if (L.sp != L.sb) lane_pop(L, S);   // a TLAS-level group (two levels only), never another sentinel
+                L.in_blas = true; L.cur_inst = new_inst; L.g0 = root; L.g1 = GRP_NODE | 0x0101u;   // a group of one: the BLAS root
             }
         }
         // lanes that just entered hold their BLAS root, lanes that just left hold a TLAS group: they visit it in this iteration
@@ -504,7 +496,7 @@ __device__ __forceinline__ void trace_wave_loop(const SceneView& sc, uint32_t n,
     order_table_init(lds_lut)
 
 template <bool STATS, bool INSTANCED>
-__global__ __launch_bounds__(TRACE_BLOCK, TRACE_WPS) void k_trace_closest(SceneView sc, PathState st, HitBuf hits, BounceCounters* cnt,
+__global__ __launch_bounds__(TRACE_BLOCK, INSTANCED ? TRACE_WPS_TLAS : TRACE_WPS) void k_trace_closest(SceneView sc, PathState st, HitBuf hits, BounceCounters* cnt,
                                                                 uint32_t* spill, uint32_t* overflow, unsigned long long* stat_out, uint32_t refill) {
     TRACE_LDS_DECL;
     const uint32_t n = cnt->n_paths;
@@ -524,7 +516,7 @@ __global__ __launch_bounds__(TRACE_BLOCK, TRACE_WPS) void k_trace_closest(SceneV
 }
 
 template <bool STATS, bool INSTANCED>
-__global__ __launch_bounds__(TRACE_BLOCK, TRACE_WPS) void k_trace_shadow(SceneView sc, ShadowQueue q, BounceCounters* cnt,
+__global__ __launch_bounds__(TRACE_BLOCK, INSTANCED ? TRACE_WPS_TLAS : TRACE_WPS) void k_trace_shadow(SceneView sc, ShadowQueue q, BounceCounters* cnt,
                                                                uint32_t* spill, uint32_t* overflow, unsigned long long* stat_out, uint32_t refill) {
     TRACE_LDS_DECL;
     const uint32_t n = cnt->n_shadow_in;
@@ -545,7 +537,7 @@ __global__ __launch_bounds__(TRACE_BLOCK, TRACE_WPS) void k_trace_shadow(SceneVi
 
 // probe kernel for tests: arbitrary rays → hit records (closest) or occlusion flags (any)
 template <bool ANY_HIT>
-__global__ __launch_bounds__(TRACE_BLOCK, TRACE_WPS) void k_trace_probe(SceneView sc, const float* rays /*7 per ray: o,d,tmax*/, uint32_t n, uint32_t* head,
+__global__ __launch_bounds__(TRACE_BLOCK, TRACE_WPS_TLAS) void k_trace_probe(SceneView sc, const float* rays /*7 per ray: o,d,tmax*/, uint32_t n, uint32_t* head,
                                                               uint32_t* out_ids /*4 per ray: hit,inst,geo,prim*/, float* out_tuv /*3 per ray*/,
                                                               uint32_t* spill, uint32_t* overflow, uint32_t refill) {
     TRACE_LDS_DECL;
@@ -573,6 +565,7 @@ __global__ __launch_bounds__(TRACE_BLOCK, TRACE_WPS) void k_trace_probe(SceneVie
 void launch_trace_closest(hipStream_t s, int grid, bool stats, const SceneView& sc, const PathState& st, const HitBuf& hits, BounceCounters* cnt,
                           uint32_t* spill, uint32_t* overflow, unsigned long long* stat_out, uint32_t refill) {
     const bool inst = sc.root_in_blas == 0u;   // a TLAS level exists
+    if (inst) grid = grid / TRACE_WPS * TRACE_WPS_TLAS;
     if (stats) { if (inst) hipLaunchKernelGGL((k_trace_closest<true, true>), dim3(grid), dim3(TRACE_BLOCK), 0, s, sc, st, hits, cnt, spill, overflow, stat_out, refill);
                  else hipLaunchKernelGGL((k_trace_closest<true, false>), dim3(grid), dim3(TRACE_BLOCK), 0, s, sc, st, hits, cnt, spill, overflow, stat_out, refill); }
     else { if (inst) hipLaunchKernelGGL((k_trace_closest<false, true>), dim3(grid), dim3(TRACE_BLOCK), 0, s, sc, st, hits, cnt, spill, overflow, stat_out, refill);
@@ -581,6 +574,7 @@ void launch_trace_closest(hipStream_t s, int grid, bool stats, const SceneView& 
 void launch_trace_shadow(hipStream_t s, int grid, bool stats, const SceneView& sc, const ShadowQueue& q, BounceCounters* cnt,
                          uint32_t* spill, uint32_t* overflow, unsigned long long* stat_out, uint32_t refill) {
     const bool inst = sc.root_in_blas == 0u;
+    if (inst) grid = grid / TRACE_WPS * TRACE_WPS_TLAS;
     if (stats) { if (inst) hipLaunchKernelGGL((k_trace_shadow<true, true>), dim3(grid), dim3(TRACE_BLOCK), 0, s, sc, q, cnt, spill, overflow, stat_out, refill);
                  else hipLaunchKernelGGL((k_trace_shadow<true, false>), dim3(grid), dim3(TRACE_BLOCK), 0, s, sc, q, cnt, spill, overflow, stat_out, refill); }
     else { if (inst) hipLaunchKernelGGL((k_trace_shadow<false, true>), dim3(grid), dim3(TRACE_BLOCK), 0, s, sc, q, cnt, spill, overflow, stat_out, refill);
@@ -588,6 +582,7 @@ void launch_trace_shadow(hipStream_t s, int grid, bool stats, const SceneView& s
 }
 void launch_trace_probe(hipStream_t s, int grid, const SceneView& sc, const float* rays, uint32_t n, int any_hit, uint32_t* head, uint32_t* out_ids, float* out_tuv,
                         uint32_t* spill, uint32_t* overflow, uint32_t refill) {
+    grid = grid / TRACE_WPS * TRACE_WPS_TLAS;
     if (any_hit) hipLaunchKernelGGL(k_trace_probe<true>, dim3(grid), dim3(TRACE_BLOCK), 0, s, sc, rays, n, head, out_ids, out_tuv, spill, overflow, refill);
     else hipLaunchKernelGGL(k_trace_probe<false>, dim3(grid), dim3(TRACE_BLOCK), 0, s, sc, rays, n, head, out_ids, out_tuv, spill, overflow, refill);
 }
