@@ -213,13 +213,19 @@ __global__ __launch_bounds__(SHADE_BLOCK, 3) void k_shade(SceneView sc, Pipeline
                 const uint32_t htri = hrec.y;
                 const uint4 pg = s_geo[src];
                 GeometryRec geometry; geometry.mesh = pg.x; geometry.material = pg.y; geometry.sampled = pg.z;
-                attrs = mesh_attributes_world(sc, opts.indexed_attributes != 0, hinst, 0u, 0u, F2(u2f(hrec.z), u2f(hrec.w)), geometry, htri, true);
                 MaterialRec mrec;
                 { const uint4 m0 = s_mat[0][src], m1 = s_mat[1][src];
                   mrec.normal = m0.x; mrec.emissive = m0.y; mrec.type = m0.z; mrec.color = m0.w; mrec.metalness = m1.x; mrec.roughness = m1.y; mrec.ior = u2f(m1.z); mrec.pad = m1.w; }
-                const Frame textureFrame = get_texture_frame(sc, mrec, opts.two_component_normal_texture != 0, attrs.texcoord, attrs.frame);
-                const f3 emissiveLight = tex_sample_rgb(sc, mrec.emissive, attrs.texcoord);
-                material = material_load(sc, mrec, attrs.texcoord);
+                // the material's texture descriptors, all at once and before the attribute fetch below hides their latency (unused slots read the normal map's again)
+                const TexDesc t_normal = sc.textures[mrec.normal], t_emissive = sc.textures[mrec.emissive];
+                const bool has_color = mrec.type == MAT_PBR || mrec.type == MAT_LAMBERT;
+                const TexDesc t_color = sc.textures[has_color ? mrec.color : mrec.normal];
+                const TexDesc t_metal = sc.textures[mrec.type == MAT_PBR ? mrec.metalness : mrec.normal], t_rough = sc.textures[mrec.type == MAT_PBR ? mrec.roughness : mrec.normal];
+                attrs = mesh_attributes_world(sc, opts.indexed_attributes != 0, hinst, 0u, 0u, F2(u2f(hrec.z), u2f(hrec.w)), geometry, htri, true);
+                const Frame textureFrame = get_texture_frame(sc, t_normal, opts.two_component_normal_texture != 0, attrs.texcoord, attrs.frame);
+                const float4 em4 = tex_sample_desc(sc, t_emissive, attrs.texcoord);
+                const f3 emissiveLight = F3(em4.x, em4.y, em4.z);
+                material = material_load_desc(sc, mrec, t_color, t_metal, t_rough, attrs.texcoord);
 
                 const f3 woWs = neg(rayD);
                 const bool frontfacing = dot(attrs.triangleFrame.n, woWs) > 0.0f;

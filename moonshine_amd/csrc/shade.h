@@ -34,6 +34,12 @@ __device__ __forceinline__ float4 tex_sample(const SceneView& sc, uint32_t idx, 
     return sample_bilinear(sc.texels + t.offset, t.w, t.h, uv.x, uv.y, false);
 }
 __device__ __forceinline__ f3 tex_sample_rgb(const SceneView& sc, uint32_t idx, f2 uv) { float4 o = tex_sample(sc, idx, uv); return F3(o.x, o.y, o.z); }
+// the same lookup from a descriptor that is already in registers: k_shade fetches the (up to five) descriptors of a hit's material
+// together, before the first of them is needed, instead of one dependent descriptor -> texel chain after the other
+__device__ __forceinline__ float4 tex_sample_desc(const SceneView& sc, const TexDesc& t, f2 uv) {
+    if (t.w == 1 && t.h == 1) return t.first;
+    return sample_bilinear(sc.texels + t.offset, t.w, t.h, uv.x, uv.y, false);
+}
 
 // ---------------- world.hlsl:86-177 ----------------
 struct Attrs { f3 position; f2 texcoord; Frame triangleFrame, frame; };
@@ -132,6 +138,17 @@ __device__ __forceinline__ Mat material_load(const SceneView& sc, const Material
         const float roughness = tex_sample(sc, m.roughness, uv).x;
         o.alpha = maxf(roughness * roughness, 0.001f);
     } else if (m.type == MAT_LAMBERT) o.color = tex_sample_rgb(sc, m.color, uv);
+    return o;
+}
+// ... with the descriptors of color / metalness / roughness already loaded (same lookups, same order)
+__device__ __forceinline__ Mat material_load_desc(const SceneView& sc, const MaterialRec& m, const TexDesc& tc, const TexDesc& tm, const TexDesc& tr, f2 uv) {
+    Mat o; o.type = m.type; o.color = F3(0.0f, 0.0f, 0.0f); o.metalness = 0.0f; o.alpha = 0.0f; o.ior = m.ior;
+    if (m.type == MAT_PBR) {
+        const float4 c = tex_sample_desc(sc, tc, uv); o.color = F3(c.x, c.y, c.z);
+        o.metalness = tex_sample_desc(sc, tm, uv).x;
+        const float roughness = tex_sample_desc(sc, tr, uv).x;
+        o.alpha = maxf(roughness * roughness, 0.001f);
+    } else if (m.type == MAT_LAMBERT) { const float4 c = tex_sample_desc(sc, tc, uv); o.color = F3(c.x, c.y, c.z); }
     return o;
 }
 // GGX :20-67
@@ -261,8 +278,8 @@ __device__ __forceinline__ MSample material_sample(const Mat& m, f3 wo, f2 sq) {
     return glass_sample(m, wo, sq);
 }
 // material.hlsl:489-522
-__device__ __forceinline__ Frame get_texture_frame(const SceneView& sc, const MaterialRec& m, bool two_component, f2 uv, const Frame& tangentFrame) {
-    const float4 o = tex_sample(sc, m.normal, uv);
+__device__ __forceinline__ Frame get_texture_frame(const SceneView& sc, const TexDesc& normal_desc, bool two_component, f2 uv, const Frame& tangentFrame) {
+    const float4 o = tex_sample_desc(sc, normal_desc, uv);
     f3 nts;
     if (two_component) {
         const float rx = o.x * 2.0f - 1.0f, ry = o.y * 2.0f - 1.0f;
