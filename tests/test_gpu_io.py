@@ -151,3 +151,30 @@ def test_config3_4k_sharded_eight_ways(tmp_path, orc):
     _oracle_tiles(orc, glb, exr, (3840, 2160), 32, (17 * 60 + 28, 25 * 60 + 41, 33 * 60 + 59), film,
                   dict(samples_per_run=1, max_bounces=8, env_samples_per_bounce=1, mesh_samples_per_bounce=1))
     print(r.stdout)
+
+
+def test_offline_cli_progressive_and_sharded(tmp_path, orc):
+    """`offline --progressive` (the online frame loop, headless) and `--devices` (members sharing this box's GPU): frames are reported as a
+    viewer would see them, sampling stops at --max-sample-count, and the EXR equals a plain 6-spp render of the oracle"""
+    glb, exr, out = str(tmp_path / "gallery.glb"), str(tmp_path / "sky.exr"), str(tmp_path / "out.exr")
+    io.write_gallery(glb, exr)
+    exe = os.path.join(ROOT, "moonshine_amd", "offline")
+    r = subprocess.run([exe, glb, exr, out, "--width", "96", "--height", "64", "--max-bounces", "8", "--devices", "0,0,0", "--progressive", "9", "--max-sample-count", "6",
+                        "--present-every", "2"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    frames = [l for l in r.stdout.splitlines() if l.startswith("frame ")]
+    assert [l.split(":")[0] for l in frames] == ["frame 1", "frame 3", "frame 5", "frame 7", "frame 8"]          # every second frame and the last
+    assert [int(l.split(":")[1].split()[0]) for l in frames] == [2, 4, 6, 6, 6]                                  # stops launching at max_sample_count
+    assert "on 3 GPUs (film gather: copy" in r.stdout
+    from moonshine_amd import api
+    got = api.exr_load(out)
+    oc = orc.Context(threads=os.cpu_count())
+    ol, _ = io.oracle_load(orc, oc, glb, exr)
+    s = oc.create_sensor(96, 64)
+    oc.set_pipeline(samples_per_run=1, max_bounces=8, env_samples_per_bounce=1, mesh_samples_per_bounce=1)
+    oc.render(s, ol, launches=6)
+    assert np.array_equal(bits(got[..., :3]), bits(oc.sensor_data(s)[..., :3]))
+    bad = subprocess.run([exe, glb, exr, out, "--gpus", "0"], capture_output=True, text=True, timeout=60)
+    assert bad.returncode == 2 and "--gpus" in bad.stderr
+    bad = subprocess.run([exe, glb, exr, out, "--devices", "0,99"], capture_output=True, text=True, timeout=60)
+    assert bad.returncode == 1 and "does not exist" in bad.stderr
