@@ -34,7 +34,9 @@ __device__ __forceinline__ uint32_t expand_bits10(uint32_t v) {
 // ---------------- primitive boxes ----------------
 // triangles of one BLAS: geometry g -> mesh; prim boxes + source records
 // `geo` = geometry index inside its instance; `inst` = owning instance for triangles of the merged world BLAS (else unused)
-struct BlasGeo { const float* positions; const uint32_t* indices; uint32_t tri_offset, tri_count, geo, inst; };
+// normals / texcoords: the mesh's attribute arrays (attr_count elements; an index beyond them reads as zero — the render refuses such a
+// mesh before any shading) or nullptr; `indexed`: attributes are read by vertex index (glTF) instead of by corner 3 * prim + k (Hydra)
+struct BlasGeo { const float* positions; const uint32_t* indices; uint32_t tri_offset, tri_count, geo, inst; const float* normals; const float* texcoords; uint32_t indexed, attr_count; };
 
 // geometry that owns triangle i of the concatenated list (tri_offset ascending): binary search — a world BLAS can merge 10^5 geometries
 __device__ __forceinline__ uint32_t geo_of(const BlasGeo* geos, uint32_t ngeo, uint32_t i) {
@@ -406,7 +408,7 @@ __global__ void k_collapse(const CollapseWork* work, uint32_t nwork, CollapseWor
     nodes[widx] = nd;
 }
 
-__global__ void k_emit_tris(const BlasGeo* geos, uint32_t ngeo, const uint32_t* item_src, uint32_t item_begin, uint32_t n, TriRec* tris) {
+__global__ void k_emit_tris(const BlasGeo* geos, uint32_t ngeo, const uint32_t* item_src, uint32_t item_begin, uint32_t n, TriRec* tris, TriAttr* attrs) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const uint32_t src = item_src[item_begin + i];
@@ -420,6 +422,24 @@ __global__ void k_emit_tris(const BlasGeo* geos, uint32_t ngeo, const uint32_t* 
     r.v2x = P[3 * (size_t)i2]; r.v2y = P[3 * (size_t)i2 + 1]; r.v2z = P[3 * (size_t)i2 + 2];
     r.geo = ge.geo; r.prim = p; r.pad = ge.inst;
     tris[item_begin + i] = r;
+    if (attrs && (ge.normals || ge.texcoords)) {   // world.hlsl:127-149: attribute indices and the texcoords a mesh without any gets
+        const uint32_t a0 = ge.indexed ? i0 : 3 * p, a1 = ge.indexed ? i1 : 3 * p + 1, a2 = ge.indexed ? i2 : 3 * p + 2;
+        TriAttr t;
+        t.n0x = t.n0y = t.n0z = t.n1x = t.n1y = t.n1z = t.n2x = t.n2y = t.n2z = 0.0f;
+        t.t0x = 0.0f; t.t0y = 0.0f; t.t1x = 1.0f; t.t1y = 0.0f; t.t2x = 1.0f; t.t2y = 1.0f; t.pad = 0.0f;
+        if (a0 >= ge.attr_count || a1 >= ge.attr_count || a2 >= ge.attr_count) { attrs[item_begin + i] = t; return; }
+        if (ge.normals) {
+            const float* N = ge.normals;
+            t.n0x = N[3 * (size_t)a0]; t.n0y = N[3 * (size_t)a0 + 1]; t.n0z = N[3 * (size_t)a0 + 2];
+            t.n1x = N[3 * (size_t)a1]; t.n1y = N[3 * (size_t)a1 + 1]; t.n1z = N[3 * (size_t)a1 + 2];
+            t.n2x = N[3 * (size_t)a2]; t.n2y = N[3 * (size_t)a2 + 1]; t.n2z = N[3 * (size_t)a2 + 2];
+        }
+        if (ge.texcoords) {
+            const float* T = ge.texcoords;
+            t.t0x = T[2 * (size_t)a0]; t.t0y = T[2 * (size_t)a0 + 1]; t.t1x = T[2 * (size_t)a1]; t.t1y = T[2 * (size_t)a1 + 1]; t.t2x = T[2 * (size_t)a2]; t.t2y = T[2 * (size_t)a2 + 1];
+        }
+        attrs[item_begin + i] = t;
+    }
 }
 __global__ void k_emit_items(const uint32_t* item_src, uint32_t item_begin, uint32_t n, const uint32_t* ids, uint32_t* out) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -554,7 +574,7 @@ static bool build_from_boxes(BuildScratch& S, hipStream_t s, uint32_t n, Node8* 
 
 // BLAS over the triangles of a geometry list (Accel.zig:94-184; one BLAS per unique mesh list, :315-343)
 bool bvh_build_blas(BuildScratch* scratch, hipStream_t s, const std::vector<BlasGeo>& geos, uint32_t ntris, Node8* nodes, uint32_t* node_counter, uint32_t node_capacity,
-                    TriRec* tris, uint32_t* tri_counter, uint32_t* item_src, uint32_t* root_out, float root_box[6]) {
+                    TriRec* tris, TriAttr* attrs, uint32_t* tri_counter, uint32_t* item_src, uint32_t* root_out, float root_box[6]) {
     if (ntris == 0) { *root_out = MAX_UINT; for (int k = 0; k < 6; k++) root_box[k] = 0.0f; return true; }
     if (!scratch) return false;
     BuildScratch& g_scratch = *scratch;
@@ -568,7 +588,7 @@ bool bvh_build_blas(BuildScratch* scratch, hipStream_t s, const std::vector<Blas
     Box rb;
     bool ok = build_from_boxes(g_scratch, s, ntris, nodes, node_counter, node_capacity, tri_counter, item_src, root_out, &rb);
     if (ok) {
-        hipLaunchKernelGGL(k_emit_tris, dim3((ntris + 255) / 256), dim3(256), 0, s, dgeos, (uint32_t)geos.size(), item_src, item_begin, ntris, tris);
+        hipLaunchKernelGGL(k_emit_tris, dim3((ntris + 255) / 256), dim3(256), 0, s, dgeos, (uint32_t)geos.size(), item_src, item_begin, ntris, tris, attrs);
         HIPCHK(hipStreamSynchronize(s));
         for (int k = 0; k < 3; k++) { root_box[k] = rb.lo[k]; root_box[3 + k] = rb.hi[k]; }
     }

@@ -32,13 +32,13 @@ void launch_unpack_film(hipStream_t, int, const ShardView&, const float4*, uint3
 bool shade_probe_widths(int, uint32_t&, uint32_t&);
 void launch_shade_probe(hipStream_t, const SceneView&, int, const float*, uint32_t, float*);
 void launch_env_build(hipStream_t, const float4*, uint32_t, uint32_t, float4*, float*, const uint32_t*, uint32_t, uint32_t);
-struct BlasGeo { const float* positions; const uint32_t* indices; uint32_t tri_offset, tri_count, geo, inst; };
+struct BlasGeo { const float* positions; const uint32_t* indices; uint32_t tri_offset, tri_count, geo, inst; const float* normals; const float* texcoords; uint32_t indexed, attr_count; };
 struct BuildScratch;   // per-context build buffers (bvh_build.hip)
 BuildScratch* bvh_scratch_create();
 void bvh_scratch_destroy(BuildScratch*);
 void bvh_scratch_release(BuildScratch*);
 size_t bvh_scratch_capacity(const BuildScratch*);
-bool bvh_build_blas(BuildScratch*, hipStream_t, const std::vector<BlasGeo>&, uint32_t, Node8*, uint32_t*, uint32_t, TriRec*, uint32_t*, uint32_t*, uint32_t*, float[6]);
+bool bvh_build_blas(BuildScratch*, hipStream_t, const std::vector<BlasGeo>&, uint32_t, Node8*, uint32_t*, uint32_t, TriRec*, TriAttr*, uint32_t*, uint32_t*, uint32_t*, float[6]);
 struct TlasInst { float T[12]; float blas_box[6]; uint32_t mesh_begin, mesh_end, exact, pad; };
 struct TlasMesh { const float* positions; uint32_t count, pad; };
 bool bvh_build_tlas(BuildScratch*, hipStream_t, const TlasInst*, const uint32_t*, uint32_t, const TlasMesh*, uint32_t, Node8*, uint32_t*, uint32_t, uint32_t*, uint32_t*, uint32_t*, uint32_t*);
@@ -116,7 +116,8 @@ struct HdMoonshine {
     DevBuf<InstanceRec> d_instances;
     DevBuf<AliasEntry> d_alias;
     DevBuf<LightTri> d_light_tris; bool lights_dirty = true; uint32_t lights_indexed = 0;   // gathered light triangles (rebuilt with the alias table / attribute mode)
-    DevBuf<Node8> d_nodes; DevBuf<TriRec> d_tris; DevBuf<uint32_t> d_tlas_items, d_item_src;
+    DevBuf<Node8> d_nodes; DevBuf<TriRec> d_tris; DevBuf<TriAttr> d_tri_attrs; DevBuf<uint32_t> d_tlas_items, d_item_src;
+    bool blas_indexed = true;                             // the attribute mode the TriAttr records of the cached BLASes were gathered with
     DevBuf<uint32_t> d_build_counters;    // [0] node count, [1] tri count, [2] tlas item count
     uint32_t blas_nodes_end = 0, blas_tris_end = 0;
     std::map<std::vector<uint32_t>, BlasInfo> blas_cache;
@@ -332,6 +333,15 @@ bool HdMoonshine::rebuild_accel() {
     // hydra.zig:495-513) the previous one is evicted, and once evicted BLASes make up more than half of the pools the pools are
     // reset and everything still referenced is rebuilt — device memory stays within 2x of what the scene needs however long
     // an interactive session edits instances.
+    // The TriAttr records hold the attributes as THIS pipeline reads them (by vertex index or by corner): a change of mode rebuilds
+    if (blas_indexed != (opts.indexed_attributes != 0)) {
+        blas_cache.clear(); world_blas_key.clear(); blas_nodes_end = 0; blas_tris_end = 0; dead_tris = 0;
+        blas_indexed = opts.indexed_attributes != 0;
+    }
+    auto blas_geo = [&](const MeshH* m, uint32_t off, uint32_t g, uint32_t inst) {
+        return BlasGeo{ m->positions.p, m->indices.p, off, m->index_count, g, inst, m->has_normals ? m->normals.p : nullptr, m->has_texcoords ? m->texcoords.p : nullptr,
+                        blas_indexed ? 1u : 0u, m->attribute_count };
+    };
     if (world_key != world_blas_key) {
         auto old = blas_cache.find(world_blas_key);
         if (!world_blas_key.empty() && old != blas_cache.end()) { dead_tris += old->second.tris; blas_cache.erase(old); }
@@ -358,6 +368,15 @@ bool HdMoonshine::rebuild_accel() {
         CHECK_HIP(this, hipStreamSynchronize(stream));
         std::swap(nt.p, d_tris.p); std::swap(nt.n, d_tris.n);
     }
+    // TriAttr records ride in the same slots as the TriRecs, allocated once any referenced mesh carries normals or texcoords
+    bool any_attrs = false;
+    for (size_t i = 0; i < N && !any_attrs; i++) for (uint32_t m : keys[i]) if (meshes[m]->has_normals || meshes[m]->has_texcoords) { any_attrs = true; break; }
+    if (any_attrs && d_tri_attrs.n < d_tris.n) {
+        DevBuf<TriAttr> na; if (!na.alloc(d_tris.n)) { fail("out of device memory (triangle attributes)"); return false; }
+        if (blas_tris_end && d_tri_attrs.p) CHECK_HIP(this, hipMemcpyAsync(na.p, d_tri_attrs.p, std::min((size_t)blas_tris_end, d_tri_attrs.n) * sizeof(TriAttr), hipMemcpyDeviceToDevice, stream));
+        CHECK_HIP(this, hipStreamSynchronize(stream));
+        std::swap(na.p, d_tri_attrs.p); std::swap(na.n, d_tri_attrs.n);
+    }
     if (need_nodes > d_nodes.n || !d_nodes.p) {
         DevBuf<Node8> nn; if (!nn.alloc(need_nodes + need_nodes / 4 + 16)) { fail("out of device memory (nodes)"); return false; }
         if (blas_nodes_end) CHECK_HIP(this, hipMemcpyAsync(nn.p, d_nodes.p, (size_t)blas_nodes_end * sizeof(Node8), hipMemcpyDeviceToDevice, stream));
@@ -370,9 +389,9 @@ bool HdMoonshine::rebuild_accel() {
     for (size_t i = 0; i < N; i++) {
         if (in_world[i] || blas_cache.count(keys[i])) continue;
         std::vector<BlasGeo> bg; uint32_t off = 0, g = 0;
-        for (uint32_t m : keys[i]) { bg.push_back(BlasGeo{ meshes[m]->positions.p, meshes[m]->indices.p, off, meshes[m]->index_count, g++, 0u }); off += meshes[m]->index_count; }
+        for (uint32_t m : keys[i]) { bg.push_back(blas_geo(meshes[m], off, g++, 0u)); off += meshes[m]->index_count; }
         BlasInfo info{}; info.tris = off;
-        if (!bvh_build_blas(build_scratch, stream, bg, off, d_nodes.p, d_build_counters.p, (uint32_t)d_nodes.n, d_tris.p, d_build_counters.p + 1, d_item_src.p, &info.root, info.box)) { fail("BLAS build failed (details on stderr)"); return false; }
+        if (!bvh_build_blas(build_scratch, stream, bg, off, d_nodes.p, d_build_counters.p, (uint32_t)d_nodes.n, d_tris.p, d_tri_attrs.p, d_build_counters.p + 1, d_item_src.p, &info.root, info.box)) { fail("BLAS build failed (details on stderr)"); return false; }
         blas_cache[keys[i]] = info;
     }
     if (!world_key.empty() && !blas_cache.count(world_key)) {
@@ -380,10 +399,10 @@ bool HdMoonshine::rebuild_accel() {
         for (size_t i = 0; i < N; i++) {
             if (!in_world[i]) continue;
             uint32_t g = 0;
-            for (uint32_t m : keys[i]) { bg.push_back(BlasGeo{ meshes[m]->positions.p, meshes[m]->indices.p, off, meshes[m]->index_count, g++, (uint32_t)i }); off += meshes[m]->index_count; }
+            for (uint32_t m : keys[i]) { bg.push_back(blas_geo(meshes[m], off, g++, (uint32_t)i)); off += meshes[m]->index_count; }
         }
         BlasInfo info{}; info.tris = off;
-        if (!bvh_build_blas(build_scratch, stream, bg, off, d_nodes.p, d_build_counters.p, (uint32_t)d_nodes.n, d_tris.p, d_build_counters.p + 1, d_item_src.p, &info.root, info.box)) { fail("world BLAS build failed (details on stderr)"); return false; }
+        if (!bvh_build_blas(build_scratch, stream, bg, off, d_nodes.p, d_build_counters.p, (uint32_t)d_nodes.n, d_tris.p, d_tri_attrs.p, d_build_counters.p + 1, d_item_src.p, &info.root, info.box)) { fail("world BLAS build failed (details on stderr)"); return false; }
         blas_cache[world_key] = info;
     }
     { uint32_t c[2]; CHECK_HIP(this, hipMemcpy(c, d_build_counters.p, 8, hipMemcpyDeviceToHost)); blas_nodes_end = c[0]; blas_tris_end = c[1]; }
@@ -466,6 +485,7 @@ bool HdMoonshine::rebuild_accel() {
 bool HdMoonshine::ensure_scene() {
     if (textures_dirty && !upload_textures()) return false;
     if ((materials_dirty || !material_updates.empty()) && !upload_materials()) return false;
+    if (blas_indexed != (opts.indexed_attributes != 0)) accel_dirty = true;
     if (accel_dirty && !rebuild_accel()) return false;
     if (lights_dirty || lights_indexed != opts.indexed_attributes) {
         const uint32_t count = h_alias.empty() ? 0u : h_alias[0].alias;
@@ -481,7 +501,7 @@ bool HdMoonshine::ensure_scene() {
 
 SceneView HdMoonshine::scene_view() const {
     SceneView v{};
-    v.nodes = d_nodes.p; v.tris = d_tris.p; v.tlas_items = d_tlas_items.p; v.instances = d_instances.p; v.geometries = d_geometries.p;
+    v.nodes = d_nodes.p; v.tris = d_tris.p; v.tri_attrs = d_tri_attrs.p; v.tlas_items = d_tlas_items.p; v.instances = d_instances.p; v.geometries = d_geometries.p;
     v.meshes = d_meshes.p; v.materials = d_materials.p; v.textures = d_texdesc.p; v.texels = d_texels.p; v.alias = d_alias.p;
     if (!h_alias.empty()) { v.alias_count = h_alias[0].alias; v.alias_sum = h_alias[0].select; }
     v.light_tris = d_light_tris.p;

@@ -29,6 +29,13 @@ struct alignas(16) TriRec {
 };
 static_assert(sizeof(TriRec) == 48, "TriRec must be 48 bytes");
 
+// What MeshAttributes::lookupAndInterpolate (world.hlsl:114-158) reads beyond the positions, for the triangle in the SAME slot of the
+// triangle pool: the three normals and texcoords the pipeline's attribute mode selects (by vertex index for glTF, by corner for Hydra),
+// gathered once at build time.  A hit then needs one 64-B record instead of the chain geometry -> mesh -> indices -> 6 scattered attributes.
+// Only filled (and only read) for geometries whose mesh has normals or texcoords.
+struct alignas(16) TriAttr { float n0x, n0y, n0z, n1x, n1y, n1z, n2x, n2y, n2z, t0x, t0y, t1x, t1y, t2x, t2y, pad; };
+static_assert(sizeof(TriAttr) == 64, "TriAttr must be 64 bytes");
+
 // per instance (Accel.zig:394-432): object->world, world->object, first geometry, BLAS root
 struct alignas(16) InstanceRec {
     m34 transform;
@@ -67,6 +74,7 @@ struct EnvView {
 struct SceneView {
     const Node8* nodes;
     const TriRec* tris;
+    const TriAttr* tri_attrs;         // parallel to tris (same slot); nullptr when no mesh of the scene has normals or texcoords
     const uint32_t* tlas_items;       // instance index per TLAS leaf item
     const InstanceRec* instances;
     const GeometryRec* geometries;

@@ -70,47 +70,53 @@ __device__ __forceinline__ f2 ld2(const float* p, uint32_t i) { return F2(p[2 * 
 // Two entry points: by (instance, geometry, primitive) — the reference's chain instance → geometry → mesh → indices →
 // positions, used for sampled light triangles — and by triangle-record slot for surface hits (`tri_slot` != MAX_UINT):
 // the BVH's 48-B record already holds the three vertices (bit-identical copies), the geometry and the primitive index,
-// which removes three dependent loads from every hit; indices are only fetched when the mesh has normals or texcoords.
+// which removes three dependent loads from every hit, and the 64-B TriAttr in the same slot holds the normals and texcoords the
+// builder gathered for it (by vertex index or by corner, as the pipeline reads them) — read only when the mesh has either.
 __device__ __forceinline__ Attrs mesh_attributes_world(const SceneView& sc, bool indexed_attributes, uint32_t instanceIndex, uint32_t geometryIndex,
                                                        uint32_t primitiveIndex, f2 attribs, GeometryRec& geo_out, uint32_t tri_slot = MAX_UINT,
                                                        bool geo_known = false /* geo_out already holds the geometry record of the hit */) {
     const InstanceRec* inst = sc.instances + instanceIndex;
     const f3 bary = F3(1.0f - attribs.x - attribs.y, attribs.x, attribs.y);
     Attrs a;
-    f3 p0, p1, p2; uint32_t i0 = 0, i1 = 0, i2 = 0;
-    GeometryRec g; MeshRec mesh;
+    f3 p0, p1, p2, n0, n1, n2; f2 t0, t1, t2;
+    GeometryRec g; bool has_normals;
     if (tri_slot != MAX_UINT) {
         const uint4* tp = reinterpret_cast<const uint4*>(sc.tris + tri_slot);
         const uint4 ta = tp[0], tb = tp[1], tc = tp[2];
         p0 = F3(u2f(ta.x), u2f(ta.y), u2f(ta.z)); p1 = F3(u2f(ta.w), u2f(tb.x), u2f(tb.y)); p2 = F3(u2f(tb.z), u2f(tb.w), u2f(tc.x));
         geometryIndex = tc.y; primitiveIndex = tc.z;
         g = geo_known ? geo_out : sc.geometries[inst->geo_offset + geometryIndex];
-        mesh.positions = nullptr; mesh.texcoords = nullptr; mesh.normals = nullptr; mesh.indices = nullptr;
-        if (g.sampled & (GEO_HAS_TEXCOORDS | GEO_HAS_NORMALS)) {
-            mesh = sc.meshes[g.mesh];
-            if (indexed_attributes) { i0 = mesh.indices[3 * (size_t)primitiveIndex]; i1 = mesh.indices[3 * (size_t)primitiveIndex + 1]; i2 = mesh.indices[3 * (size_t)primitiveIndex + 2]; }
+        has_normals = (g.sampled & GEO_HAS_NORMALS) != 0;
+        t0 = F2(0.0f, 0.0f); t1 = F2(1.0f, 0.0f); t2 = F2(1.0f, 1.0f);
+        n0 = n1 = n2 = F3(0.0f, 0.0f, 0.0f);
+        if (g.sampled & (GEO_HAS_TEXCOORDS | GEO_HAS_NORMALS)) {   // the TriAttr in the same slot: the attributes the builder gathered for this triangle
+            const float4* ap = reinterpret_cast<const float4*>(sc.tri_attrs + tri_slot);
+            const float4 qa = ap[0], qb = ap[1], qc = ap[2], qd = ap[3];
+            n0 = F3(qa.x, qa.y, qa.z); n1 = F3(qa.w, qb.x, qb.y); n2 = F3(qb.z, qb.w, qc.x);
+            t0 = F2(qc.y, qc.z); t1 = F2(qc.w, qd.x); t2 = F2(qd.y, qd.z);
         }
     } else {
         const uint32_t instanceID = inst->geo_offset;
         g = sc.geometries[instanceID + geometryIndex];
-        mesh = sc.meshes[g.mesh];
-        i0 = mesh.indices[3 * (size_t)primitiveIndex]; i1 = mesh.indices[3 * (size_t)primitiveIndex + 1]; i2 = mesh.indices[3 * (size_t)primitiveIndex + 2];
+        const MeshRec mesh = sc.meshes[g.mesh];
+        const uint32_t i0 = mesh.indices[3 * (size_t)primitiveIndex], i1 = mesh.indices[3 * (size_t)primitiveIndex + 1], i2 = mesh.indices[3 * (size_t)primitiveIndex + 2];
         p0 = ld3(mesh.positions, i0); p1 = ld3(mesh.positions, i1); p2 = ld3(mesh.positions, i2);
+        uint32_t a0, a1, a2;
+        if (indexed_attributes) { a0 = i0; a1 = i1; a2 = i2; }
+        else { a0 = primitiveIndex * 3 + 0; a1 = primitiveIndex * 3 + 1; a2 = primitiveIndex * 3 + 2; }
+        if (mesh.texcoords) { t0 = ld2(mesh.texcoords, a0); t1 = ld2(mesh.texcoords, a1); t2 = ld2(mesh.texcoords, a2); }
+        else { t0 = F2(0.0f, 0.0f); t1 = F2(1.0f, 0.0f); t2 = F2(1.0f, 1.0f); }
+        has_normals = mesh.normals != nullptr;
+        n0 = n1 = n2 = F3(0.0f, 0.0f, 0.0f);
+        if (has_normals) { n0 = ld3(mesh.normals, a0); n1 = ld3(mesh.normals, a1); n2 = ld3(mesh.normals, a2); }
     }
     geo_out = g;
     a.position = interp3(bary, p0, p1, p2);
-    uint32_t a0, a1, a2;
-    if (indexed_attributes) { a0 = i0; a1 = i1; a2 = i2; }
-    else { a0 = primitiveIndex * 3 + 0; a1 = primitiveIndex * 3 + 1; a2 = primitiveIndex * 3 + 2; }
-    f2 t0, t1, t2;
-    if (mesh.texcoords) { t0 = ld2(mesh.texcoords, a0); t1 = ld2(mesh.texcoords, a1); t2 = ld2(mesh.texcoords, a2); }
-    else { t0 = F2(0.0f, 0.0f); t1 = F2(1.0f, 0.0f); t2 = F2(1.0f, 1.0f); }
     a.texcoord = interp2(bary, t0, t1, t2);
     get_tangent_bitangent(p0, p1, p2, t0, t1, t2, a.triangleFrame.s, a.triangleFrame.t);
     a.triangleFrame.n = normalize(cross(sub(p0, p2), sub(p1, p2)));
     frame_reorthogonalize(a.triangleFrame);
-    if (mesh.normals) {
-        const f3 n0 = ld3(mesh.normals, a0), n1 = ld3(mesh.normals, a1), n2 = ld3(mesh.normals, a2);
+    if (has_normals) {
         a.frame = a.triangleFrame;
         a.frame.n = normalize(interp3(bary, n0, n1, n2));
         frame_reorthogonalize(a.frame);
@@ -118,7 +124,7 @@ __device__ __forceinline__ Attrs mesh_attributes_world(const SceneView& sc, bool
     // inWorld
     const m34 toWorld = inst->transform, toMesh = inst->world_to_instance;
     a.position = m34_mul_point(toWorld, a.position);
-    const bool own_frame = mesh.normals != nullptr;   // without vertex normals the two frames are the same vectors: the same operations give the same bits
+    const bool own_frame = has_normals;   // without vertex normals the two frames are the same vectors: the same operations give the same bits
     a.triangleFrame = frame_in_space(a.triangleFrame, toMesh);
     a.frame = own_frame ? frame_in_space(a.frame, toMesh) : a.triangleFrame;
     return a;
