@@ -483,6 +483,38 @@ def test_unsupported_pipeline_is_rejected_loudly(gpu_api):
 
 
 @pytest.mark.gpu
+def test_attribute_mode_switch_regathers_triangle_attributes(orc, gpu_api):
+    """The per-triangle attribute records are gathered at BLAS build for the pipeline's mode (by vertex index / by corner, world.hlsl:127-135).
+    Flipping indexed_attributes on a live context — the arrays cover both readings — must re-gather them: every mode, in either
+    order, equals the oracle's render of that mode."""
+    P, I = scenes.icosphere(2)
+    corner = I.reshape(-1)
+    rs = np.random.default_rng(11)
+    n = rs.normal(size=(len(corner), 3)).astype(np.float32) * 0.3 + P[corner]
+    n /= np.linalg.norm(n, axis=1, keepdims=True)
+    uv = rs.random((len(corner), 2)).astype(np.float32)
+    half = rs.random((8, 8, 4)).astype(np.float16)
+    films = {}
+    for name, c in (("gpu", gpu_api.Context()), ("orc", orc.Context(threads=8))):
+        mesh = c.create_mesh(P, I, normals=n, texcoords=uv)        # 3 * tris corners >= vertices: both modes are in range
+        col = c.create_texture(half, 8, 8, "r16g16b16a16_sfloat")
+        m = c.create_material(scenes.STANDARD_PBR, c.solid_texture(0.5, 0.5), c.solid_texture(0.0, 0.0, 0.0), color=col,
+                              metalness=c.solid_texture(0.1), roughness=c.solid_texture(0.4), ior=1.5)
+        c.create_instance([(mesh, m, False)])
+        T = np.zeros((3, 4), np.float32); T[:, :3] = np.eye(3) * 0.8; T[:, 3] = (0.0, 2.3, 0.0)
+        c.create_instance([(mesh, m, False)], transform=T)
+        s = c.create_sensor(48, 40); l = c.create_lens(c.make_lens((-4, 1.2, 0.4), (1, 0, 0), (0, 0, 1), 0.9))
+        for step, indexed in enumerate((True, False, True)):
+            c.set_pipeline(samples_per_run=1, max_bounces=6, env_samples_per_bounce=0, mesh_samples_per_bounce=0, indexed_attributes=indexed)
+            c.clear_sensor(s); c.render(s, l, launches=4)
+            films[name, step] = c.sensor_data(s).copy()
+    for step in range(3):
+        assert_film_equal(films["gpu", step], films["orc", step], "attribute mode step %d" % step)
+    assert not np.array_equal(films["gpu", 0], films["gpu", 1])
+    assert np.array_equal(films["gpu", 0], films["gpu", 2])
+
+
+@pytest.mark.gpu
 def test_attribute_arrays_must_cover_what_the_pipeline_reads(gpu_api):
     """per-vertex normals (glTF layout) under the face-varying pipeline (Hydra's constants) would be read out of bounds:
     MsneRender refuses instead"""
