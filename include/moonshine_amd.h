@@ -280,7 +280,9 @@ int MsneTraceRays(HdMoonshine*, const float* rays, uint32_t n, int any_hit, uint
 /* Batch probe of the device-side shading functions (the material.hlsl / light.hlsl / mappings.hlsl / math.hlsl restatements that
  * k_shade runs), one record per thread: fn 0 BSDF pdf/eval/sample, 1-3 EnvMap sample/eval/incomingRadiance on the context's
  * environment, 4-8 sampling warps, 9 Fresnel::dielectric, 10 offsetAlongNormal, 11 coordinateSystem, 12 areaMeasureToSolidAngleMeasure,
- * 13 GGX D/Lambda/G, 14 refractDir, 15 powerHeuristic, 16 Frame, 17 dTextures[i].SampleLevel.  Record widths: tests/second_source.py PROBES. */
+ * 13 GGX D/Lambda/G, 14 refractDir, 15 powerHeuristic, 16 Frame, 17 dTextures[i].SampleLevel, 18 MeshAttributes::lookupAndInterpolate + inWorld
+ * on explicit vertex data (world.hlsl:86-176), 19 getTextureFrame on a sampled normal texel (material.hlsl:489-517), 20 Camera::generateRay from a
+ * lens + extent (camera.hlsl:14-42; the host half is the make_camera() MsneRender runs).  Record widths: tests/second_source.py PROBES. */
 int MsneShadeProbe(HdMoonshine*, int fn, const float* in, uint32_t n, float* out);
 uint32_t MsneGetEnvSize(const HdMoonshine*);
 int MsneReadEnv(HdMoonshine*, float* rgb_out, float* lum_pyramid_out);

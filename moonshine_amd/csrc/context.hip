@@ -1024,6 +1024,21 @@ int MsneShadeProbe(HdMoonshine* c, int fn, const float* in, uint32_t n, float* o
         if (c->textures_dirty && !c->upload_textures()) return -1;
         for (uint32_t i = 0; i < n; i++) if (!(in[3 * (size_t)i] >= 0.0f && in[3 * (size_t)i] < (float)c->textures.size())) { c->fail("shade probe: unknown texture"); return -1; }
     }
+    std::vector<float> cams;
+    if (fn == 20) {   // camera probe: the caller hands over lenses; the constants MsneRender would derive from them (make_camera) go to the device
+        cams.resize((size_t)n * win);
+        for (uint32_t i = 0; i < n; i++) {
+            const float* a = in + 18 * (size_t)i; float* o = &cams[(size_t)i * win];
+            if (!(a[12] >= 1.0f && a[13] >= 1.0f)) { c->fail("shade probe: camera record without an extent"); return -1; }
+            Lens lens{}; lens.origin = F32x3{ a[0], a[1], a[2] }; lens.forward = F32x3{ a[3], a[4], a[5] }; lens.up = F32x3{ a[6], a[7], a[8] };
+            lens.vfov = a[9]; lens.aperture = a[10]; lens.focus_distance = a[11];
+            const CameraConsts k = make_camera(lens, (uint32_t)a[12], (uint32_t)a[13]);
+            const f3 v[6] = { k.origin, k.u, k.v, k.horizontal, k.vertical, k.llc };
+            for (int j = 0; j < 6; j++) { o[3 * j] = v[j].x; o[3 * j + 1] = v[j].y; o[3 * j + 2] = v[j].z; }
+            o[18] = k.aperture; o[19] = a[14]; o[20] = a[15]; o[21] = a[16]; o[22] = a[17];
+        }
+        in = cams.data();
+    }
     DevBuf<float> di, dout;
     if (!di.alloc((size_t)n * win) || !dout.alloc((size_t)n * wout)) { c->fail("out of device memory (probe)"); return -1; }
     if (hipMemcpyAsync(di.p, in, (size_t)n * win * 4, hipMemcpyHostToDevice, c->stream) != hipSuccess) return -1;

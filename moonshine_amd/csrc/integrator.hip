@@ -411,8 +411,8 @@ __global__ __launch_bounds__(SHADE_BLOCK) void k_unpack_film(ShardView sh, const
 
 // Batch probe of the shading functions for parity tests (MsneShadeProbe): the SAME device functions k_shade runs, one record
 // per thread.  The table (function codes, record widths) is the test oracle's OrcProbeBatch.
-__constant__ uint32_t c_probe_in[18]  = { 15, 2, 3, 3, 2, 3, 2, 2, 2, 3, 6, 3, 12, 7, 7, 4, 9, 3 };
-__constant__ uint32_t c_probe_out[18] = {  8, 7, 4, 3, 3, 2, 2, 2, 3, 1, 3, 6,  1, 3, 3, 1, 6, 4 };
+__constant__ uint32_t c_probe_in[21]  = { 15, 2, 3, 3, 2, 3, 2, 2, 2, 3, 6, 3, 12, 7, 7, 4, 9, 3, 51, 13, 23 };
+__constant__ uint32_t c_probe_out[21] = {  8, 7, 4, 3, 3, 2, 2, 2, 3, 1, 3, 6,  1, 3, 3, 1, 6, 4, 23,  9,  6 };
 __global__ void k_shade_probe(SceneView sc, int fn, const float* in, uint32_t n, float* out) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
@@ -444,11 +444,36 @@ __global__ void k_shade_probe(SceneView sc, int fn, const float* in, uint32_t n,
                    const f3 p = frame_world_to_frame(f, F3(a[6], a[7], a[8])), q = frame_frame_to_world(f, F3(a[6], a[7], a[8]));
                    o[0] = p.x; o[1] = p.y; o[2] = p.z; o[3] = q.x; o[4] = q.y; o[5] = q.z; break; }
         case 17: { const float4 t = tex_sample(sc, (uint32_t)a[0], F2(a[1], a[2])); o[0] = t.x; o[1] = t.y; o[2] = t.z; o[3] = t.w; break; }   // (the caller checked the index)
+        case 18: {   // MeshAttributes::lookupAndInterpolate(...).inWorld(...) on explicit vertex data: flags bit 0 = the mesh has texcoords, bit 1 = normals
+            const uint32_t flags = (uint32_t)a[26];
+            const bool ht = (flags & 1u) != 0u, hn = (flags & 2u) != 0u;
+            const f2 t0 = ht ? F2(a[9], a[10]) : F2(0.0f, 0.0f), t1 = ht ? F2(a[11], a[12]) : F2(1.0f, 0.0f), t2 = ht ? F2(a[13], a[14]) : F2(1.0f, 1.0f);
+            m34 tw, tm;
+            for (int r = 0; r < 3; r++) for (int c = 0; c < 4; c++) { tw.m[r][c] = a[27 + 4 * r + c]; tm.m[r][c] = a[39 + 4 * r + c]; }
+            const Attrs at = mesh_attributes_core(F3(a[0], a[1], a[2]), F3(a[3], a[4], a[5]), F3(a[6], a[7], a[8]), t0, t1, t2, F3(a[15], a[16], a[17]), F3(a[18], a[19], a[20]), F3(a[21], a[22], a[23]),
+                                                  hn, F3(1.0f - a[24] - a[25], a[24], a[25]), tw, tm);
+            o[0] = at.position.x; o[1] = at.position.y; o[2] = at.position.z; o[3] = at.texcoord.x; o[4] = at.texcoord.y;
+            const Frame* fr[2] = { &at.triangleFrame, &at.frame };
+            for (int k = 0; k < 2; k++) { float* q = o + 5 + 9 * k; q[0] = fr[k]->n.x; q[1] = fr[k]->n.y; q[2] = fr[k]->n.z; q[3] = fr[k]->s.x; q[4] = fr[k]->s.y; q[5] = fr[k]->s.z; q[6] = fr[k]->t.x; q[7] = fr[k]->t.y; q[8] = fr[k]->t.z; }
+            break; }
+        case 19: {   // getTextureFrame on an already sampled normal texel
+            Frame tf; tf.n = F3(a[3], a[4], a[5]); tf.s = F3(a[6], a[7], a[8]); tf.t = F3(a[9], a[10], a[11]);
+            const Frame f = texture_frame_from_texel(make_float4(a[0], a[1], a[2], 1.0f), a[12] != 0.0f, tf);
+            o[0] = f.n.x; o[1] = f.n.y; o[2] = f.n.z; o[3] = f.s.x; o[4] = f.s.y; o[5] = f.s.z; o[6] = f.t.x; o[7] = f.t.y; o[8] = f.t.z;
+            break; }
+        case 20: {   // Camera::generateRay: the host evaluated make_camera() on the lens (as MsneRender does); 19 constants, uv, rand
+            CameraConsts cam;
+            cam.origin = F3(a[0], a[1], a[2]); cam.u = F3(a[3], a[4], a[5]); cam.v = F3(a[6], a[7], a[8]); cam.horizontal = F3(a[9], a[10], a[11]);
+            cam.vertical = F3(a[12], a[13], a[14]); cam.llc = F3(a[15], a[16], a[17]); cam.aperture = a[18];
+            f3 O, D; camera_generate_ray(cam, F2(a[19], a[20]), F2(a[21], a[22]), O, D);
+            o[0] = O.x; o[1] = O.y; o[2] = O.z; o[3] = D.x; o[4] = D.y; o[5] = D.z;
+            break; }
     }
 }
 bool shade_probe_widths(int fn, uint32_t& win, uint32_t& wout) {
-    static const uint32_t pin[18]  = { 15, 2, 3, 3, 2, 3, 2, 2, 2, 3, 6, 3, 12, 7, 7, 4, 9, 3 }, pout[18] = { 8, 7, 4, 3, 3, 2, 2, 2, 3, 1, 3, 6, 1, 3, 3, 1, 6, 4 };
-    if (fn < 0 || fn > 17) return false;
+    // (fn 20: the width on the device — the host turns the caller's 18-float lens record into make_camera()'s constants first)
+    static const uint32_t pin[21]  = { 15, 2, 3, 3, 2, 3, 2, 2, 2, 3, 6, 3, 12, 7, 7, 4, 9, 3, 51, 13, 23 }, pout[21] = { 8, 7, 4, 3, 3, 2, 2, 2, 3, 1, 3, 6, 1, 3, 3, 1, 6, 4, 23, 9, 6 };
+    if (fn < 0 || fn > 20) return false;
     win = pin[fn]; wout = pout[fn]; return true;
 }
 void launch_shade_probe(hipStream_t s, const SceneView& sc, int fn, const float* in, uint32_t n, float* out) {

@@ -66,6 +66,28 @@ __device__ __forceinline__ Frame frame_in_space(const Frame& f, const m34& toMes
 __device__ __forceinline__ f3 ld3(const float* p, uint32_t i) { return F3(p[3 * (size_t)i], p[3 * (size_t)i + 1], p[3 * (size_t)i + 2]); }
 __device__ __forceinline__ f2 ld2(const float* p, uint32_t i) { return F2(p[2 * (size_t)i], p[2 * (size_t)i + 1]); }
 
+// The arithmetic of MeshAttributes::lookupAndInterpolate + inWorld (world.hlsl:122-176) once the three vertices' attributes are in hand
+// (t = (0,0),(1,0),(1,1) for a mesh without texcoords, :137-141); k_shade and the probe MsneShadeProbe(18) both run this.
+__device__ __forceinline__ Attrs mesh_attributes_core(f3 p0, f3 p1, f3 p2, f2 t0, f2 t1, f2 t2, f3 n0, f3 n1, f3 n2, bool has_normals, f3 bary, const m34& toWorld, const m34& toMesh) {
+    Attrs a;
+    a.position = interp3(bary, p0, p1, p2);
+    a.texcoord = interp2(bary, t0, t1, t2);
+    get_tangent_bitangent(p0, p1, p2, t0, t1, t2, a.triangleFrame.s, a.triangleFrame.t);
+    a.triangleFrame.n = normalize(cross(sub(p0, p2), sub(p1, p2)));
+    frame_reorthogonalize(a.triangleFrame);
+    if (has_normals) {
+        a.frame = a.triangleFrame;
+        a.frame.n = normalize(interp3(bary, n0, n1, n2));
+        frame_reorthogonalize(a.frame);
+    } else a.frame = a.triangleFrame;
+    // inWorld
+    a.position = m34_mul_point(toWorld, a.position);
+    const bool own_frame = has_normals;   // without vertex normals the two frames are the same vectors: the same operations give the same bits
+    a.triangleFrame = frame_in_space(a.triangleFrame, toMesh);
+    a.frame = own_frame ? frame_in_space(a.frame, toMesh) : a.triangleFrame;
+    return a;
+}
+
 // MeshAttributes::lookupAndInterpolate(...).inWorld(...)  world.hlsl:114-176; also returns the geometry record.
 // Two entry points: by (instance, geometry, primitive) — the reference's chain instance → geometry → mesh → indices →
 // positions, used for sampled light triangles — and by triangle-record slot for surface hits (`tri_slot` != MAX_UINT):
@@ -77,7 +99,6 @@ __device__ __forceinline__ Attrs mesh_attributes_world(const SceneView& sc, bool
                                                        bool geo_known = false /* geo_out already holds the geometry record of the hit */) {
     const InstanceRec* inst = sc.instances + instanceIndex;
     const f3 bary = F3(1.0f - attribs.x - attribs.y, attribs.x, attribs.y);
-    Attrs a;
     f3 p0, p1, p2, n0, n1, n2; f2 t0, t1, t2;
     GeometryRec g; bool has_normals;
     if (tri_slot != MAX_UINT) {
@@ -111,23 +132,7 @@ __device__ __forceinline__ Attrs mesh_attributes_world(const SceneView& sc, bool
         if (has_normals) { n0 = ld3(mesh.normals, a0); n1 = ld3(mesh.normals, a1); n2 = ld3(mesh.normals, a2); }
     }
     geo_out = g;
-    a.position = interp3(bary, p0, p1, p2);
-    a.texcoord = interp2(bary, t0, t1, t2);
-    get_tangent_bitangent(p0, p1, p2, t0, t1, t2, a.triangleFrame.s, a.triangleFrame.t);
-    a.triangleFrame.n = normalize(cross(sub(p0, p2), sub(p1, p2)));
-    frame_reorthogonalize(a.triangleFrame);
-    if (has_normals) {
-        a.frame = a.triangleFrame;
-        a.frame.n = normalize(interp3(bary, n0, n1, n2));
-        frame_reorthogonalize(a.frame);
-    } else a.frame = a.triangleFrame;
-    // inWorld
-    const m34 toWorld = inst->transform, toMesh = inst->world_to_instance;
-    a.position = m34_mul_point(toWorld, a.position);
-    const bool own_frame = has_normals;   // without vertex normals the two frames are the same vectors: the same operations give the same bits
-    a.triangleFrame = frame_in_space(a.triangleFrame, toMesh);
-    a.frame = own_frame ? frame_in_space(a.frame, toMesh) : a.triangleFrame;
-    return a;
+    return mesh_attributes_core(p0, p1, p2, t0, t1, t2, n0, n1, n2, has_normals, bary, inst->transform, inst->world_to_instance);
 }
 
 // ---------------- material.hlsl ----------------
@@ -283,9 +288,8 @@ __device__ __forceinline__ MSample material_sample(const Mat& m, f3 wo, f2 sq) {
     if (m.type == MAT_MIRROR) { MSample s; s.pdf = 1.0f; s.dirFs = F3(-wo.x, -wo.y, wo.z); return s; }
     return glass_sample(m, wo, sq);
 }
-// material.hlsl:489-522
-__device__ __forceinline__ Frame get_texture_frame(const SceneView& sc, const TexDesc& normal_desc, bool two_component, f2 uv, const Frame& tangentFrame) {
-    const float4 o = tex_sample_desc(sc, normal_desc, uv);
+// material.hlsl:489-522: decodeNormal / tangentNormalToWorld / createTextureFrame on a sampled normal texel (k_shade and MsneShadeProbe(19))
+__device__ __forceinline__ Frame texture_frame_from_texel(float4 o, bool two_component, const Frame& tangentFrame) {
     f3 nts;
     if (two_component) {
         const float rx = o.x * 2.0f - 1.0f, ry = o.y * 2.0f - 1.0f;
@@ -295,6 +299,9 @@ __device__ __forceinline__ Frame get_texture_frame(const SceneView& sc, const Te
     const f3 nws = normalize(frame_frame_to_world(tangentFrame, nts));
     Frame f = tangentFrame; f.n = nws; frame_reorthogonalize(f);
     return f;
+}
+__device__ __forceinline__ Frame get_texture_frame(const SceneView& sc, const TexDesc& normal_desc, bool two_component, f2 uv, const Frame& tangentFrame) {
+    return texture_frame_from_texel(tex_sample_desc(sc, normal_desc, uv), two_component, tangentFrame);
 }
 
 // ---------------- light.hlsl ----------------

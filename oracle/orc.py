@@ -340,7 +340,8 @@ def bsdf_probe(type, color, metalness, roughness, ior, wi, wo, sq):
 PROBES = {"bsdf": (0, 15, 8), "env_sample": (1, 2, 7), "env_eval": (2, 3, 4), "env_incoming": (3, 3, 3), "equal_area": (4, 2, 3),
           "equal_area_inverse": (5, 3, 2), "triangle": (6, 2, 2), "gaussian": (7, 2, 2), "cosine_hemisphere": (8, 2, 3),
           "fresnel_dielectric": (9, 3, 1), "offset_along_normal": (10, 6, 3), "coordinate_system": (11, 3, 6),
-          "area_to_solid_angle": (12, 12, 1), "ggx": (13, 7, 3), "refract": (14, 7, 3), "power_heuristic": (15, 4, 1), "frame": (16, 9, 6), "texture": (17, 3, 4)}
+          "area_to_solid_angle": (12, 12, 1), "ggx": (13, 7, 3), "refract": (14, 7, 3), "power_heuristic": (15, 4, 1), "frame": (16, 9, 6), "texture": (17, 3, 4),
+          "mesh_attributes": (18, 51, 23), "texture_frame": (19, 13, 9), "camera": (20, 18, 6)}
 
 
 def probe(name, x, ctx=None):

@@ -577,11 +577,15 @@ void OrcBsdfProbe(uint32_t type, const float params[6], const float wi[3], const
  * 13 GGX {alpha, a xyz, b xyz} -> {D(a), Lambda(a), G(a, b)}
  * 14 refractDir {wi, n, eta} -> {dir}              15 powerHeuristic {numf, fPdf, numg, gPdf} -> {w}
  * 16 Frame: {n xyz, s xyz, v xyz} -> reorthogonalize(n, s) then {worldToFrame(v), frameToWorld(v)}
- * 17 dTextures[i].SampleLevel(dTextureSampler, uv, 0) {texture index, u, v} -> {rgba}   (context textures; linear, repeat) */
-static const uint32_t PROBE_IN[18]  = { 15, 2, 3, 3, 2, 3, 2, 2, 2, 3, 6, 3, 12, 7, 7, 4, 9, 3 };
-static const uint32_t PROBE_OUT[18] = {  8, 7, 4, 3, 3, 2, 2, 2, 3, 1, 3, 6,  1, 3, 3, 1, 6, 4 };
+ * 17 dTextures[i].SampleLevel(dTextureSampler, uv, 0) {texture index, u, v} -> {rgba}   (context textures; linear, repeat)
+ * 18 MeshAttributes::lookupAndInterpolate + inWorld {p0 p1 p2, t0 t1 t2, n0 n1 n2, attribs, flags (1 texcoords | 2 normals), toWorld 3x4, toMesh 3x4}
+ *    -> {position, texcoord, triangleFrame n s t, frame n s t}
+ * 19 getTextureFrame {normal texel rgb, tangent frame n s t, two_component} -> {frame n s t}
+ * 20 Camera::generateRay {origin, forward, up, vfov, aperture, focus_distance, width, height, uv, rand} -> {origin, direction} */
+static const uint32_t PROBE_IN[21]  = { 15, 2, 3, 3, 2, 3, 2, 2, 2, 3, 6, 3, 12, 7, 7, 4, 9, 3, 51, 13, 18 };
+static const uint32_t PROBE_OUT[21] = {  8, 7, 4, 3, 3, 2, 2, 2, 3, 1, 3, 6,  1, 3, 3, 1, 6, 4, 23,  9,  6 };
 int OrcProbeBatch(OrcContext *c, int fn, const float *in, uint32_t n, float *out) {
-    if (fn < 0 || fn > 17) return -1;
+    if (fn < 0 || fn > 20) return -1;
     orc_counters cnt; memset(&cnt, 0, sizeof cnt);
     for (uint32_t i = 0; i < n; i++) {
         const float *a = in + (size_t)i * PROBE_IN[fn]; float *o = out + (size_t)i * PROBE_OUT[fn];
@@ -607,6 +611,32 @@ int OrcProbeBatch(OrcContext *c, int fn, const float *in, uint32_t n, float *out
                        v3 p = frame_world_to_frame(&f, V3(a[6], a[7], a[8])), q = frame_frame_to_world(&f, V3(a[6], a[7], a[8]));
                        o[0] = p.x; o[1] = p.y; o[2] = p.z; o[3] = q.x; o[4] = q.y; o[5] = q.z; break; }
             case 17: { uint32_t t = (uint32_t)a[0]; if (!c || t >= c->texture_count) return -1; tex_sample_bilinear(&c->textures[t], a[1], a[2], 0, o); break; }
+            case 18: {
+                uint32_t flags = (uint32_t)a[26];
+                int ht = (flags & 1u) != 0, hn = (flags & 2u) != 0;
+                v2 t0 = ht ? V2(a[9], a[10]) : V2(0, 0), t1 = ht ? V2(a[11], a[12]) : V2(1, 0), t2 = ht ? V2(a[13], a[14]) : V2(1, 1);
+                m34 tw, tm;
+                for (int r = 0; r < 3; r++) for (int k = 0; k < 4; k++) { tw.m[r][k] = a[27 + 4 * r + k]; tm.m[r][k] = a[39 + 4 * r + k]; }
+                orc_attrs at = mesh_attributes_core(V3(a[0], a[1], a[2]), V3(a[3], a[4], a[5]), V3(a[6], a[7], a[8]), t0, t1, t2, V3(a[15], a[16], a[17]), V3(a[18], a[19], a[20]), V3(a[21], a[22], a[23]),
+                                                    hn, V3(1.0f - a[24] - a[25], a[24], a[25]), &tw, &tm);
+                o[0] = at.position.x; o[1] = at.position.y; o[2] = at.position.z; o[3] = at.texcoord.x; o[4] = at.texcoord.y;
+                const orc_frame *fr[2] = { &at.triangleFrame, &at.frame };
+                for (int k = 0; k < 2; k++) { float *q = o + 5 + 9 * k; q[0] = fr[k]->n.x; q[1] = fr[k]->n.y; q[2] = fr[k]->n.z; q[3] = fr[k]->s.x; q[4] = fr[k]->s.y; q[5] = fr[k]->s.z; q[6] = fr[k]->t.x; q[7] = fr[k]->t.y; q[8] = fr[k]->t.z; }
+                break; }
+            case 19: {
+                orc_frame tf; tf.n = V3(a[3], a[4], a[5]); tf.s = V3(a[6], a[7], a[8]); tf.t = V3(a[9], a[10], a[11]);
+                float texel[4] = { a[0], a[1], a[2], 1.0f };
+                orc_frame f = texture_frame_from_texel(texel, a[12] != 0.0f, &tf);
+                o[0] = f.n.x; o[1] = f.n.y; o[2] = f.n.z; o[3] = f.s.x; o[4] = f.s.y; o[5] = f.s.z; o[6] = f.t.x; o[7] = f.t.y; o[8] = f.t.z;
+                break; }
+            case 20: {
+                if (!(a[12] >= 1.0f && a[13] >= 1.0f)) return -1;
+                Lens lens; memset(&lens, 0, sizeof lens);
+                lens.origin.x = a[0]; lens.origin.y = a[1]; lens.origin.z = a[2]; lens.forward.x = a[3]; lens.forward.y = a[4]; lens.forward.z = a[5];
+                lens.up.x = a[6]; lens.up.y = a[7]; lens.up.z = a[8]; lens.vfov = a[9]; lens.aperture = a[10]; lens.focus_distance = a[11];
+                v3 O, D; generate_ray(&lens, (uint32_t)a[12], (uint32_t)a[13], V2(a[14], a[15]), V2(a[16], a[17]), &O, &D);
+                o[0] = O.x; o[1] = O.y; o[2] = O.z; o[3] = D.x; o[4] = D.y; o[5] = D.z;
+                break; }
         }
     }
     return 0;

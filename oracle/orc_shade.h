@@ -67,6 +67,26 @@ static inline orc_frame frame_in_space(const orc_frame *f, const m34 *toMesh) { 
     return o;
 }
 
+/* the arithmetic of lookupAndInterpolate + inWorld (world.hlsl:122-176) on the three vertices' attributes; the renderer and OrcProbeBatch(18) both run this */
+static inline orc_attrs mesh_attributes_core(v3 p0, v3 p1, v3 p2, v2 t0, v2 t1, v2 t2, v3 n0, v3 n1, v3 n2, int has_normals, v3 bary, const m34 *toWorld, const m34 *toMesh) {
+    orc_attrs a;
+    a.position = interp3(bary, p0, p1, p2);
+    a.texcoord = interp2(bary, t0, t1, t2);
+    get_tangent_bitangent(p0, p1, p2, t0, t1, t2, &a.triangleFrame.s, &a.triangleFrame.t);
+    a.triangleFrame.n = v3normalize(v3cross(v3sub(p0, p2), v3sub(p1, p2)));
+    frame_reorthogonalize(&a.triangleFrame);
+    if (has_normals) {
+        a.frame = a.triangleFrame;
+        a.frame.n = v3normalize(interp3(bary, n0, n1, n2));
+        frame_reorthogonalize(&a.frame);
+    } else a.frame = a.triangleFrame;
+    /* inWorld */
+    a.position = m34_mul_point(toWorld, a.position);
+    a.triangleFrame = frame_in_space(&a.triangleFrame, toMesh);
+    a.frame = frame_in_space(&a.frame, toMesh);
+    return a;
+}
+
 /* lookupAndInterpolate(...).inWorld(...) world.hlsl:114-176 */
 static inline orc_attrs mesh_attributes_world(const OrcContext *c, uint32_t instanceIndex, uint32_t geometryIndex, uint32_t primitiveIndex, v2 attribs) {
     const orc_instance *inst = &c->instances[instanceIndex];
@@ -74,31 +94,17 @@ static inline orc_attrs mesh_attributes_world(const OrcContext *c, uint32_t inst
     const orc_geometry *g = &c->geometries[instanceID + geometryIndex];
     const orc_mesh *mesh = &c->meshes[g->mesh];
     v3 bary = V3(1.0f - attribs.x - attribs.y, attribs.x, attribs.y);
-    orc_attrs a;
     uint32_t i0 = mesh->indices[3 * primitiveIndex + 0], i1 = mesh->indices[3 * primitiveIndex + 1], i2 = mesh->indices[3 * primitiveIndex + 2];
     v3 p0 = mesh->positions[i0], p1 = mesh->positions[i1], p2 = mesh->positions[i2];
-    a.position = interp3(bary, p0, p1, p2);
     uint32_t a0, a1, a2;
     if (c->opts.indexed_attributes) { a0 = i0; a1 = i1; a2 = i2; }
     else { a0 = primitiveIndex * 3 + 0; a1 = primitiveIndex * 3 + 1; a2 = primitiveIndex * 3 + 2; }
     v2 t0, t1, t2;
     if (mesh->texcoords) { t0 = mesh->texcoords[a0]; t1 = mesh->texcoords[a1]; t2 = mesh->texcoords[a2]; }
     else { t0 = V2(0, 0); t1 = V2(1, 0); t2 = V2(1, 1); }
-    a.texcoord = interp2(bary, t0, t1, t2);
-    get_tangent_bitangent(p0, p1, p2, t0, t1, t2, &a.triangleFrame.s, &a.triangleFrame.t);
-    a.triangleFrame.n = v3normalize(v3cross(v3sub(p0, p2), v3sub(p1, p2)));
-    frame_reorthogonalize(&a.triangleFrame);
-    if (mesh->normals) {
-        v3 n0 = mesh->normals[a0], n1 = mesh->normals[a1], n2 = mesh->normals[a2];
-        a.frame = a.triangleFrame;
-        a.frame.n = v3normalize(interp3(bary, n0, n1, n2));
-        frame_reorthogonalize(&a.frame);
-    } else a.frame = a.triangleFrame;
-    /* inWorld */
-    a.position = m34_mul_point(&inst->transform, a.position);
-    a.triangleFrame = frame_in_space(&a.triangleFrame, &inst->world_to_instance);
-    a.frame = frame_in_space(&a.frame, &inst->world_to_instance);
-    return a;
+    v3 n0 = V3(0, 0, 0), n1 = n0, n2 = n0;
+    if (mesh->normals) { n0 = mesh->normals[a0]; n1 = mesh->normals[a1]; n2 = mesh->normals[a2]; }
+    return mesh_attributes_core(p0, p1, p2, t0, t1, t2, n0, n1, n2, mesh->normals != NULL, bary, &inst->transform, &inst->world_to_instance);
 }
 
 /* ---------------- material.hlsl ---------------- */
@@ -269,12 +275,10 @@ static inline orc_msample material_sample(const orc_mat *m, v3 wo, v2 sq) {
     }
 }
 
-/* material.hlsl:489-522 */
-static inline orc_frame get_texture_frame(const OrcContext *c, uint32_t materialIdx, v2 uv, const orc_frame *tangentFrame) {
-    const orc_material *m = &c->materials[materialIdx];
-    float o[4]; tex_sample_bilinear(&c->textures[m->normal], uv.x, uv.y, 0, o);
+/* material.hlsl:489-522: decodeNormal / tangentNormalToWorld / createTextureFrame on a sampled normal texel (renderer and OrcProbeBatch(19)) */
+static inline orc_frame texture_frame_from_texel(const float o[4], int two_component, const orc_frame *tangentFrame) {
     v3 nts;
-    if (c->opts.two_component_normal_texture) {
+    if (two_component) {
         float rx = o[0] * 2.0f - 1.0f, ry = o[1] * 2.0f - 1.0f;
         float dd = rx * rx + ry * ry;
         nts = V3(rx, ry, sqrtf(1.0f - orc_clampf(dd, 0.0f, 1.0f)));
@@ -282,6 +286,11 @@ static inline orc_frame get_texture_frame(const OrcContext *c, uint32_t material
     v3 nws = v3normalize(frame_frame_to_world(tangentFrame, nts));
     orc_frame f = *tangentFrame; f.n = nws; frame_reorthogonalize(&f);
     return f;
+}
+static inline orc_frame get_texture_frame(const OrcContext *c, uint32_t materialIdx, v2 uv, const orc_frame *tangentFrame) {
+    const orc_material *m = &c->materials[materialIdx];
+    float o[4]; tex_sample_bilinear(&c->textures[m->normal], uv.x, uv.y, 0, o);
+    return texture_frame_from_texel(o, c->opts.two_component_normal_texture, tangentFrame);
 }
 static inline v3 get_emissive(const OrcContext *c, uint32_t materialIdx, v2 uv) { return tex_sample_rgb(c, c->materials[materialIdx].emissive, uv); }
 

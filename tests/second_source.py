@@ -21,7 +21,8 @@ GLASS, LAMBERT, PERFECT_MIRROR, STANDARD_PBR = 0, 1, 2, 3   # world.hlsl:31-36 M
 PROBES = {"bsdf": (0, 15, 8), "env_sample": (1, 2, 7), "env_eval": (2, 3, 4), "env_incoming": (3, 3, 3), "equal_area": (4, 2, 3),
           "equal_area_inverse": (5, 3, 2), "triangle": (6, 2, 2), "gaussian": (7, 2, 2), "cosine_hemisphere": (8, 2, 3),
           "fresnel_dielectric": (9, 3, 1), "offset_along_normal": (10, 6, 3), "coordinate_system": (11, 3, 6),
-          "area_to_solid_angle": (12, 12, 1), "ggx": (13, 7, 3), "refract": (14, 7, 3), "power_heuristic": (15, 4, 1), "frame": (16, 9, 6), "texture": (17, 3, 4)}
+          "area_to_solid_angle": (12, 12, 1), "ggx": (13, 7, 3), "refract": (14, 7, 3), "power_heuristic": (15, 4, 1), "frame": (16, 9, 6), "texture": (17, 3, 4),
+          "mesh_attributes": (18, 51, 23), "texture_frame": (19, 13, 9), "camera": (20, 18, 6)}
 
 
 DTYPE = np.float64
@@ -427,6 +428,84 @@ class EnvMap:
         idx = np.clip(np.trunc(uv * s).astype(np.int64), 0, s)
         discrete = self.load(idx[..., 0], idx[..., 1], 0) * float(s * s) / self.integral()
         return self.load_rgb(idx[..., 0], idx[..., 1]), discrete / (4.0 * PI)
+
+
+# ------------------------------------------------------------------ world.hlsl:86-176 MeshAttributes
+def get_tangent_bitangent(p0, p1, p2, t0, t1, t2):
+    """world.hlsl:86-100"""
+    dt02, dt12 = t0 - t2, t1 - t2
+    dp02, dp12 = p0 - p2, p1 - p2
+    det = dt02[..., 0] * dt12[..., 1] - dt02[..., 1] * dt12[..., 0]
+    safe = np.where(det == 0, 1.0, det)[..., None]
+    tangent = normalize((dt12[..., 1:2] * dp02 - dt02[..., 1:2] * dp12) / safe)
+    bitangent = normalize((-dt12[..., 0:1] * dp02 + dt02[..., 0:1] * dp12) / safe)
+    a, b = coordinate_system(normalize(cross(p2 - p0, p1 - p0)))       # det == 0: coordinateSystem(n, tangent, bitangent)
+    flat = (det == 0)[..., None]
+    return np.where(flat, a, tangent), np.where(flat, b, bitangent)
+
+
+def interpolate(bary, v1, v2, v3):
+    """world.hlsl:102-105"""
+    return bary[..., 0:1] * v1 + bary[..., 1:2] * v2 + bary[..., 2:3] * v3
+
+
+def frame_in_space(m4x3, n, s, t):
+    """reflection_frame.hlsl:23-29: normalize(mul(m, v).xyz) with m a float4x3 (mul(matrix, vector): row i of m dot v)"""
+    f = lambda v: normalize(np.einsum("...ij,...j->...i", m4x3, v)[..., :3])
+    return f(n), f(s), f(t)
+
+
+def mesh_attributes(p0, p1, p2, t0, t1, t2, n0, n1, n2, attribs, has_texcoords, has_normals, to_world, to_mesh):
+    """MeshAttributes::lookupAndInterpolate(...).inWorld(...) on explicit vertex data.  to_world / to_mesh: (..., 3, 4) float3x4.
+    -> position, texcoord, (triangleFrame n, s, t), (frame n, s, t)"""
+    ht = np.asarray(has_texcoords, bool)[..., None]
+    t0 = np.where(ht, t0, _a([0.0, 0.0])); t1 = np.where(ht, t1, _a([1.0, 0.0])); t2 = np.where(ht, t2, _a([1.0, 1.0]))   # :137-141
+    bary = vec(1.0 - attribs[..., 0] - attribs[..., 1], attribs[..., 0], attribs[..., 1])
+    position = interpolate(bary, p0, p1, p2)
+    texcoord = interpolate(bary, t0, t1, t2)
+    ts, tt = get_tangent_bitangent(p0, p1, p2, t0, t1, t2)
+    tn = normalize(cross(p0 - p2, p1 - p2))
+    ts, tt = reorthogonalize(tn, ts)
+    fn_ = normalize(interpolate(bary, n0, n1, n2))
+    fs, ft = reorthogonalize(fn_, ts)                                   # attrs.frame = attrs.triangleFrame; frame.n = ...; reorthogonalize()
+    hn = np.asarray(has_normals, bool)[..., None]
+    fn_, fs, ft = np.where(hn, fn_, tn), np.where(hn, fs, ts), np.where(hn, ft, tt)
+    # inWorld (:164-175)
+    position = np.einsum("...ij,...j->...i", to_world, np.concatenate([position, np.ones_like(position[..., :1])], -1))
+    m = np.swapaxes(to_mesh, -1, -2)                                    # transpose(toMesh): float4x3
+    return position, texcoord, frame_in_space(m, tn, ts, tt), frame_in_space(m, fn_, fs, ft)
+
+
+# ------------------------------------------------------------------ material.hlsl:489-517
+def decode_normal(rg):
+    rg = rg * 2 - 1
+    return vec(rg[..., 0], rg[..., 1], np.sqrt(1.0 - np.clip(dot(rg, rg), 0.0, 1.0)))
+
+
+def texture_frame(texel_rgb, n, s, t, two_component):
+    """getTextureFrame after the SampleLevel: decodeNormal / tangentNormalToWorld / createTextureFrame -> (n, s, t)"""
+    two = np.asarray(two_component, bool)[..., None]
+    nts = np.where(two, decode_normal(texel_rgb[..., :2]), texel_rgb)
+    nws = normalize(frame_to_world(n, s, t, nts))
+    s2, t2 = reorthogonalize(nws, s)
+    return nws, s2, t2
+
+
+# ------------------------------------------------------------------ camera.hlsl:14-42
+def camera_generate_ray(origin, forward, up, vfov, aperture, focus_distance, width, height, uv, rand):
+    aspect = _a(width) / _a(height)
+    w = forward * -1.0
+    u = normalize(cross(up, w))
+    v = cross(w, u)
+    h = np.tan(vfov / 2.0)
+    viewport_height = 2.0 * h * focus_distance
+    viewport_width = aspect * viewport_height
+    horizontal = u * viewport_width[..., None]
+    vertical = v * viewport_height[..., None]
+    llc = origin - horizontal / 2.0 - vertical / 2.0 - w * focus_distance[..., None]
+    rd = aperture[..., None] * square_to_uniform_disk_concentric(rand) / 2.0
+    defocus = u * rd[..., 0:1] + v * rd[..., 1:2]
+    return origin + defocus, normalize(llc + uv[..., 0:1] * horizontal + uv[..., 1:2] * vertical - defocus - origin)
 
 
 # ------------------------------------------------------------------ image.SampleLevel(sampler, uv, 0)

@@ -114,6 +114,51 @@ def inputs(name, rs, n=N):
         x[:, 6:9] = unit_vectors(rs, n)
         ok = np.abs((x[:, 0:3] * s).sum(1)) < 0.98                        # a tangent (nearly) parallel to the normal is ill-posed
         return x[ok]
+    if name == "mesh_attributes":
+        x = np.zeros((n, 51), f)
+        c = rs.normal(size=(n, 1, 3)) * 3.0
+        x[:, 0:9] = (c + rs.normal(size=(n, 3, 3)) * 10.0 ** rs.uniform(-2, 0.5, (n, 1, 1))).reshape(n, 9)      # triangles of size 0.01 .. 3 around a centre
+        x[:, 9:15] = rs.uniform(-2, 3, (n, 6))
+        x[: n // 40, 11:15] = np.tile(x[: n // 40, 9:11], (1, 2))                                                 # all three texcoords equal: det == 0 exactly
+        p0, p1, p2 = x[:, 0:3].astype(np.float64), x[:, 3:6].astype(np.float64), x[:, 6:9].astype(np.float64)
+        gn = np.cross(p0 - p2, p1 - p2); gn /= np.linalg.norm(gn, axis=1, keepdims=True)
+        for k in range(3):                                                                                        # shading normals within ~35 degrees of the face normal, not unit length
+            v = gn + rs.normal(size=(n, 3)) * 0.3
+            x[:, 15 + 3 * k: 18 + 3 * k] = v * rs.uniform(0.5, 1.5, (n, 1))
+        b = rs.uniform(0, 1, (n, 2)); flip = b.sum(1) > 1; b[flip] = 1 - b[flip]
+        x[:, 24:26] = b; x[:16, 24:26] = [[0, 0], [1, 0], [0, 1], [0.5, 0.5]] * 4
+        x[:, 26] = rs.integers(0, 4, n)
+        # instance transform: rotation x (non-uniform) scale + translation, and its inverse as the reference computes it on the host in f32
+        q = rs.normal(size=(n, 3, 3)); q, _ = np.linalg.qr(q)
+        sc = 10.0 ** rs.uniform(-0.7, 0.7, (n, 1, 3)); sc[: n // 2] = sc[: n // 2, :, :1]                         # half uniform scales
+        A = q * sc; tr = rs.normal(size=(n, 3)) * 4
+        A[:64] = np.eye(3); tr[:64] = 0
+        tw = np.concatenate([A, tr[:, :, None]], 2).astype(f)
+        Ai = np.linalg.inv(tw[:, :, :3].astype(np.float64)); tm = np.concatenate([Ai, -(Ai @ tw[:, :, 3:].astype(np.float64))], 2).astype(f)
+        x[:, 27:39] = tw.reshape(n, 12); x[:, 39:51] = tm.reshape(n, 12)
+        return x
+    if name == "texture_frame":
+        x = np.zeros((n, 13), f)
+        x[:, 0:3] = rs.uniform(0, 1, (n, 3)); x[: n // 10, 0:2] = rs.choice([0.0, 1.0], (n // 10, 2)); x[:32, 0:2] = 0.5       # incl. rg whose decoded length exceeds 1 (the saturate), and the flat normal
+        nn = unit_vectors(rs, n, 0.0); s0 = unit_vectors(rs, n, 0.0)
+        ok = np.abs((nn * s0).sum(1)) < 0.9
+        s1 = s0 - nn * (nn * s0).sum(1, keepdims=True); s1 /= np.linalg.norm(s1, axis=1, keepdims=True)
+        x[:, 3:6] = nn; x[:, 6:9] = s1; x[:, 9:12] = np.cross(nn, s1)
+        x[:, 12] = rs.integers(0, 2, n)
+        x[x[:, 12] == 0, 0:3] = (unit_vectors(rs, n, 0.0) * [1, 1, 0.5] + [0, 0, 0.6])[x[:, 12] == 0]                 # three-component textures hold vectors, mostly +z
+        return x[ok]
+    if name == "camera":
+        x = np.zeros((n, 18), f)
+        x[:, 0:3] = rs.normal(size=(n, 3)) * 5
+        fw = unit_vectors(rs, n, 0.0); up = unit_vectors(rs, n, 0.0)
+        ok = np.abs((fw * up).sum(1)) < 0.95
+        x[:, 3:6] = fw; x[:, 6:9] = up
+        x[:, 9] = rs.uniform(0.2, 2.4, n)                       # vfov (radians)
+        x[:, 10] = rs.uniform(0, 0.5, n); x[: n // 4, 10] = 0   # aperture, a quarter pinhole
+        x[:, 11] = 10.0 ** rs.uniform(-1, 2, n)                 # focus distance
+        x[:, 12] = rs.integers(1, 4097, n); x[:, 13] = rs.integers(1, 4097, n)
+        x[:, 14:16] = rs.uniform(0, 1, (n, 2)); x[:, 16:18] = rs.uniform(0, 1, (n, 2)); x[:32, 16:18] = 0.5
+        return x[ok]
     raise KeyError(name)
 
 
@@ -168,6 +213,16 @@ def second(name, x, env=None, dtype=np.float64, images=None):
         if name == "frame":
             n = x[:, 0:3]; s, t = ss.reorthogonalize(n, x[:, 3:6]); v = x[:, 6:9]
             return np.concatenate([ss.world_to_frame(n, s, t, v), ss.frame_to_world(n, s, t, v)], 1)
+        if name == "mesh_attributes":
+            fl = x[:, 26].astype(int)
+            pos, tc, tf, fr = ss.mesh_attributes(x[:, 0:3], x[:, 3:6], x[:, 6:9], x[:, 9:11], x[:, 11:13], x[:, 13:15], x[:, 15:18], x[:, 18:21], x[:, 21:24],
+                                                 x[:, 24:26], (fl & 1) != 0, (fl & 2) != 0, x[:, 27:39].reshape(-1, 3, 4), x[:, 39:51].reshape(-1, 3, 4))
+            return np.concatenate([pos, tc, *tf, *fr], 1)
+        if name == "texture_frame":
+            return np.concatenate(ss.texture_frame(x[:, 0:3], x[:, 3:6], x[:, 6:9], x[:, 9:12], x[:, 12] != 0), 1)
+        if name == "camera":
+            o, d = ss.camera_generate_ray(x[:, 0:3], x[:, 3:6], x[:, 6:9], x[:, 9], x[:, 10], x[:, 11], x[:, 12], x[:, 13], x[:, 14:16], x[:, 16:18])
+            return np.concatenate([o, d], 1)
     raise KeyError(name)
 
 
@@ -198,6 +253,18 @@ def near_decision(name, x):
         bad |= np.abs(ei / et * np.sqrt(np.maximum(0, 1 - c * c)) - 1) < 1e-5
     if name == "coordinate_system":
         bad |= np.abs(np.abs(x[:, 0]) - np.abs(x[:, 1])) < 1e-6
+    if name == "mesh_attributes":   # getTangentBitangent's det == 0.0 switch: a determinant that is zero in one precision and merely tiny in the other
+        ht = (x[:, 26].astype(int) & 1) != 0
+        t0 = np.where(ht[:, None], x[:, 9:11], [0.0, 0.0]); t1 = np.where(ht[:, None], x[:, 11:13], [1.0, 0.0]); t2 = np.where(ht[:, None], x[:, 13:15], [1.0, 1.0])
+        a, b = t0 - t2, t1 - t2
+        det = a[:, 0] * b[:, 1] - a[:, 1] * b[:, 0]
+        scale = np.abs(a[:, 0] * b[:, 1]) + np.abs(a[:, 1] * b[:, 0])
+        bad |= (det != 0) & (np.abs(det) < 1e-5 * scale)
+    if name == "texture_frame":     # a texture normal (nearly) along the tangent leaves Gram-Schmidt nothing to work with: ill-posed, as for "frame"
+        two = x[:, 12] != 0
+        rg = x[:, 0:2] * 2 - 1
+        nts = np.where(two[:, None], np.concatenate([rg, np.sqrt(1 - np.clip((rg * rg).sum(1, keepdims=True), 0, 1))], 1), x[:, 0:3])
+        bad |= np.abs(nts[:, 0]) > 0.98 * np.linalg.norm(nts, axis=1)
     return bad
 
 
@@ -206,7 +273,9 @@ def near_decision(name, x):
 # vector as a whole is as accurate as f32 gets.  name -> [(first, last+1, fixed scale or None for the vector's own length)]
 VECTOR_GROUPS = {"texture": [(0, 4, 1.0)], "env_incoming": [(0, 3, None)], "bsdf": [(4, 7, None)], "env_sample": [(0, 3, None)], "equal_area": [(0, 3, None)], "cosine_hemisphere": [(0, 3, None)],
                  "coordinate_system": [(0, 3, None), (3, 6, None)], "refract": [(0, 3, None)], "frame": [(0, 3, None), (3, 6, None)],
-                 "triangle": [(0, 2, 1.0)], "gaussian": [(0, 2, None)], "equal_area_inverse": [(0, 2, 1.0)], "offset_along_normal": [(0, 3, None)]}
+                 "triangle": [(0, 2, 1.0)], "gaussian": [(0, 2, None)], "equal_area_inverse": [(0, 2, 1.0)], "offset_along_normal": [(0, 3, None)],
+                 "mesh_attributes": [(0, 3, None), (3, 5, None), (5, 8, 1.0), (8, 11, 1.0), (11, 14, 1.0), (14, 17, 1.0), (17, 20, 1.0), (20, 23, 1.0)],
+                 "texture_frame": [(0, 3, 1.0), (3, 6, 1.0), (6, 9, 1.0)], "camera": [(0, 3, None), (3, 6, 1.0)]}
 
 
 def magnitude(name, ref):
@@ -234,6 +303,15 @@ def check_values(name, got, x, env=None, rel=1e-5, images=None):
     assert np.isfinite(got[finite & ~skip]).all(), "%s: non-finite output where the reference formula is finite" % name
     use = finite & ~skip
     noise = np.abs(ref32 - ref)
+    if name == "env_sample":
+        # The mip descent rescales the random number at every level ((r - p) / (1 - p) or r / p): choosing a texel of probability P leaves
+        # the position inside it with ~24 - log2(1/P) bits, whatever the order of the f32 operations.  |ref32 - ref| samples that loss once;
+        # the sensitivity to a one-ulp change of the INPUT bounds it: both are rounding noise of the reference's formula at that input.
+        x32 = x.astype(np.float32)
+        for toward in (np.float32(2.0), np.float32(-1.0)):
+            moved = second(name, np.nextafter(x32, toward), env, np.float64, images)
+            same_texel = np.abs(moved[:, 6] - ref[:, 6]) <= 1e-9 * np.abs(ref[:, 6])
+            noise = np.maximum(noise, np.where(same_texel[:, None], np.abs(moved - ref), 0.0))
     mag = magnitude(name, ref)
     tol = rel * mag + 8.0 * noise + 1e-7
     err = np.abs(got - ref)
@@ -251,7 +329,8 @@ def check_values(name, got, x, env=None, rel=1e-5, images=None):
 
 
 STATELESS = ["bsdf", "equal_area", "equal_area_inverse", "triangle", "gaussian", "cosine_hemisphere", "fresnel_dielectric",
-             "offset_along_normal", "coordinate_system", "area_to_solid_angle", "ggx", "refract", "power_heuristic", "frame"]
+             "offset_along_normal", "coordinate_system", "area_to_solid_angle", "ggx", "refract", "power_heuristic", "frame",
+             "mesh_attributes", "texture_frame", "camera"]
 ENV = ["env_sample", "env_eval", "env_incoming", "texture"]
 
 
@@ -331,6 +410,7 @@ def run_value_checks(probe, names):
 def test_oracle_matches_second_source_values(orc):
     rep = run_value_checks(OrcProbe(orc), STATELESS + ENV)
     assert all(r["records"] >= 10000 for k, r in rep.items() if k != "frame"), rep
+    print(rep)
 
 
 @pytest.mark.gpu
