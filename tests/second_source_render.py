@@ -15,6 +15,7 @@ import numpy as np
 from tests import second_source as ss
 
 MAX_UINT = 0xFFFFFFFF
+RR_AFTER_BOUNCE = 3      # integrator.hlsl:130 `bounceCount > 3` (a module constant so that a test can show the comparison notices a different one)
 
 
 # ---------------------------------------------------------------------------------------------------------------- random.hlsl
@@ -316,7 +317,7 @@ def incoming_radiance(sc, o, d, rng, stats=None):
         acc[idx] += thr[idx] * add
         # termination (:128-135)
         stop = bounce[idx] >= max_b + 1
-        rr = ~stop & (bounce[idx] > 3)
+        rr = ~stop & (bounce[idx] > RR_AFTER_BOUNCE)
         if rr.any():
             k = idx[rr]
             p = np.minimum(0.95, ss.luminance(thr[k]))

@@ -182,3 +182,24 @@ def test_alias_table_restatement_is_a_distribution():
         if select[i] < 1.0:
             p[int(alias[i])] += (1.0 - float(select[i])) / len(w)
     assert np.allclose(p, w / w.sum(), rtol=1e-5, atol=1e-7) and abs(float(total) - float(w.sum())) < 1e-4
+
+
+@pytest.mark.parametrize("mutation", ["float2_order", "no_face_forward", "rr_one_bounce_early", "light_sample_count_in_mis"])
+def test_comparison_catches_mutations_of_the_restatement(orc, monkeypatch, mutation):
+    """the pixel-by-pixel comparison is sensitive: a restatement that consumes the two floats of a float2 in the other order, offsets the next ray along the
+    unflipped normal, starts Russian roulette one bounce early or forgets the light-sample count in the MIS weight no longer matches the oracle"""
+    if mutation == "float2_order":
+        def get2(self, idx):
+            b = self.get(idx); a = self.get(idx)
+            return np.stack([a, b], -1)
+        monkeypatch.setattr(ssr.Rng, "get2", get2)
+    elif mutation == "no_face_forward":
+        monkeypatch.setattr(ssr.ss, "face_forward", lambda n, d: n)
+    elif mutation == "rr_one_bounce_early":
+        monkeypatch.setattr(ssr, "RR_AFTER_BOUNCE", 2)
+    else:
+        real = ssr.ss.power_heuristic
+        monkeypatch.setattr(ssr.ss, "power_heuristic", lambda nf, f, ng, g: real(1, f, 1, g))
+    spec = spec_mixed() if mutation != "light_sample_count_in_mis" else spec_lights()
+    with pytest.raises(AssertionError):
+        compare(orc.Context(threads=8), spec, launches=1)
