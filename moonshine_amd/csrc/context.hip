@@ -32,6 +32,7 @@ void launch_unpack_film(hipStream_t, int, const ShardView&, const float4*, uint3
 bool shade_probe_widths(int, uint32_t&, uint32_t&);
 void launch_shade_probe(hipStream_t, const SceneView&, int, const float*, uint32_t, float*);
 void launch_env_build(hipStream_t, const float4*, uint32_t, uint32_t, float4*, float*, const uint32_t*, uint32_t, uint32_t);
+void launch_env_quads(hipStream_t, const float*, const uint32_t*, float4*, const uint32_t*, uint32_t, uint32_t);
 struct BlasGeo { const float* positions; const uint32_t* indices; uint32_t tri_offset, tri_count, geo, inst; const float* normals; const float* texcoords; uint32_t indexed, attr_count; };
 struct BuildScratch;   // per-context build buffers (bvh_build.hip)
 BuildScratch* bvh_scratch_create();
@@ -127,7 +128,7 @@ struct HdMoonshine {
     uint32_t tlas_root = MAX_UINT, root_in_blas = 0;
     std::vector<AliasEntry> h_alias;
     // environment
-    DevBuf<float4> d_env_rgb; DevBuf<float> d_env_lum; EnvView env{};
+    DevBuf<float4> d_env_rgb, d_env_quads; DevBuf<float> d_env_lum; EnvView env{};
     // wavefront
     // A pipe = one independent wavefront pipeline (state ping-pong, hit/shadow queues, counters, two streams).  A batch of
     // launches is split over up to n_pipes pipes that run concurrently: while one pipe is in the thin tail of a bounce
@@ -522,9 +523,18 @@ bool HdMoonshine::set_background(const float* rgba, Extent2D e) {
     if (!d_env_lum.alloc(total)) { fail("out of device memory (background)"); return false; }
     CHECK_HIP(this, hipMemcpyAsync(src.p, rgba, (size_t)e.width * e.height * 16, hipMemcpyHostToDevice, stream));
     launch_env_build(stream, src.p, e.width, e.height, d_env_rgb.p, d_env_lum.p, off, S, mips);
+    size_t nquads = 0; uint32_t qoff[12] = { 0 };
+    for (uint32_t l = 0; l + 1 < mips; l++) { qoff[l] = (uint32_t)nquads; nquads += (size_t)((S >> l) / 2) * ((S >> l) / 2); }
+    if (nquads) {
+        if (!d_env_quads.alloc(nquads)) { fail("out of device memory (background)"); return false; }
+        launch_env_quads(stream, d_env_lum.p, off, d_env_quads.p, qoff, S, mips);
+    }
+    float top = 0.0f;
+    CHECK_HIP(this, hipMemcpyAsync(&top, d_env_lum.p + off[mips - 1], 4, hipMemcpyDeviceToHost, stream));
     CHECK_HIP(this, hipStreamSynchronize(stream));
     env.rgb = d_env_rgb.p; env.lum = d_env_lum.p; env.size = S; env.mip_count = mips;
-    for (int l = 0; l < 12; l++) env.lum_offset[l] = off[l];
+    env.quads = nquads ? d_env_quads.p : nullptr; env.top = top;
+    for (int l = 0; l < 12; l++) { env.lum_offset[l] = off[l]; env.quad_offset[l] = qoff[l]; }
     clear_all_sensors();
     return true;
 }

@@ -40,6 +40,21 @@ __global__ __launch_bounds__(64) void k_env_fold(const float* srcm, float* dstm,
                             + srcm[(size_t)(2 * y + 1) * sd + 2 * x] + srcm[(size_t)(2 * y + 1) * sd + 2 * x + 1];
 }
 
+// one float4 per 2x2 quad of a level: the four texels one step of the mip descent (light.hlsl:52-66) reads
+__global__ __launch_bounds__(64) void k_env_quads(const float* level, float4* quads, uint32_t d /* quads per side = level size / 2 */) {
+    const uint32_t x = blockIdx.x * 8 + threadIdx.x, y = blockIdx.y * 8 + threadIdx.y;
+    if (x >= d || y >= d) return;
+    const uint32_t sd = d * 2;
+    quads[(size_t)y * d + x] = make_float4(level[(size_t)(2 * y) * sd + 2 * x], level[(size_t)(2 * y + 1) * sd + 2 * x],
+                                           level[(size_t)(2 * y) * sd + 2 * x + 1], level[(size_t)(2 * y + 1) * sd + 2 * x + 1]);
+}
+void launch_env_quads(hipStream_t s, const float* lum, const uint32_t* lum_offset, float4* quads, const uint32_t* quad_offset, uint32_t S, uint32_t mips) {
+    for (uint32_t l = 0; l + 1 < mips; l++) {
+        const uint32_t d = (S >> l) / 2;
+        hipLaunchKernelGGL(k_env_quads, dim3((d + 7) / 8, (d + 7) / 8, 1), dim3(8, 8, 1), 0, s, lum + lum_offset[l], quads + quad_offset[l], d);
+    }
+}
+
 void launch_env_build(hipStream_t s, const float4* src, uint32_t sw, uint32_t sh_, float4* rgb, float* lum, const uint32_t* lum_offset, uint32_t S, uint32_t mips) {
     const dim3 blk(8, 8, 1);
     const dim3 grid((S + 7) / 8, (S + 7) / 8, 1);

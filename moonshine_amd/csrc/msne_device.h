@@ -69,6 +69,11 @@ struct EnvView {
     const float* lum;         // luminance pyramid, level l at lum + lum_offset[l], (S>>l)^2 texels
     uint32_t lum_offset[12];
     uint32_t size, mip_count;
+    // The same pyramid once more, packed for EnvMap::sample's descent: level l (2x2 and larger) as one float4 per 2x2 quad, {(x,y), (x,y+1), (x+1,y), (x+1,y+1)}
+    // of the quad whose corner is (x, y) = 2 * (parent texel) — everything one level of the descent reads, in one 16-B load instead of two dependent rounds of loads.
+    const float4* quads;      // level l at quads + quad_offset[l], ((S>>l)/2)^2 quads; nullptr for a 1x1 map
+    uint32_t quad_offset[12];
+    float top;                // the single texel of the last level (the map's integral)
 };
 
 struct SceneView {

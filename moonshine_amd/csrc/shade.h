@@ -321,17 +321,25 @@ __device__ __forceinline__ f3 env_rgb_load(const EnvView& e, uint32_t x, uint32_
 __device__ __forceinline__ LSample env_sample_unoccluded(const EnvView& e, f2 rand) {
     const uint32_t size = e.size, mipCount = e.mip_count;
     uint32_t ix = 0, iy = 0;
+    // One level of the descent reads the 2x2 quad at (2 ix, 2 iy): the last level is the single texel e.top and three reads out of bounds (0);
+    // every other level is one float4 of the quad-packed copy.  Same values, same operations, same order as the texel-by-texel form.
+    float4 q = make_float4(e.top, 0.0f, 0.0f, 0.0f);
+    float chosen = e.top;   // the texel the descent stands on: after level 0 it is luminanceTexture[idx]
     for (uint32_t level = mipCount; level-- > 0;) {
+        if (level + 1 != mipCount) q = e.quads[e.quad_offset[level] + (size_t)iy * ((size >> level) >> 1) + ix];   // (ix, iy) still name the parent texel here
         ix *= 2; iy *= 2;
-        const float px = env_lum_load(e, ix + 0, iy + 0, level) + env_lum_load(e, ix + 0, iy + 1, level);
-        const float py = env_lum_load(e, ix + 1, iy + 0, level) + env_lum_load(e, ix + 1, iy + 1, level);
-        ix += coin_flip_remap(py / (px + py), rand.x) ? 1u : 0u;
-        const float qx = env_lum_load(e, ix + 0, iy + 0, level);
-        const float qy = env_lum_load(e, ix + 0, iy + 1, level);
-        iy += coin_flip_remap(qy / (qx + qy), rand.y) ? 1u : 0u;
+        const float px = q.x + q.y;
+        const float py = q.z + q.w;
+        const bool right = coin_flip_remap(py / (px + py), rand.x);
+        ix += right ? 1u : 0u;
+        const float qx = right ? q.z : q.x;
+        const float qy = right ? q.w : q.y;
+        const bool down = coin_flip_remap(qy / (qx + qy), rand.y);
+        iy += down ? 1u : 0u;
+        chosen = down ? qy : qx;
     }
-    const float integral = env_lum_load(e, 0, 0, mipCount - 1);
-    const float discretePdf = env_lum_load(e, ix, iy, 0) * (float)(size * size) / integral;
+    const float integral = e.top;
+    const float discretePdf = chosen * (float)(size * size) / integral;
     const f2 uv = F2(((float)ix + rand.x) / (float)size, ((float)iy + rand.y) / (float)size);
     LSample ls;
     ls.pdf = discretePdf / (4.0f * PI);
