@@ -238,7 +238,7 @@ bool HdMoonshine::upload_textures() {
         CHECK_HIP(this, hipMemcpyAsync(d_texels.p + desc[i].offset, textures[i].rgba.data(), textures[i].rgba.size() * 4, hipMemcpyHostToDevice, stream));
     if (!desc.empty()) CHECK_HIP(this, hipMemcpyAsync(d_texdesc.p, desc.data(), desc.size() * sizeof(TexDesc), hipMemcpyHostToDevice, stream));
     CHECK_HIP(this, hipStreamSynchronize(stream));
-    textures_dirty = false;
+    textures_dirty = false; lights_dirty = true;   // (the gathered light triangles hold texture descriptors)
     return true;
 }
 
@@ -268,7 +268,7 @@ bool HdMoonshine::upload_materials() {
     if (!d_materials.alloc(materials.size())) { fail("out of device memory (materials)"); return false; }
     if (!materials.empty()) CHECK_HIP(this, hipMemcpyAsync(d_materials.p, materials.data(), materials.size() * sizeof(MaterialRec), hipMemcpyHostToDevice, stream));
     CHECK_HIP(this, hipStreamSynchronize(stream));
-    materials_dirty = false;
+    materials_dirty = false; lights_dirty = true;   // (... of their materials' emissive textures)
     return true;
 }
 

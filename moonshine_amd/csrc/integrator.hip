@@ -68,6 +68,9 @@ __global__ void k_light_tris(SceneView sc, uint32_t indexed_attributes, uint32_t
     LightTri r;
     r.p0x = r.p0y = r.p0z = r.p1x = r.p1y = r.p1z = r.p2x = r.p2y = r.p2z = 0.0f;
     r.t0x = 0.0f; r.t0y = 0.0f; r.t1x = 1.0f; r.t1y = 0.0f; r.t2x = 1.0f; r.t2y = 1.0f; r.material = 0;
+    r.nx = r.ny = r.nz = 0.0f; r.instance = en.instance;
+    for (int k = 0; k < 12; k++) r.to_world[k] = 0.0f;
+    r.emissive.offset = 0; r.emissive.w = 1; r.emissive.h = 1; r.emissive.pad = 0; r.emissive.first = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
     if (en.instance < n_instances) {
         const GeometryRec g = sc.geometries[sc.instances[en.instance].geo_offset + en.geometry];
         const MeshRec mesh = sc.meshes[g.mesh];
@@ -80,6 +83,12 @@ __global__ void k_light_tris(SceneView sc, uint32_t indexed_attributes, uint32_t
             r.t0x = t0.x; r.t0y = t0.y; r.t1x = t1.x; r.t1y = t1.y; r.t2x = t2.x; r.t2y = t2.y;
         }
         r.material = g.material;
+        const InstanceRec* inst = sc.instances + en.instance;
+        const m34 tw = inst->transform, tm = inst->world_to_instance;
+        for (int a = 0; a < 3; a++) for (int b = 0; b < 4; b++) r.to_world[4 * a + b] = tw.m[a][b];
+        const f3 n = normalize(m34_mul_transposed(tm, normalize(cross(sub(p0, p2), sub(p1, p2)))));   // triangleFrame.n after inWorld(): world.hlsl:145,171 + reflection_frame.hlsl:24
+        r.nx = n.x; r.ny = n.y; r.nz = n.z;
+        r.emissive = sc.textures[sc.materials[g.material].emissive];
     }
     out[i] = r;
 }
@@ -303,22 +312,25 @@ __global__ __launch_bounds__(SHADE_BLOCK, 3) void k_shade(SceneView sc, Pipeline
                         const float scaled = rand.x * (float)entryCount;
                         uint32_t idx = (uint32_t)scaled;
                         rand.x = scaled - floor_(scaled);
-                        AliasEntry en = alias_load(sc, entryCount, 1 + idx);
-                        if (!coin_flip_remap(en.select, rand.x)) { idx = en.alias; en = alias_load(sc, entryCount, 1 + idx); }
+                        const AliasEntry en = alias_load(sc, entryCount, 1 + idx);
+                        if (!coin_flip_remap(en.select, rand.x)) idx = en.alias;
                         const f2 bary = square_to_triangle(rand);
                         // MeshAttributes::lookupAndInterpolate(...).inWorld(...) (world.hlsl:114-176) from the light's gathered record
                         // (position, texcoord and triangle normal are all the light sample uses; same operations, same order)
                         const uint4* lp = reinterpret_cast<const uint4*>(sc.light_tris + (idx < entryCount ? idx : entryCount));
-                        const uint4 la = lp[0], lb = lp[1], lc = lp[2], ld = lp[3];
-                        const InstanceRec* linst = sc.instances + en.instance;
-                        const m34 ltoWorld = linst->transform, ltoMesh = linst->world_to_instance;
+                        const uint4 la = lp[0], lb = lp[1], lc = lp[2], ld = lp[3], le = lp[4], lf = lp[5], lg = lp[6], lh = lp[7], li = lp[8], lj = lp[9];
+                        m34 ltoWorld;
+                        ltoWorld.m[0][0] = u2f(lf.x); ltoWorld.m[0][1] = u2f(lf.y); ltoWorld.m[0][2] = u2f(lf.z); ltoWorld.m[0][3] = u2f(lf.w);
+                        ltoWorld.m[1][0] = u2f(lg.x); ltoWorld.m[1][1] = u2f(lg.y); ltoWorld.m[1][2] = u2f(lg.z); ltoWorld.m[1][3] = u2f(lg.w);
+                        ltoWorld.m[2][0] = u2f(lh.x); ltoWorld.m[2][1] = u2f(lh.y); ltoWorld.m[2][2] = u2f(lh.z); ltoWorld.m[2][3] = u2f(lh.w);
+                        TexDesc t_light; t_light.offset = li.x; t_light.w = li.y; t_light.h = li.z; t_light.pad = 0u; t_light.first = make_float4(u2f(lj.x), u2f(lj.y), u2f(lj.z), u2f(lj.w));
                         const f3 lp0 = F3(u2f(la.x), u2f(la.y), u2f(la.z)), lp1 = F3(u2f(la.w), u2f(lb.x), u2f(lb.y)), lp2 = F3(u2f(lb.z), u2f(lb.w), u2f(lc.x));
                         const f3 lbary = F3(1.0f - bary.x - bary.y, bary.x, bary.y);
                         const f3 at_position = m34_mul_point(ltoWorld, interp3(lbary, lp0, lp1, lp2));
                         const f2 at_texcoord = interp2(lbary, F2(u2f(lc.y), u2f(lc.z)), F2(u2f(lc.w), u2f(ld.x)), F2(u2f(ld.y), u2f(ld.z)));
-                        const f3 at_n = normalize(m34_mul_transposed(ltoMesh, normalize(cross(sub(lp0, lp2), sub(lp1, lp2)))));
+                        const f3 at_n = F3(u2f(le.x), u2f(le.y), u2f(le.z));
                         LSample ls;
-                        ls.radiance = tex_sample_rgb(sc, sc.materials[ld.w].emissive, at_texcoord);
+                        { const float4 em = tex_sample_desc(sc, t_light, at_texcoord); ls.radiance = F3(em.x, em.y, em.z); }
                         ls.dirWs = normalize(sub(at_position, attrs.position));
                         ls.pdf = area_to_solid_angle(at_position, attrs.position, ls.dirWs, at_n) / sum;
                         if (ls.pdf > 0.0f) {

@@ -59,10 +59,18 @@ struct alignas(16) MaterialRec { uint32_t normal, emissive, type, color, metalne
 struct alignas(16) TexDesc { uint32_t offset, w, h, pad; float4 first; };
 struct AliasEntry { uint32_t alias; float select; uint32_t instance, geometry, primitive; };  // light.hlsl:17-22,112-116 (20 B)
 // What MeshLights::sample (light.hlsl:130-158) needs of alias entry i, gathered once per scene: the object-space vertices and
-// texcoords of the emissive triangle and its material — one 64-B load per light sample instead of the chain
+// texcoords of the emissive triangle and its material — one record per light sample instead of the chain
 // instance → geometry → mesh → indices → positions.  Entry [count] stands for the all-zero entry of an out-of-range index.
-struct alignas(16) LightTri { float p0x, p0y, p0z, p1x, p1y, p1z, p2x, p2y, p2z, t0x, t0y, t1x, t1y, t2x, t2y; uint32_t material; };
-static_assert(sizeof(LightTri) == 64, "LightTri must be 64 bytes");
+struct alignas(16) LightTri {
+    float p0x, p0y, p0z, p1x, p1y, p1z, p2x, p2y, p2z, t0x, t0y, t1x, t1y, t2x, t2y; uint32_t material;
+    // ... and what else MeshLights::sample (light.hlsl:130-158) fetches through indices after it: the triangle's world-space normal exactly as
+    // inWorld() derives it (it does not depend on the sampled point), the instance's object-to-world matrix, and the descriptor of the material's
+    // emissive texture.  A light sample is then alias entry -> this record -> (texel), not alias -> alias -> record -> instance -> material -> descriptor -> texel.
+    float nx, ny, nz; uint32_t instance;
+    float to_world[12];
+    TexDesc emissive;
+};
+static_assert(sizeof(LightTri) == 160, "LightTri must be 160 bytes");
 
 struct EnvView {
     const float4* rgb;        // S*S equal-area map
