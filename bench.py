@@ -215,6 +215,11 @@ def main():
             roof["valu"] = {"issue_busy_frac": k["valu_issue_busy_frac"], "lanes_per_instruction": k["lanes_per_valu_instruction"],
                             "thread_instructions_per_unit": k["valu_thread_instructions_per_unit"], "wave_instructions_per_unit": k["valu_wave_instructions_per_unit"],
                             "source": "profiles/" + cnt_file}
+        if roof["traffic"] and avg_ms > 0:
+            roof["traffic_frac"] = roof["traffic"] / (avg_ms * 1e-3) / HBM_PEAK    # measured HBM bytes against the same peak
+        if roof["frac"] > 1.0:
+            roof["note"] += ("; frac > 1: most of the algorithmic bytes are re-reads of BVH nodes that L2 / Infinity Cache serve (the scene's BVH is smaller than the cache), "
+                             "so HBM is not what bounds this kernel — measured traffic is `traffic_frac` of peak — VALU issue is (`valu.issue_busy_frac`, `valu.lanes_per_instruction` of 64)")
         rates = [rays / t / 1e6 for t in times]
         out = {
             "metric": "Mrays/sec, 1M-tri scene @1080p" if a.scene == "s1" else "Mrays/sec, 10M-tri instanced scene @1080p",
