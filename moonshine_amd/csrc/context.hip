@@ -62,7 +62,7 @@ template <typename T> struct DevBuf {
     DevBuf() = default; DevBuf(const DevBuf&) = delete; DevBuf& operator=(const DevBuf&) = delete;
 };
 
-struct TextureH { uint32_t w, h; std::vector<float> rgba; };
+struct TextureH { uint32_t w, h; std::vector<float> rgba; float first[4]; size_t offset = 0; bool on_device = false; };   // rgba: float RGBA texels until they are on the device, then released
 struct MeshH {
     DevBuf<float> positions, normals, texcoords; DevBuf<uint32_t> indices;
     std::vector<float> h_positions; std::vector<uint32_t> h_indices;   // host copies for the alias-table areas (Accel.zig:503-519)
@@ -110,7 +110,7 @@ struct HdMoonshine {
     std::vector<SensorH*> sensors;
 
     // device scene tables
-    DevBuf<float4> d_texels; DevBuf<TexDesc> d_texdesc;
+    DevBuf<float4> d_texels; DevBuf<TexDesc> d_texdesc; size_t texels_end = 0;   // texels of the textures already on the device
     DevBuf<MaterialRec> d_materials;
     DevBuf<MeshRec> d_meshes;
     DevBuf<GeometryRec> d_geometries;
@@ -224,20 +224,36 @@ static int64_t add_texture(HdMoonshine* c, const void* bytes, uint32_t w, uint32
             case MSNE_FORMAT_R16G16B16A16_SFLOAT: o[0] = half_to_float(hf[4 * i]); o[1] = half_to_float(hf[4 * i + 1]); o[2] = half_to_float(hf[4 * i + 2]); o[3] = half_to_float(hf[4 * i + 3]); break;
         }
     }
+    memcpy(t.first, t.rgba.data(), 16);
     c->textures.push_back(std::move(t));
     c->textures_dirty = true;
     return (int64_t)c->textures.size() - 1;
 }
 
+// Textures are append-only (the reference never frees one either, MaterialManager.zig): the texel pool grows like the triangle pools — what is already
+// on the device is moved device-to-device, only new textures cross PCIe, and their host copies are released once they are uploaded, so a scene with
+// gigabytes of texels keeps them once, in HBM, as float RGBA (16 B per texel whatever the source format: the decode is paid at creation, not per lookup).
 bool HdMoonshine::upload_textures() {
-    size_t total = 0;
+    size_t end = texels_end, total = texels_end;
+    for (auto& t : textures) if (!t.on_device) { t.offset = total; total += (size_t)t.w * t.h; }
+    if (total > 0xFFFFFFFFull) { fail("more than 2^32 texels"); return false; }
+    if (total > d_texels.n || !d_texels.p) {
+        DevBuf<float4> nt; if (!nt.alloc(total + total / 4 + 16)) { fail("out of device memory (textures)"); return false; }
+        if (end) CHECK_HIP(this, hipMemcpyAsync(nt.p, d_texels.p, end * sizeof(float4), hipMemcpyDeviceToDevice, stream));
+        CHECK_HIP(this, hipStreamSynchronize(stream));
+        std::swap(nt.p, d_texels.p); std::swap(nt.n, d_texels.n);
+    }
     std::vector<TexDesc> desc(textures.size());
-    for (size_t i = 0; i < textures.size(); i++) { desc[i] = TexDesc{ (uint32_t)total, textures[i].w, textures[i].h, 0, make_float4(textures[i].rgba[0], textures[i].rgba[1], textures[i].rgba[2], textures[i].rgba[3]) }; total += (size_t)textures[i].w * textures[i].h; }
-    if (!d_texels.alloc(total) || !d_texdesc.alloc(desc.size())) { fail("out of device memory (textures)"); return false; }
-    for (size_t i = 0; i < textures.size(); i++)
-        CHECK_HIP(this, hipMemcpyAsync(d_texels.p + desc[i].offset, textures[i].rgba.data(), textures[i].rgba.size() * 4, hipMemcpyHostToDevice, stream));
+    for (size_t i = 0; i < textures.size(); i++) {
+        TextureH& t = textures[i];
+        desc[i] = TexDesc{ (uint32_t)t.offset, t.w, t.h, 0, make_float4(t.first[0], t.first[1], t.first[2], t.first[3]) };
+        if (!t.on_device) CHECK_HIP(this, hipMemcpyAsync(d_texels.p + t.offset, t.rgba.data(), t.rgba.size() * 4, hipMemcpyHostToDevice, stream));
+    }
+    if (!d_texdesc.alloc(desc.size())) { fail("out of device memory (textures)"); return false; }
     if (!desc.empty()) CHECK_HIP(this, hipMemcpyAsync(d_texdesc.p, desc.data(), desc.size() * sizeof(TexDesc), hipMemcpyHostToDevice, stream));
     CHECK_HIP(this, hipStreamSynchronize(stream));
+    for (auto& t : textures) if (!t.on_device) { t.on_device = true; std::vector<float>().swap(t.rgba); }
+    texels_end = total;
     textures_dirty = false; lights_dirty = true;   // (the gathered light triangles hold texture descriptors)
     return true;
 }

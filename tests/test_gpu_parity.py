@@ -483,6 +483,33 @@ def test_unsupported_pipeline_is_rejected_loudly(gpu_api):
 
 
 @pytest.mark.gpu
+def test_textures_added_between_renders_keep_the_earlier_ones(orc, gpu_api):
+    """the texel pool grows in place (device-to-device move, host copies are released after upload): textures created after a render — here enough
+    of them to outgrow the pool several times — leave the earlier ones intact, and every stage equals the oracle"""
+    P, I = scenes.icosphere(2)
+    uv = np.stack([np.arctan2(P[:, 1], P[:, 0]) / (2 * math.pi) + 0.5, np.arccos(np.clip(P[:, 2], -1, 1)) / math.pi], -1).astype(np.float32)
+    rs = np.random.default_rng(21)
+    images = [rs.random((16 << (k % 3), 16 << (k % 3), 4)).astype(np.float32) for k in range(9)]
+    films = {}
+    for name, c in (("gpu", gpu_api.Context()), ("orc", orc.Context(threads=8))):
+        mesh = c.create_mesh(P, I, texcoords=uv)
+        s = c.create_sensor(40, 32); l = c.create_lens(c.make_lens((-6, 0.5, 0.8), (1, 0, 0), (0, 0, 1), 0.9))
+        c.set_pipeline(samples_per_run=1, max_bounces=4, env_samples_per_bounce=1, mesh_samples_per_bounce=0)
+        flat, black = c.solid_texture(0.5, 0.5), c.solid_texture(0.0, 0.0, 0.0)
+        for stage in range(3):
+            for k in range(3 * stage, 3 * stage + 3):
+                img = images[k]
+                t = c.create_texture(img, img.shape[1], img.shape[0], "r32g32b32a32_sfloat")
+                m = c.create_material(scenes.LAMBERT, flat, black, color=t)
+                T = np.zeros((3, 4), np.float32); T[:, :3] = np.eye(3) * 0.8; T[:, 3] = (0.0, 2.0 * (k % 3) - 2.0, 2.0 * stage - 2.0)
+                c.create_instance([(mesh, m, False)], transform=T)
+            c.clear_sensor(s); c.render(s, l, launches=3)
+            films[name, stage] = c.sensor_data(s).copy()
+    for stage in range(3):
+        assert_film_equal(films["gpu", stage], films["orc", stage], "texture stage %d" % stage)
+
+
+@pytest.mark.gpu
 def test_attribute_mode_switch_regathers_triangle_attributes(orc, gpu_api):
     """The per-triangle attribute records are gathered at BLAS build for the pipeline's mode (by vertex index / by corner, world.hlsl:127-135).
     Flipping indexed_attributes on a live context — the arrays cover both readings — must re-gather them: every mode, in either
