@@ -72,10 +72,44 @@ __global__ void k_bounds(const Box* boxes, uint32_t n, uint32_t* bounds /*6 orde
     else if (threadIdx.x < 6) atomicMax(&bounds[threadIdx.x], s[threadIdx.x]);
 }
 
-__global__ void k_morton(const Box* boxes, uint32_t n, const uint32_t* bounds, uint32_t* keys, uint32_t* idx) {
+// ---- batched builds: several independent trees ("segments": the BLASes of one rebuild) go through ONE pass of the builder ----
+// Primitives of a segment are consecutive in the input; seg_first[j] is the first primitive of segment j (seg_first[nseg] = n).
+// Every segment gets its own Morton frame, the sort keeps segments apart, PLOC only pairs clusters of one segment and stops at one
+// cluster per segment: each tree is exactly the tree a build of that segment alone produces.
+__global__ void k_seg_of(const uint32_t* seg_first, uint32_t nseg, uint32_t n, uint32_t* seg) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    uint32_t lo = 0, hi = nseg;
+    while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (seg_first[mid] <= i) lo = mid; else hi = mid; }
+    seg[i] = lo;
+}
+__global__ void k_bounds_seg(const Box* boxes, const uint32_t* seg, uint32_t n, uint32_t* bounds /*6 ordered uints per segment*/) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    const bool valid = i < n;
+    const uint32_t sg = valid ? seg[i] : 0xFFFFFFFFu;
+    uint32_t v[6];
+    if (valid) { const Box b = boxes[i]; for (int k = 0; k < 3; k++) { v[k] = float_to_ordered(b.lo[k]); v[3 + k] = float_to_ordered(b.hi[k]); } }
+    else for (int k = 0; k < 3; k++) { v[k] = 0xFFFFFFFFu; v[3 + k] = 0u; }
+    const uint32_t first = (uint32_t)__builtin_amdgcn_readfirstlane((int)sg);
+    if (__ballot(valid && sg != first) == 0ull && __ballot(!valid && first != 0xFFFFFFFFu) == 0ull) {   // the whole wave lies in one segment: reduce, then six atomics
+        for (int o = 32; o >= 1; o >>= 1) for (int k = 0; k < 3; k++) { v[k] = min(v[k], (uint32_t)__shfl_xor((int)v[k], o)); v[3 + k] = max(v[3 + k], (uint32_t)__shfl_xor((int)v[3 + k], o)); }
+        if ((threadIdx.x & 63u) == 0 && valid) for (int k = 0; k < 3; k++) { atomicMin(&bounds[6 * (size_t)sg + k], v[k]); atomicMax(&bounds[6 * (size_t)sg + 3 + k], v[3 + k]); }
+    } else if (valid) for (int k = 0; k < 3; k++) { atomicMin(&bounds[6 * (size_t)sg + k], v[k]); atomicMax(&bounds[6 * (size_t)sg + 3 + k], v[3 + k]); }
+}
+__global__ void k_fill_bounds(uint32_t* bounds, uint32_t nseg) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < 6 * nseg) bounds[i] = (i % 6) < 3 ? 0xFFFFFFFFu : 0u;
+}
+__global__ void k_gather_u32(const uint32_t* src, const uint32_t* idx, uint32_t n, uint32_t* out) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = src[idx[i]];
+}
+
+__global__ void k_morton(const Box* boxes, uint32_t n, const uint32_t* bounds_all, const uint32_t* seg /* nullptr: one segment */, uint32_t* keys, uint32_t* idx) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const Box b = boxes[i];
+    const uint32_t* bounds = bounds_all + (seg ? 6 * (size_t)seg[i] : 0);
     uint32_t code = 0;
     for (int k = 0; k < 3; k++) {
         const float lo = ordered_to_float(bounds[k]), hi = ordered_to_float(bounds[3 + k]);
@@ -194,15 +228,17 @@ constexpr int PLOC_BLOCK = 256;
 // and writes the other one.  c = clusters left, node_base = binary nodes made so far, stuck = a round merged nothing (cannot happen).
 struct PlocState { uint32_t c, node_base, stuck, pad; };
 
-__global__ __launch_bounds__(PLOC_BLOCK) void k_ploc_nn(const Box* cbox, const PlocState* st, uint32_t radius, uint32_t* nn) {
+__global__ __launch_bounds__(PLOC_BLOCK) void k_ploc_nn(const Box* cbox, const uint32_t* cseg /* nullptr: one segment */, const PlocState* st, uint32_t radius, uint32_t* nn) {
     const uint32_t c = st->c;
     const uint32_t i = blockIdx.x * PLOC_BLOCK + threadIdx.x;
     if (i >= c) return;
     const Box bi = cbox[i];
     const uint32_t lo = i > radius ? i - radius : 0u, hi = i + radius < c ? i + radius : c - 1u;
+    const uint32_t si = cseg ? cseg[i] : 0u;
     float best = 3.0e38f; uint32_t bj = i;
     for (uint32_t j = lo; j <= hi; j++) {
         if (j == i) continue;
+        if (cseg && cseg[j] != si) continue;   // clusters of other trees are not neighbours
         const Box bb = cbox[j];
         Box u;
         for (int k = 0; k < 3; k++) { u.lo[k] = fminf(bi.lo[k], bb.lo[k]); u.hi[k] = fmaxf(bi.hi[k], bb.hi[k]); }
@@ -234,7 +270,7 @@ __global__ __launch_bounds__(PLOC_BLOCK) void k_ploc_mark(const uint32_t* nn, co
 }
 
 // exclusive scan of the per-block sums (both 16-bit halves at once would overflow: they are widened to two words here)
-__global__ __launch_bounds__(1024) void k_ploc_scan(const uint32_t* block_sums, const PlocState* st, PlocState* st_next, uint2* block_base) {
+__global__ __launch_bounds__(1024) void k_ploc_scan(const uint32_t* block_sums, const PlocState* st, PlocState* st_next, uint2* block_base, uint32_t target /* clusters at the end: one per segment */) {
     __shared__ uint32_t s_wave[17];
     const uint32_t nblocks = (st->c + PLOC_BLOCK - 1) / PLOC_BLOCK;
     const uint32_t per = (nblocks + 1023u) / 1024u;
@@ -247,13 +283,13 @@ __global__ __launch_bounds__(1024) void k_ploc_scan(const uint32_t* block_sums, 
     run.y = block_scan_1024(s.y, s_wave, tot.y);
     if (threadIdx.x == 0) {
         st_next->c = tot.x; st_next->node_base = st->node_base + tot.y;
-        st_next->stuck = st->stuck | ((st->c > 1u && tot.y == 0u) ? 1u : 0u);
+        st_next->stuck = st->stuck | ((st->c > target && tot.y == 0u) ? 1u : 0u);
     }
     for (uint32_t i = a; i < b; i++) { const uint32_t v = block_sums[i]; block_base[i] = run; run.x += v & 0xffffu; run.y += v >> 16; }
 }
 
-__global__ __launch_bounds__(PLOC_BLOCK) void k_ploc_merge(const uint32_t* cref, const Box* cbox, const uint32_t* nn, const uint32_t* flags, const uint2* block_base,
-                                                        const PlocState* st, BinTree t, uint32_t* oref, Box* obox) {
+__global__ __launch_bounds__(PLOC_BLOCK) void k_ploc_merge(const uint32_t* cref, const Box* cbox, const uint32_t* cseg, const uint32_t* nn, const uint32_t* flags, const uint2* block_base,
+                                                        const PlocState* st, BinTree t, uint32_t* oref, Box* obox, uint32_t* oseg) {
     __shared__ uint2 wbase[PLOC_BLOCK / 64];
     const uint32_t c = st->c, node_base = st->node_base;
     if (blockIdx.x * PLOC_BLOCK >= c) return;
@@ -296,6 +332,7 @@ __global__ __launch_bounds__(PLOC_BLOCK) void k_ploc_merge(const uint32_t* cref,
         ref = id;
     }
     oref[pos] = ref; obox[pos] = b;
+    if (cseg) oseg[pos] = cseg[i];
 }
 
 __global__ void k_ploc_init(uint32_t n, uint32_t* cref) {
@@ -459,9 +496,10 @@ struct BuildScratch {
     Box *cba = nullptr, *cbb = nullptr;                                       // PLOC cluster boxes (ping-pong)
     uint32_t *cra = nullptr, *crb = nullptr, *nn = nullptr, *pflags = nullptr, *bsum = nullptr; PlocState* totals = nullptr;
     uint2* bbase = nullptr;
+    uint32_t *seg = nullptr, *csa = nullptr, *csb = nullptr;                   // batched builds: segment of every primitive / cluster (ping-pong)
     void release() {
         void* p[] = { boxes, sorted, ibox, keys, keys2, idx, idx2, ghist, bounds, left, right, cost, split, wa, wb, next_count,
-                      cba, cbb, cra, crb, nn, pflags, bsum, totals, bbase };
+                      cba, cbb, cra, crb, nn, pflags, bsum, totals, bbase, seg, csa, csb };
         for (void* q : p) if (q) (void)hipFree(q);
         *this = BuildScratch();
     }
@@ -480,6 +518,7 @@ struct BuildScratch {
         HIPCHK(hipMalloc(&cba, N * sizeof(Box))); HIPCHK(hipMalloc(&cbb, N * sizeof(Box)));
         HIPCHK(hipMalloc(&cra, N * 4)); HIPCHK(hipMalloc(&crb, N * 4)); HIPCHK(hipMalloc(&nn, N * 4)); HIPCHK(hipMalloc(&pflags, N * 4));
         HIPCHK(hipMalloc(&bsum, nb * 4)); HIPCHK(hipMalloc(&bbase, nb * sizeof(uint2))); HIPCHK(hipMalloc(&totals, 2 * sizeof(PlocState)));
+        HIPCHK(hipMalloc(&seg, N * 4)); HIPCHK(hipMalloc(&csa, N * 4)); HIPCHK(hipMalloc(&csb, N * 4));
         cap = n;
         return true;
     }
@@ -492,73 +531,94 @@ void bvh_scratch_destroy(BuildScratch* s) { if (s) { s->release(); delete s; } }
 void bvh_scratch_release(BuildScratch* s) { if (s) s->release(); }
 size_t bvh_scratch_capacity(const BuildScratch* s) { return s ? s->cap : 0; }
 
-// Builds a wide BVH over the n boxes in S.boxes.  Nodes are appended at *node_counter (device),
-// items at *item_counter; item_src[pos] = source box index for final item position pos.
-// Returns the root node index and the root box (host).
-static bool build_from_boxes(BuildScratch& S, hipStream_t s, uint32_t n, Node8* nodes, uint32_t* node_counter, uint32_t node_capacity,
-                             uint32_t* item_counter, uint32_t* item_src, uint32_t* root_out, Box* root_box) {
+// Builds `nseg` wide BVHs over the n boxes in S.boxes — segment j = boxes [seg_first[j], seg_first[j + 1]), none empty; nseg == 1: one tree over
+// all of them.  Nodes are appended at *node_counter (device), items at *item_counter; item_src[pos] = source box index for final item position pos.
+// Returns the root node index and the root box of every segment (host).
+static bool build_from_boxes(BuildScratch& S, hipStream_t s, uint32_t n, uint32_t nseg, const uint32_t* seg_first /* host, nseg + 1 */, Node8* nodes, uint32_t* node_counter, uint32_t node_capacity,
+                             uint32_t* item_counter, uint32_t* item_src, uint32_t* roots_out, Box* root_boxes) {
     const uint32_t ntiles = (n + RS_TILE - 1) / RS_TILE;
-    const uint32_t init_bounds[6] = { 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0u, 0u, 0u };
-    HIPCHK(hipMemcpyAsync(S.bounds, init_bounds, sizeof init_bounds, hipMemcpyHostToDevice, s));
-    hipLaunchKernelGGL(k_bounds, dim3(std::min<uint32_t>((n + 255) / 256, 1024)), dim3(256), 0, s, S.boxes, n, S.bounds);
-    hipLaunchKernelGGL(k_morton, dim3((n + 255) / 256), dim3(256), 0, s, S.boxes, n, S.bounds, S.keys, S.idx);
+    const bool segmented = nseg > 1;
+    uint32_t* d_segfirst = nullptr; uint32_t* d_bounds = S.bounds;
+    struct Guard { uint32_t*& a; uint32_t*& b; uint32_t* keep; ~Guard() { if (a) (void)hipFree(a); if (b && b != keep) (void)hipFree(b); } } guard{ d_segfirst, d_bounds, S.bounds };
+    if (segmented) {
+        HIPCHK(hipMalloc(&d_segfirst, ((size_t)nseg + 1) * 4));
+        d_bounds = nullptr;
+        HIPCHK(hipMalloc(&d_bounds, (size_t)nseg * 24));
+        HIPCHK(hipMemcpyAsync(d_segfirst, seg_first, ((size_t)nseg + 1) * 4, hipMemcpyHostToDevice, s));
+        hipLaunchKernelGGL(k_seg_of, dim3((n + 255) / 256), dim3(256), 0, s, d_segfirst, nseg, n, S.seg);
+        hipLaunchKernelGGL(k_fill_bounds, dim3((6 * nseg + 255) / 256), dim3(256), 0, s, d_bounds, nseg);
+        hipLaunchKernelGGL(k_bounds_seg, dim3((n + 255) / 256), dim3(256), 0, s, S.boxes, S.seg, n, d_bounds);
+    } else {
+        const uint32_t init_bounds[6] = { 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0u, 0u, 0u };
+        HIPCHK(hipMemcpyAsync(S.bounds, init_bounds, sizeof init_bounds, hipMemcpyHostToDevice, s));
+        hipLaunchKernelGGL(k_bounds, dim3(std::min<uint32_t>((n + 255) / 256, 1024)), dim3(256), 0, s, S.boxes, n, S.bounds);
+    }
+    hipLaunchKernelGGL(k_morton, dim3((n + 255) / 256), dim3(256), 0, s, S.boxes, n, d_bounds, segmented ? S.seg : nullptr, S.keys, S.idx);
     uint32_t *ka = S.keys, *kb = S.keys2, *va = S.idx, *vb = S.idx2;
-    for (int pass = 0; pass < 4; pass++) {
-        const int shift = pass * 8;
+    auto radix_pass = [&](int shift) {
         hipLaunchKernelGGL(k_radix_hist, dim3(ntiles), dim3(256), 0, s, ka, n, shift, S.ghist, ntiles);
         hipLaunchKernelGGL(k_radix_scan, dim3(1), dim3(1024), 0, s, S.ghist, ntiles * 256u);
         hipLaunchKernelGGL(k_radix_scatter, dim3(ntiles), dim3(64), 0, s, ka, va, n, shift, S.ghist, ntiles, kb, vb);
         std::swap(ka, kb); std::swap(va, vb);
+    };
+    for (int pass = 0; pass < 4; pass++) radix_pass(pass * 8);
+    if (segmented) {   // the sort is stable: further passes on the segment number bring every segment back together, in Morton order inside
+        int bits = 0; while ((1ull << bits) < nseg) bits++;
+        hipLaunchKernelGGL(k_gather_u32, dim3((n + 255) / 256), dim3(256), 0, s, S.seg, va, n, ka);
+        for (int shift = 0; shift < bits; shift += 8) radix_pass(shift);
     }
-    // after 4 passes (ka,va) are back in (keys, idx)
     hipLaunchKernelGGL(k_gather_boxes, dim3((n + 255) / 256), dim3(256), 0, s, S.boxes, va, n, S.sorted);
     BinTree t{ S.left, S.right, S.ibox, S.cost, S.split };
-    uint32_t root_ref;
+    std::vector<uint32_t> root_refs(nseg);
     if (n >= 2) {
         HIPCHK(hipMemcpyAsync(S.cba, S.sorted, (size_t)n * sizeof(Box), hipMemcpyDeviceToDevice, s));
         hipLaunchKernelGGL(k_ploc_init, dim3((n + 255) / 256), dim3(256), 0, s, n, S.cra);
+        if (segmented) hipLaunchKernelGGL(k_gather_u32, dim3((n + 255) / 256), dim3(256), 0, s, S.seg, va, n, S.csa);
         static const uint32_t radius = [] { const char* e = getenv("MSNE_PLOC_RADIUS"); return e ? (uint32_t)atoi(e) : (uint32_t)PLOC_RADIUS; }();
         uint32_t *ra = S.cra, *rb = S.crb; Box *ba = S.cba, *bb = S.cbb;
+        uint32_t *sa = segmented ? S.csa : nullptr, *sb = segmented ? S.csb : nullptr;
         // Rounds are queued in groups of PLOC_GROUP without a host round trip: every kernel reads the cluster count of its round from
         // the device (slot r & 1 of S.totals) and runs on a grid sized for the count at the start of the group; a round that starts
-        // with one cluster copies it through unchanged.  One read-back per group instead of one per round (1 M triangles: ~56 rounds).
+        // with one cluster per segment copies them through unchanged.  One read-back per group instead of one per round (1 M triangles: ~56 rounds).
         constexpr uint32_t PLOC_GROUP = 8;
         PlocState st0{ n, 0u, 0u, 0u };
         HIPCHK(hipMemcpyAsync(S.totals, &st0, sizeof st0, hipMemcpyHostToDevice, s));
         uint32_t c = n, round = 0;
-        while (c > 1) {
+        while (c > nseg) {
             const uint32_t nb = (c + PLOC_BLOCK - 1) / PLOC_BLOCK;
             for (uint32_t g = 0; g < PLOC_GROUP; g++, round++) {
                 const PlocState* cur = S.totals + (round & 1u); PlocState* nxt = S.totals + ((round + 1u) & 1u);
-                hipLaunchKernelGGL(k_ploc_nn, dim3(nb), dim3(PLOC_BLOCK), 0, s, ba, cur, radius, S.nn);
+                hipLaunchKernelGGL(k_ploc_nn, dim3(nb), dim3(PLOC_BLOCK), 0, s, ba, sa, cur, radius, S.nn);
                 hipLaunchKernelGGL(k_ploc_mark, dim3(nb), dim3(PLOC_BLOCK), 0, s, S.nn, cur, S.pflags, S.bsum);
-                hipLaunchKernelGGL(k_ploc_scan, dim3(1), dim3(1024), 0, s, S.bsum, cur, nxt, S.bbase);
-                hipLaunchKernelGGL(k_ploc_merge, dim3(nb), dim3(PLOC_BLOCK), 0, s, ra, ba, S.nn, S.pflags, S.bbase, cur, t, rb, bb);
-                std::swap(ra, rb); std::swap(ba, bb);
+                hipLaunchKernelGGL(k_ploc_scan, dim3(1), dim3(1024), 0, s, S.bsum, cur, nxt, S.bbase, nseg);
+                hipLaunchKernelGGL(k_ploc_merge, dim3(nb), dim3(PLOC_BLOCK), 0, s, ra, ba, sa, S.nn, S.pflags, S.bbase, cur, t, rb, bb, sb);
+                std::swap(ra, rb); std::swap(ba, bb); std::swap(sa, sb);
             }
             PlocState now{};
             HIPCHK(hipMemcpyAsync(&now, S.totals + (round & 1u), sizeof now, hipMemcpyDeviceToHost, s));
             HIPCHK(hipStreamSynchronize(s));
-            if (now.stuck || now.c >= c) { fprintf(stderr, "moonshine_amd: PLOC made no progress\n"); return false; }
+            if (now.stuck || now.c >= c || now.c < nseg) { fprintf(stderr, "moonshine_amd: PLOC made no progress\n"); return false; }
             c = now.c;
         }
-        HIPCHK(hipMemcpyAsync(&root_ref, ra, 4, hipMemcpyDeviceToHost, s));
-        HIPCHK(hipMemcpyAsync(root_box, ba, sizeof(Box), hipMemcpyDeviceToHost, s));
+        HIPCHK(hipMemcpyAsync(root_refs.data(), ra, (size_t)nseg * 4, hipMemcpyDeviceToHost, s));
+        HIPCHK(hipMemcpyAsync(root_boxes, ba, (size_t)nseg * sizeof(Box), hipMemcpyDeviceToHost, s));
         HIPCHK(hipStreamSynchronize(s));
     } else {
-        root_ref = REF_LEAF | 0u;
-        HIPCHK(hipMemcpyAsync(root_box, S.sorted, sizeof(Box), hipMemcpyDeviceToHost, s));
+        root_refs[0] = REF_LEAF | 0u;
+        HIPCHK(hipMemcpyAsync(root_boxes, S.sorted, sizeof(Box), hipMemcpyDeviceToHost, s));
     }
-    // root wide node
+    // one wide root node per segment
     uint32_t root_wide = 0;
     HIPCHK(hipMemcpyAsync(&root_wide, node_counter, 4, hipMemcpyDeviceToHost, s));
     HIPCHK(hipStreamSynchronize(s));
-    if (root_wide + n + 1 > node_capacity) { fprintf(stderr, "moonshine_amd: node pool exhausted\n"); return false; }
-    const uint32_t after = root_wide + 1;
+    if ((uint64_t)root_wide + n + nseg > node_capacity) { fprintf(stderr, "moonshine_amd: node pool exhausted\n"); return false; }
+    const uint32_t after = root_wide + nseg;
     HIPCHK(hipMemcpyAsync(node_counter, &after, 4, hipMemcpyHostToDevice, s));
-    CollapseWork w0{ root_ref, root_wide };
-    HIPCHK(hipMemcpyAsync(S.wa, &w0, sizeof w0, hipMemcpyHostToDevice, s));
-    uint32_t nwork = 1;
+    std::vector<CollapseWork> w0(nseg);
+    for (uint32_t j = 0; j < nseg; j++) { w0[j] = CollapseWork{ root_refs[j], root_wide + j }; roots_out[j] = root_wide + j; }
+    HIPCHK(hipMemcpyAsync(S.wa, w0.data(), (size_t)nseg * sizeof(CollapseWork), hipMemcpyHostToDevice, s));
+    HIPCHK(hipStreamSynchronize(s));   // (w0 is pageable host memory about to go out of scope)
+    uint32_t nwork = nseg;
     CollapseWork *cur = S.wa, *nxt = S.wb;
     while (nwork) {
         HIPCHK(hipMemsetAsync(S.next_count, 0, 4, s));
@@ -568,32 +628,33 @@ static bool build_from_boxes(BuildScratch& S, hipStream_t s, uint32_t n, Node8* 
         HIPCHK(hipStreamSynchronize(s));
         std::swap(cur, nxt);
     }
-    *root_out = root_wide;
     return true;
 }
 
-// BLAS over the triangles of a geometry list (Accel.zig:94-184; one BLAS per unique mesh list, :315-343)
-bool bvh_build_blas(BuildScratch* scratch, hipStream_t s, const std::vector<BlasGeo>& geos, uint32_t ntris, Node8* nodes, uint32_t* node_counter, uint32_t node_capacity,
-                    TriRec* tris, TriAttr* attrs, uint32_t* tri_counter, uint32_t* item_src, uint32_t* root_out, float root_box[6]) {
-    if (ntris == 0) { *root_out = MAX_UINT; for (int k = 0; k < 6; k++) root_box[k] = 0.0f; return true; }
+// BLASes over the triangles of geometry lists (Accel.zig:94-184; one BLAS per unique mesh list, :315-343) — ALL the BLASes a rebuild needs in one pass, as the
+// reference hands them to one vkCmdBuildAccelerationStructuresKHR: `geos` lists the geometries of every job one after the other with tri_offset running
+// over the whole batch, job j owns triangles [job_first[j], job_first[j + 1]).  A scene of thousands of small meshes costs one build, not thousands
+// (2 000 meshes of 320 triangles: 1.65 s one by one).
+bool bvh_build_blas_batch(BuildScratch* scratch, hipStream_t s, const std::vector<BlasGeo>& geos, const std::vector<uint32_t>& job_first, Node8* nodes, uint32_t* node_counter, uint32_t node_capacity,
+                          TriRec* tris, TriAttr* attrs, uint32_t* tri_counter, uint32_t* item_src, uint32_t* roots_out, float* root_boxes /* 6 per job */) {
+    const uint32_t njobs = (uint32_t)job_first.size() - 1u, ntris = job_first.back();
+    if (njobs == 0 || ntris == 0) return true;
     if (!scratch) return false;
     BuildScratch& g_scratch = *scratch;
     if (!g_scratch.reserve(ntris)) return false;
     BlasGeo* dgeos = nullptr;
     HIPCHK(hipMalloc(&dgeos, geos.size() * sizeof(BlasGeo)));
+    struct Free { BlasGeo* p; ~Free() { (void)hipFree(p); } } free_geos{ dgeos };
     HIPCHK(hipMemcpyAsync(dgeos, geos.data(), geos.size() * sizeof(BlasGeo), hipMemcpyHostToDevice, s));
     hipLaunchKernelGGL(k_prim_boxes_tris, dim3((ntris + 255) / 256), dim3(256), 0, s, dgeos, (uint32_t)geos.size(), ntris, g_scratch.boxes);
     uint32_t item_begin = 0;
     HIPCHK(hipMemcpyAsync(&item_begin, tri_counter, 4, hipMemcpyDeviceToHost, s));
-    Box rb;
-    bool ok = build_from_boxes(g_scratch, s, ntris, nodes, node_counter, node_capacity, tri_counter, item_src, root_out, &rb);
-    if (ok) {
-        hipLaunchKernelGGL(k_emit_tris, dim3((ntris + 255) / 256), dim3(256), 0, s, dgeos, (uint32_t)geos.size(), item_src, item_begin, ntris, tris, attrs);
-        HIPCHK(hipStreamSynchronize(s));
-        for (int k = 0; k < 3; k++) { root_box[k] = rb.lo[k]; root_box[3 + k] = rb.hi[k]; }
-    }
-    (void)hipFree(dgeos);
-    return ok;
+    std::vector<Box> rb(njobs);
+    if (!build_from_boxes(g_scratch, s, ntris, njobs, job_first.data(), nodes, node_counter, node_capacity, tri_counter, item_src, roots_out, rb.data())) return false;
+    hipLaunchKernelGGL(k_emit_tris, dim3((ntris + 255) / 256), dim3(256), 0, s, dgeos, (uint32_t)geos.size(), item_src, item_begin, ntris, tris, attrs);
+    HIPCHK(hipStreamSynchronize(s));
+    for (uint32_t j = 0; j < njobs; j++) for (int k = 0; k < 3; k++) { root_boxes[6 * j + k] = rb[j].lo[k]; root_boxes[6 * j + 3 + k] = rb[j].hi[k]; }
+    return true;
 }
 
 // ---------------- TLAS (Accel.zig:484): instance world boxes on the GPU, then the same builder ----------------
@@ -659,7 +720,7 @@ bool bvh_build_tlas(BuildScratch* scratch, hipStream_t s, const TlasInst* insts,
     uint32_t item_begin = 0;
     HIPCHK(hipMemcpyAsync(&item_begin, item_counter, 4, hipMemcpyDeviceToHost, s));
     Box rb;
-    bool ok = build_from_boxes(g_scratch, s, n, nodes, node_counter, node_capacity, item_counter, item_src, root_out, &rb);
+    bool ok = build_from_boxes(g_scratch, s, n, 1u, nullptr, nodes, node_counter, node_capacity, item_counter, item_src, root_out, &rb);
     if (ok) {
         hipLaunchKernelGGL(k_emit_items, dim3((n + 255) / 256), dim3(256), 0, s, item_src, item_begin, n, dids, tlas_items);
         HIPCHK(hipStreamSynchronize(s));

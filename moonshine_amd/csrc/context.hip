@@ -39,7 +39,7 @@ BuildScratch* bvh_scratch_create();
 void bvh_scratch_destroy(BuildScratch*);
 void bvh_scratch_release(BuildScratch*);
 size_t bvh_scratch_capacity(const BuildScratch*);
-bool bvh_build_blas(BuildScratch*, hipStream_t, const std::vector<BlasGeo>&, uint32_t, Node8*, uint32_t*, uint32_t, TriRec*, TriAttr*, uint32_t*, uint32_t*, uint32_t*, float[6]);
+bool bvh_build_blas_batch(BuildScratch*, hipStream_t, const std::vector<BlasGeo>&, const std::vector<uint32_t>&, Node8*, uint32_t*, uint32_t, TriRec*, TriAttr*, uint32_t*, uint32_t*, uint32_t*, float*);
 struct TlasInst { float T[12]; float blas_box[6]; uint32_t mesh_begin, mesh_end, exact, pad; };
 struct TlasMesh { const float* positions; uint32_t count, pad; };
 bool bvh_build_tlas(BuildScratch*, hipStream_t, const TlasInst*, const uint32_t*, uint32_t, const TlasMesh*, uint32_t, Node8*, uint32_t*, uint32_t, uint32_t*, uint32_t*, uint32_t*, uint32_t*);
@@ -403,24 +403,37 @@ bool HdMoonshine::rebuild_accel() {
     if (!d_item_src.ensure(std::max(d_tris.n, N + 2)) || !d_tlas_items.ensure(N + 2)) { fail("out of device memory (items)"); return false; }
     // counters: node count resumes after the BLAS region (the previous TLAS is discarded)
     { uint32_t c[4] = { blas_nodes_end, blas_tris_end, 0u, 0u }; CHECK_HIP(this, hipMemcpyAsync(d_build_counters.p, c, 16, hipMemcpyHostToDevice, stream)); CHECK_HIP(this, hipStreamSynchronize(stream)); }
-    for (size_t i = 0; i < N; i++) {
-        if (in_world[i] || blas_cache.count(keys[i])) continue;
-        std::vector<BlasGeo> bg; uint32_t off = 0, g = 0;
-        for (uint32_t m : keys[i]) { bg.push_back(blas_geo(meshes[m], off, g++, 0u)); off += meshes[m]->index_count; }
-        BlasInfo info{}; info.tris = off;
-        if (!bvh_build_blas(build_scratch, stream, bg, off, d_nodes.p, d_build_counters.p, (uint32_t)d_nodes.n, d_tris.p, d_tri_attrs.p, d_build_counters.p + 1, d_item_src.p, &info.root, info.box)) { fail("BLAS build failed (details on stderr)"); return false; }
-        blas_cache[keys[i]] = info;
-    }
-    if (!world_key.empty() && !blas_cache.count(world_key)) {
-        std::vector<BlasGeo> bg; uint32_t off = 0;
+    {   // every BLAS this rebuild needs — one per unique mesh list not yet cached, and the world BLAS — goes through ONE pass of the builder
+        std::vector<BlasGeo> bg; std::vector<uint32_t> job_first{ 0u }; std::vector<std::vector<uint32_t>> job_key;
+        uint32_t off = 0;
+        std::map<std::vector<uint32_t>, bool> queued;
         for (size_t i = 0; i < N; i++) {
-            if (!in_world[i]) continue;
-            uint32_t g = 0;
-            for (uint32_t m : keys[i]) { bg.push_back(blas_geo(meshes[m], off, g++, (uint32_t)i)); off += meshes[m]->index_count; }
+            if (in_world[i] || blas_cache.count(keys[i]) || queued.count(keys[i])) continue;
+            uint32_t g = 0, nt = 0;
+            for (uint32_t m : keys[i]) { bg.push_back(blas_geo(meshes[m], off, g++, 0u)); off += meshes[m]->index_count; nt += meshes[m]->index_count; }
+            queued[keys[i]] = true;
+            if (nt == 0) { blas_cache[keys[i]] = BlasInfo{ MAX_UINT, { 0, 0, 0, 0, 0, 0 }, 0u }; while (g--) bg.pop_back(); continue; }
+            job_first.push_back(off); job_key.push_back(keys[i]);
         }
-        BlasInfo info{}; info.tris = off;
-        if (!bvh_build_blas(build_scratch, stream, bg, off, d_nodes.p, d_build_counters.p, (uint32_t)d_nodes.n, d_tris.p, d_tri_attrs.p, d_build_counters.p + 1, d_item_src.p, &info.root, info.box)) { fail("world BLAS build failed (details on stderr)"); return false; }
-        blas_cache[world_key] = info;
+        if (!world_key.empty() && !blas_cache.count(world_key)) {
+            for (size_t i = 0; i < N; i++) {
+                if (!in_world[i]) continue;
+                uint32_t g = 0;
+                for (uint32_t m : keys[i]) { bg.push_back(blas_geo(meshes[m], off, g++, (uint32_t)i)); off += meshes[m]->index_count; }
+            }
+            job_first.push_back(off); job_key.push_back(world_key);
+        }
+        const size_t njobs = job_key.size();
+        if (njobs) {
+            std::vector<uint32_t> roots(njobs); std::vector<float> boxes(6 * njobs);
+            if (!bvh_build_blas_batch(build_scratch, stream, bg, job_first, d_nodes.p, d_build_counters.p, (uint32_t)d_nodes.n, d_tris.p, d_tri_attrs.p, d_build_counters.p + 1, d_item_src.p,
+                                      roots.data(), boxes.data())) { fail("BLAS build failed (details on stderr)"); return false; }
+            for (size_t j = 0; j < njobs; j++) {
+                BlasInfo info{}; info.root = roots[j]; info.tris = job_first[j + 1] - job_first[j];
+                memcpy(info.box, &boxes[6 * j], 24);
+                blas_cache[job_key[j]] = info;
+            }
+        }
     }
     { uint32_t c[2]; CHECK_HIP(this, hipMemcpy(c, d_build_counters.p, 8, hipMemcpyDeviceToHost)); blas_nodes_end = c[0]; blas_tris_end = c[1]; }
 

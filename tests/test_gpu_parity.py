@@ -119,6 +119,44 @@ def test_trace_rays_instanced(orc, gpu_api):
     _check_rays(oc, gc, rays[:1500])
 
 
+def test_many_distinct_meshes_build_in_one_batch(orc, gpu_api):
+    """every BLAS of a rebuild goes through one segmented pass of the builder (per-mesh Morton frames, segment-aware sort and PLOC): 60 distinct meshes from a single
+    triangle to 1280 triangles, some instances sharing a mesh list, some with two geometries, plus identity instances (the world BLAS rides in the same batch);
+    closest hits and occlusion of 6000 rays equal the oracle's, then again after adding meshes to the live scene (a second, smaller batch next to cached BLASes)"""
+    def populate(c, first, count):
+        mat = c.create_material(scenes.LAMBERT, c.solid_texture(0.5, 0.5), c.solid_texture(0, 0, 0), color=c.solid_texture(0.7, 0.7, 0.7))
+        made = []
+        r2 = np.random.default_rng(100 + first)
+        for k in range(first, first + count):
+            kind = k % 5
+            if kind == 0:
+                P = r2.normal(size=(3, 3)).astype(np.float32) * 0.4; I = np.array([[0, 1, 2]], np.uint32)                 # one triangle
+            elif kind == 1:
+                P = np.array([[-.5, -.5, 0], [.5, -.5, 0], [.5, .5, 0], [-.5, .5, 0]], np.float32) * r2.uniform(0.5, 1.5); I = np.array([[0, 1, 2], [0, 2, 3]], np.uint32)
+            else:
+                P, I = scenes.icosphere(kind - 2 + (k % 2)); P = (P * r2.uniform(0.3, 0.6, (1, 3))).astype(np.float32)
+            made.append(c.create_mesh(P, I))
+        side = 5
+        for n_, m in enumerate(made):
+            k = first + n_
+            T = np.zeros((3, 4), np.float32); T[:, :3] = np.eye(3); T[:, 3] = (1.5 * (k % side), 1.5 * ((k // side) % side), 1.5 * (k // (side * side)))
+            if k % 3:
+                T[:, :3] = scenes._rot((r2.normal(), r2.normal(), r2.normal() + 1e-3), r2.uniform(0, 6.28)) * r2.uniform(0.6, 1.2)
+            geos = [(m, mat, False)] + ([(made[n_ - 1], mat, False)] if k % 7 == 3 and n_ else [])
+            c.create_instance(geos, transform=T)
+            if k % 11 == 5:
+                T2 = T.copy(); T2[:, 3] += (0.4, 0.4, 0.4); c.create_instance(geos, transform=T2)                           # a second instance of the same mesh list
+    oc, gc = orc.Context(threads=8), gpu_api.Context()
+    for c in (oc, gc):
+        populate(c, 0, 60)
+    rays = _random_rays(6000, 5, radius=9.0)
+    rays[:, :3] += (3.0, 3.0, 1.5)
+    _check_rays(oc, gc, rays)
+    for c in (oc, gc):
+        populate(c, 60, 15)
+    _check_rays(oc, gc, rays)
+
+
 def test_object_pick_matches_oracle(orc, gpu_api):
     """ObjectPicker (ObjectPicker.zig:89-128, input.hlsl:24-69): one closest-hit ray through normalized sensor coordinates,
     y flipped, lens sample (0,0) on the lens AS GIVEN (second lens: a real aperture, so the ray starts on the lens rim)."""
