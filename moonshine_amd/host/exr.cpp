@@ -6,6 +6,9 @@
 //   save: three FLOAT channels in header order B,G,R, scanline, ZIP (exr.zig:137-206 with tinyexr's header defaults; alpha is dropped).
 #include "host.h"
 #include <zlib.h>
+#include <atomic>
+#include <thread>
+#include <sched.h>
 #include <cstdio>
 #include <cstring>
 #include <algorithm>
@@ -370,8 +373,11 @@ bool exr_save_rgb(const std::string& path, const float* rgba, uint32_t w, uint32
     const size_t line_bytes = (size_t)w * 12, table = o.size();
     const uint32_t nblocks = (h + 15u) / 16u;
     o.resize(table + (size_t)nblocks * 8);
-    std::vector<uint8_t> raw, tmp, z;
-    for (uint32_t b = 0; b < nblocks; b++) {
+    // The blocks are independent: they are packed on all the host threads this process may use (deflate of a 1080p float film is 0.5 s on one thread,
+    // more than rendering it), then appended in order — the file is byte for byte what the one-thread loop writes.
+    std::vector<std::vector<uint8_t>> packed_blocks(nblocks);
+    auto pack_block = [&](uint32_t b) {
+        std::vector<uint8_t> raw, tmp, z;
         const uint32_t y0 = b * 16u, y1 = std::min(h, y0 + 16u);
         raw.resize((size_t)(y1 - y0) * line_bytes);
         for (uint32_t y = y0; y < y1; y++)
@@ -383,10 +389,25 @@ bool exr_save_rgb(const std::string& path, const float* rgba, uint32_t w, uint32
         uLongf zn = compressBound((uLong)tmp.size());
         z.resize(zn);
         const bool packed = compress(z.data(), &zn, tmp.data(), (uLong)tmp.size()) == Z_OK && zn < raw.size();
+        if (packed) { z.resize(zn); packed_blocks[b].swap(z); } else packed_blocks[b].swap(raw);
+    };
+    {
+        unsigned nthreads = std::thread::hardware_concurrency();
+        cpu_set_t set; CPU_ZERO(&set);
+        if (sched_getaffinity(0, sizeof set, &set) == 0) nthreads = std::min<unsigned>(nthreads ? nthreads : 1u, (unsigned)CPU_COUNT(&set));
+        nthreads = std::max(1u, std::min({ nthreads, 32u, nblocks }));
+        std::atomic<uint32_t> next{ 0 };
+        auto worker = [&] { for (uint32_t b; (b = next.fetch_add(1)) < nblocks;) pack_block(b); };
+        std::vector<std::thread> pool;
+        for (unsigned t = 1; t < nthreads; t++) pool.emplace_back(worker);
+        worker();
+        for (auto& t : pool) t.join();
+    }
+    for (uint32_t b = 0; b < nblocks; b++) {
         const uint64_t off = o.size();
         memcpy(&o[table + (size_t)b * 8], &off, 8);
-        put<int32_t>(o, (int32_t)y0); put<int32_t>(o, (int32_t)(packed ? zn : raw.size()));
-        if (packed) o.insert(o.end(), z.begin(), z.begin() + zn); else o.insert(o.end(), raw.begin(), raw.end());
+        put<int32_t>(o, (int32_t)(b * 16u)); put<int32_t>(o, (int32_t)packed_blocks[b].size());
+        o.insert(o.end(), packed_blocks[b].begin(), packed_blocks[b].end());
     }
     FILE* f = fopen(path.c_str(), "wb");
     if (!f) { err = "cannot write " + path; return false; }
