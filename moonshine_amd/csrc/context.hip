@@ -13,6 +13,7 @@
 #include <cstring>
 #include <map>
 #include <mutex>
+#include <functional>
 #include <string>
 #include <vector>
 
@@ -194,6 +195,8 @@ struct HdMoonshine {
 };
 
 // ---------------- textures ----------------
+namespace msne_host { void parallel_for(uint32_t n, const std::function<void(uint32_t)>& job); }   // host/exr.cpp: the host threads this process may use
+
 static float half_to_float(uint16_t h) {
     const uint32_t s = (uint32_t)(h >> 15) << 31, e = (h >> 10) & 0x1f, m = h & 0x3ff;
     if (e == 0) { if (m == 0) return u2f(s); const float f = (float)m * 0x1p-24f; return (h >> 15) ? -f : f; }
@@ -201,9 +204,9 @@ static float half_to_float(uint16_t h) {
     return u2f(s | ((e + 112) << 23) | (m << 13));
 }
 static const float* srgb_lut() {
-    static float lut[256]; static bool init = false;
-    if (!init) { for (int i = 0; i < 256; i++) { const double v = i / 255.0; lut[i] = (float)(v <= 0.04045 ? v / 12.92 : pow((v + 0.055) / 1.055, 2.4)); } init = true; }
-    return lut;
+    struct Lut { float v[256]; Lut() { for (int i = 0; i < 256; i++) { const double x = i / 255.0; v[i] = (float)(x <= 0.04045 ? x / 12.92 : pow((x + 0.055) / 1.055, 2.4)); } } };
+    static const Lut lut;   // (initialised once, thread-safely: contexts on different threads create textures concurrently)
+    return lut.v;
 }
 static int64_t add_texture(HdMoonshine* c, const void* bytes, uint32_t w, uint32_t h, int fmt) {
     if (!bytes || w == 0 || h == 0) { c->fail("texture: bad arguments"); return -1; }
@@ -212,18 +215,23 @@ static int64_t add_texture(HdMoonshine* c, const void* bytes, uint32_t w, uint32
     const size_t n = (size_t)w * h;
     const uint8_t* b = (const uint8_t*)bytes; const float* f = (const float*)bytes; const uint16_t* hf = (const uint16_t*)bytes;
     const float* lut = srgb_lut();
-    for (size_t i = 0; i < n; i++) {
-        float* o = &t.rgba[4 * i]; o[0] = o[1] = o[2] = 0.0f; o[3] = 1.0f;
-        switch (fmt) {
-            case MSNE_FORMAT_R8G8B8A8_SRGB: o[0] = lut[b[4 * i]]; o[1] = lut[b[4 * i + 1]]; o[2] = lut[b[4 * i + 2]]; o[3] = (float)b[4 * i + 3] / 255.0f; break;
-            case MSNE_FORMAT_R8G8_UNORM: o[0] = (float)b[2 * i] / 255.0f; o[1] = (float)b[2 * i + 1] / 255.0f; break;
-            case MSNE_FORMAT_R8_UNORM: o[0] = (float)b[i] / 255.0f; break;
-            case MSNE_FORMAT_R32G32B32A32_SFLOAT: o[0] = f[4 * i]; o[1] = f[4 * i + 1]; o[2] = f[4 * i + 2]; o[3] = f[4 * i + 3]; break;
-            case MSNE_FORMAT_R32G32_SFLOAT: o[0] = f[2 * i]; o[1] = f[2 * i + 1]; break;
-            case MSNE_FORMAT_R32_SFLOAT: o[0] = f[i]; break;
-            case MSNE_FORMAT_R16G16B16A16_SFLOAT: o[0] = half_to_float(hf[4 * i]); o[1] = half_to_float(hf[4 * i + 1]); o[2] = half_to_float(hf[4 * i + 2]); o[3] = half_to_float(hf[4 * i + 3]); break;
+    auto convert = [&](size_t i0, size_t i1) {
+        for (size_t i = i0; i < i1; i++) {
+            float* o = &t.rgba[4 * i]; o[0] = o[1] = o[2] = 0.0f; o[3] = 1.0f;
+            switch (fmt) {
+                case MSNE_FORMAT_R8G8B8A8_SRGB: o[0] = lut[b[4 * i]]; o[1] = lut[b[4 * i + 1]]; o[2] = lut[b[4 * i + 2]]; o[3] = (float)b[4 * i + 3] / 255.0f; break;
+                case MSNE_FORMAT_R8G8_UNORM: o[0] = (float)b[2 * i] / 255.0f; o[1] = (float)b[2 * i + 1] / 255.0f; break;
+                case MSNE_FORMAT_R8_UNORM: o[0] = (float)b[i] / 255.0f; break;
+                case MSNE_FORMAT_R32G32B32A32_SFLOAT: o[0] = f[4 * i]; o[1] = f[4 * i + 1]; o[2] = f[4 * i + 2]; o[3] = f[4 * i + 3]; break;
+                case MSNE_FORMAT_R32G32_SFLOAT: o[0] = f[2 * i]; o[1] = f[2 * i + 1]; break;
+                case MSNE_FORMAT_R32_SFLOAT: o[0] = f[i]; break;
+                case MSNE_FORMAT_R16G16B16A16_SFLOAT: o[0] = half_to_float(hf[4 * i]); o[1] = half_to_float(hf[4 * i + 1]); o[2] = half_to_float(hf[4 * i + 2]); o[3] = half_to_float(hf[4 * i + 3]); break;
+            }
         }
-    }
+    };
+    constexpr size_t PIECE = 1u << 16;   // texels per piece of work: big textures are converted on all host threads
+    if (n <= PIECE) convert(0, n);
+    else msne_host::parallel_for((uint32_t)((n + PIECE - 1) / PIECE), [&](uint32_t k) { convert((size_t)k * PIECE, std::min(n, ((size_t)k + 1) * PIECE)); });
     memcpy(t.first, t.rgba.data(), 16);
     c->textures.push_back(std::move(t));
     c->textures_dirty = true;

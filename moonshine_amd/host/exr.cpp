@@ -10,6 +10,7 @@
 #include <thread>
 #include <sched.h>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <algorithm>
 
@@ -357,6 +358,20 @@ static void put_str(std::vector<uint8_t>& o, const char* s) { o.insert(o.end(), 
 template <typename T> static void put(std::vector<uint8_t>& o, T v) { const uint8_t* p = (const uint8_t*)&v; o.insert(o.end(), p, p + sizeof(T)); }
 static void put_attr(std::vector<uint8_t>& o, const char* name, const char* type, const std::vector<uint8_t>& v) { put_str(o, name); put_str(o, type); put<uint32_t>(o, (uint32_t)v.size()); o.insert(o.end(), v.begin(), v.end()); }
 
+void parallel_for(uint32_t n, const std::function<void(uint32_t)>& job) {
+    unsigned nthreads = std::thread::hardware_concurrency();
+    cpu_set_t set; CPU_ZERO(&set);
+    if (sched_getaffinity(0, sizeof set, &set) == 0) nthreads = std::min<unsigned>(nthreads ? nthreads : 1u, (unsigned)CPU_COUNT(&set));
+    if (const char* e = getenv("MSNE_HOST_THREADS")) nthreads = (unsigned)std::max(1, atoi(e));   // (1: everything on the calling thread)
+    nthreads = std::max(1u, std::min({ nthreads, 32u, n }));
+    std::atomic<uint32_t> next{ 0 };
+    auto worker = [&] { for (uint32_t i; (i = next.fetch_add(1)) < n;) job(i); };
+    std::vector<std::thread> pool;
+    for (unsigned t = 1; t < nthreads; t++) pool.emplace_back(worker);
+    worker();
+    for (auto& t : pool) t.join();
+}
+
 bool exr_save_rgb(const std::string& path, const float* rgba, uint32_t w, uint32_t h, std::string& err) {
     std::vector<uint8_t> o;
     put<uint32_t>(o, 20000630u); put<uint32_t>(o, 2u);
@@ -391,18 +406,7 @@ bool exr_save_rgb(const std::string& path, const float* rgba, uint32_t w, uint32
         const bool packed = compress(z.data(), &zn, tmp.data(), (uLong)tmp.size()) == Z_OK && zn < raw.size();
         if (packed) { z.resize(zn); packed_blocks[b].swap(z); } else packed_blocks[b].swap(raw);
     };
-    {
-        unsigned nthreads = std::thread::hardware_concurrency();
-        cpu_set_t set; CPU_ZERO(&set);
-        if (sched_getaffinity(0, sizeof set, &set) == 0) nthreads = std::min<unsigned>(nthreads ? nthreads : 1u, (unsigned)CPU_COUNT(&set));
-        nthreads = std::max(1u, std::min({ nthreads, 32u, nblocks }));
-        std::atomic<uint32_t> next{ 0 };
-        auto worker = [&] { for (uint32_t b; (b = next.fetch_add(1)) < nblocks;) pack_block(b); };
-        std::vector<std::thread> pool;
-        for (unsigned t = 1; t < nthreads; t++) pool.emplace_back(worker);
-        worker();
-        for (auto& t : pool) t.join();
-    }
+    parallel_for(nblocks, pack_block);
     for (uint32_t b = 0; b < nblocks; b++) {
         const uint64_t off = o.size();
         memcpy(&o[table + (size_t)b * 8], &off, 8);

@@ -113,6 +113,9 @@ static Mat3x4 to_z_up(const M4& g) {
 
 struct Glb {
     JVal j; const uint8_t* bin = nullptr; size_t bin_len = 0;
+    // images decoded ahead of the material loop, all at once on the host threads (a scene's PNGs are most of its load time and independent of each other);
+    // per image: 0 = not tried, 1 = decoded, 2 = failed with decode_err
+    std::vector<Image8> decoded; std::vector<char> decode_state; std::vector<std::string> decode_err;
     const JVal& arr(const char* k) const { static JVal empty; const JVal* v = j.get(k); return v && v->t == JVal::ARR ? *v : empty; }
 };
 
@@ -164,6 +167,8 @@ static bool image_rgb(const Glb& g, int64_t texture_index, Image8& img, std::str
     if (bvi < 0 || (size_t)bvi >= bvs.size()) { err = "image without bufferView (external URIs are not supported in .glb)"; return false; }
     const int64_t off = bvs.arr[(size_t)bvi].integer("byteOffset", 0), len = bvs.arr[(size_t)bvi].integer("byteLength", 0);
     if (off < 0 || len < 0 || (uint64_t)off > g.bin_len || (uint64_t)len > g.bin_len - (uint64_t)off) { err = "image out of range"; return false; }
+    if ((size_t)src < g.decode_state.size() && g.decode_state[(size_t)src] == 1) { img = g.decoded[(size_t)src]; return true; }
+    if ((size_t)src < g.decode_state.size() && g.decode_state[(size_t)src] == 2) { err = g.decode_err[(size_t)src]; return false; }
     return png_decode(g.bin + off, (size_t)len, img, err);
 }
 
@@ -249,6 +254,26 @@ bool glb_import(const std::string& path, const SceneSink& s, GlbSummary& out, st
     JParser jp{ json.data(), json.data() + json.size() };
     g.j = jp.parse();
     if (!jp.ok || g.j.t != JVal::OBJ) { err = "GLB JSON chunk does not parse"; return false; }
+
+    {   // decode every PNG some texture refers to, in parallel; what image_rgb checks (mime type, ranges) stays with image_rgb, which also reports the errors
+        const JVal& imgs = g.arr("images"); const JVal& bvs = g.arr("bufferViews");
+        std::vector<uint32_t> todo; std::vector<char> wanted(imgs.size(), 0);
+        for (const JVal& t : g.arr("textures").arr) { const int64_t src = t.integer("source", -1); if (src >= 0 && (size_t)src < imgs.size()) wanted[(size_t)src] = 1; }
+        g.decoded.resize(imgs.size()); g.decode_state.assign(imgs.size(), 0); g.decode_err.resize(imgs.size());
+        std::vector<std::pair<size_t, size_t>> range(imgs.size());
+        for (size_t i = 0; i < imgs.size(); i++) {
+            if (!wanted[i] || imgs.arr[i].str("mimeType") != "image/png") continue;
+            const int64_t bvi = imgs.arr[i].integer("bufferView", -1);
+            if (bvi < 0 || (size_t)bvi >= bvs.size()) continue;
+            const int64_t off = bvs.arr[(size_t)bvi].integer("byteOffset", 0), len = bvs.arr[(size_t)bvi].integer("byteLength", 0);
+            if (off < 0 || len < 0 || (uint64_t)off > g.bin_len || (uint64_t)len > g.bin_len - (uint64_t)off) continue;
+            range[i] = { (size_t)off, (size_t)len }; todo.push_back((uint32_t)i);
+        }
+        parallel_for((uint32_t)todo.size(), [&](uint32_t k) {
+            const size_t i = todo[k];
+            g.decode_state[i] = png_decode(g.bin + range[i].first, range[i].second, g.decoded[i], g.decode_err[i]) ? 1 : 2;
+        });
+    }
 
     // materials (World.zig:234-248)
     const JVal& mats = g.arr("materials");

@@ -5,6 +5,7 @@
 #pragma once
 #include "../../include/moonshine_amd.h"
 #include <cstdint>
+#include <functional>
 #include <string>
 #include <vector>
 
@@ -17,6 +18,8 @@ bool read_file(const std::string& path, std::vector<uint8_t>& out);
 bool exr_load(const std::string& path, Image& img, std::string& err);
 bool exr_save_rgb(const std::string& path, const float* rgba, uint32_t w, uint32_t h, std::string& err);
 bool png_decode(const uint8_t* data, size_t n, Image8& img, std::string& err);
+// runs job(i) for i in [0, n) on the host threads this process may use (affinity mask, at most 32); job must not throw
+void parallel_for(uint32_t n, const std::function<void(uint32_t)>& job);
 
 // the subset of the C ABI the importer needs (bound to HdMoonshine*/Msne* by scene_io.cpp)
 struct SceneSink {
