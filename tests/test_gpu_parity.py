@@ -157,6 +157,28 @@ def test_many_distinct_meshes_build_in_one_batch(orc, gpu_api):
     _check_rays(oc, gc, rays)
 
 
+def test_more_than_65536_meshes_in_one_batch(orc, gpu_api):
+    """66 000 one- and two-triangle meshes, each its own transformed instance: more segments than 16 bits (the segment sort takes a third pass), every segment a
+    one- or two-cluster tree, a 66 000-leaf TLAS; rays equal the oracle's"""
+    rs = np.random.default_rng(23)
+    n = 66000
+    tri = rs.normal(size=(n, 3, 3)).astype(np.float32) * 0.3
+    centre = np.stack([np.arange(n) % 41, (np.arange(n) // 41) % 41, np.arange(n) // 1681], 1).astype(np.float32) * 0.8
+    oc, gc = orc.Context(threads=8), gpu_api.Context()
+    for c in (oc, gc):
+        mat = c.create_material(scenes.LAMBERT, c.solid_texture(0.5, 0.5), c.solid_texture(0, 0, 0), color=c.solid_texture(0.7, 0.7, 0.7))
+        for k in range(n):
+            if k % 5 == 0:
+                P = np.concatenate([tri[k], tri[k, :1] + (0.2, 0.1, 0.3)]).astype(np.float32); I = np.array([[0, 1, 2], [0, 2, 3]], np.uint32)
+            else:
+                P = tri[k]; I = np.array([[0, 1, 2]], np.uint32)
+            T = np.zeros((3, 4), np.float32); T[:, :3] = np.eye(3); T[0, 1] = 0.05; T[:, 3] = centre[k]
+            c.create_instance([(c.create_mesh(P, I), mat, False)], transform=T)
+    rays = _random_rays(4000, 9, radius=30.0)
+    rays[:, :3] += (16.0, 16.0, 16.0)
+    _check_rays(oc, gc, rays)
+
+
 def test_object_pick_matches_oracle(orc, gpu_api):
     """ObjectPicker (ObjectPicker.zig:89-128, input.hlsl:24-69): one closest-hit ray through normalized sensor coordinates,
     y flipped, lens sample (0,0) on the lens AS GIVEN (second lens: a real aperture, so the ray starts on the lens rim)."""
