@@ -669,7 +669,9 @@ bool HdMoonshine::render(uint32_t sensor, uint32_t lens, uint32_t launches, bool
     hipEvent_t ev_begin = nullptr, ev_end = nullptr;
     ev_begin = next_event(); ev_end = next_event();
     if (ev_begin) (void)hipEventRecord(ev_begin, stream);
-    const uint32_t max_iter = opts.max_bounces + 3;   // hits b = 0..max_bounces+1, + one pass to retire zombies
+    // hits b = 0 .. max_bounces + 1.  The last pass creates nothing (integrator.hlsl:128 ends every path before its light samples and its next direction): it adds emission,
+    // the light samples of the pass before and retires that pass's zombies, and needs no shadow rays after it.
+    const uint32_t max_iter = opts.max_bounces + 2;
     auto timed2 = [&](int kind, hipStream_t st_, auto&& fn) {
         if (!profile) { fn(); return; }
         hipEvent_t a = next_event(), b = next_event();
@@ -704,6 +706,7 @@ bool HdMoonshine::render(uint32_t sensor, uint32_t lens, uint32_t launches, bool
             hipEvent_t shade_done = next_event();
             if (!shade_done) { fail("hipEventCreate failed"); return false; }
             CHECK_HIP(this, hipEventRecord(shade_done, pp.s0));
+            if (b + 1 == max_iter) { shadow_done = nullptr; break; }   // (k_shade of the last pass wrote no shadow rays)
             CHECK_HIP(this, hipStreamWaitEvent(sh_stream, shade_done, 0));
             timed2(1, sh_stream, [&] { launch_trace_shadow(sh_stream, trace_grid, trace_stats, sv, shq, cnt + b + 1, pp.spill2.p, d_overflow.p, d_trace_stats.p, std::max(1u, refill / 2)); });   // the shadow queue has unused entries (light samples with pdf 0): refill sooner
             shadow_done = next_event();
