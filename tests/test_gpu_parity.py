@@ -570,6 +570,37 @@ def test_textures_added_between_renders_keep_the_earlier_ones(orc, gpu_api):
 
 
 @pytest.mark.gpu
+def test_triangle_attribute_records_survive_pool_growth(orc, gpu_api):
+    """the TriAttr records sit in the same slots as the triangle records and move with them: meshes with normals / texcoords added to a live scene
+    (first a small one, then one that outgrows the pools, then one without attributes, then a second textured one) render like the oracle at every stage"""
+    rs = np.random.default_rng(31)
+    tex = rs.random((16, 16, 4)).astype(np.float32)
+    def sphere(order, with_attrs):
+        P, I = scenes.icosphere(order)
+        if not with_attrs:
+            return dict(positions=P, indices=I)
+        uv = np.stack([np.arctan2(P[:, 1], P[:, 0]) / (2 * math.pi) + 0.5, np.arccos(np.clip(P[:, 2], -1, 1)) / math.pi], -1).astype(np.float32)
+        return dict(positions=P, indices=I, normals=(P / np.linalg.norm(P, axis=1, keepdims=True)).astype(np.float32), texcoords=uv)
+    stages = [(1, True), (5, True), (3, False), (2, True)]       # order 5 = 20 480 triangles: the pools grow
+    films = {}
+    for name, c in (("gpu", gpu_api.Context()), ("orc", orc.Context(threads=8))):
+        t = c.create_texture(tex, 16, 16, "r32g32b32a32_sfloat")
+        m = c.create_material(scenes.STANDARD_PBR, c.solid_texture(0.5, 0.5), c.solid_texture(0, 0, 0), color=t, metalness=c.solid_texture(0.1), roughness=c.solid_texture(0.5), ior=1.5)
+        s = c.create_sensor(48, 36); l = c.create_lens(c.make_lens((-7, 0.0, 1.0), (1, 0, 0), (0, 0, 1), 0.8))
+        c.set_pipeline(samples_per_run=1, max_bounces=4, env_samples_per_bounce=1, mesh_samples_per_bounce=0)
+        for k, (order, attrs) in enumerate(stages):
+            g = sphere(order, attrs)
+            mesh = c.create_mesh(g["positions"], g["indices"], normals=g.get("normals"), texcoords=g.get("texcoords"))
+            T = np.zeros((3, 4), np.float32); T[:, :3] = np.eye(3) * 0.9; T[:, 3] = (0.0, 2.2 * k - 3.3, 0.0)
+            if k % 2 == 0: T[0, 1] = 0.1          # some transformed (own BLAS), some identity (world BLAS)
+            c.create_instance([(mesh, m, False)], transform=T)
+            c.clear_sensor(s); c.render(s, l, launches=3)
+            films[name, k] = c.sensor_data(s).copy()
+    for k in range(len(stages)):
+        assert_film_equal(films["gpu", k], films["orc", k], "attribute stage %d" % k)
+
+
+@pytest.mark.gpu
 def test_attribute_mode_switch_regathers_triangle_attributes(orc, gpu_api):
     """The per-triangle attribute records are gathered at BLAS build for the pipeline's mode (by vertex index / by corner, world.hlsl:127-135).
     Flipping indexed_attributes on a live context — the arrays cover both readings — must re-gather them: every mode, in either
