@@ -570,6 +570,44 @@ def test_textures_added_between_renders_keep_the_earlier_ones(orc, gpu_api):
 
 
 @pytest.mark.gpu
+def test_mesh_light_records_follow_material_and_texture_edits(orc, gpu_api):
+    """a mesh light's gathered record carries the descriptor of its emissive texture: a deferred Hydra edit of the material's emissive (hydra.zig:152-223) and textures
+    created afterwards (the texel pool moves) must re-gather it — every stage equals the oracle with the same material"""
+    import ctypes as C
+    rs = np.random.default_rng(41)
+    em = [np.concatenate([rs.uniform(1.0, 8.0, (4, 4, 3)), np.ones((4, 4, 1))], -1).astype(np.float32) for _ in range(2)]
+    big_image = rs.random((64, 64, 4)).astype(np.float32)
+    films = {}
+    for name, c in (("gpu", gpu_api.Context()), ("orc", orc.Context(threads=8))):
+        flat, black, grey = c.solid_texture(0.5, 0.5), c.solid_texture(0, 0, 0), c.solid_texture(0.7, 0.7, 0.7)
+        e0 = c.create_texture(em[0], 4, 4, "r32g32b32a32_sfloat"); e1 = c.create_texture(em[1], 4, 4, "r32g32b32a32_sfloat")
+        floor_m = c.create_material(scenes.LAMBERT, flat, black, color=grey)
+        light_m = c.create_material(scenes.LAMBERT, flat, e0, color=grey)
+        P, I = scenes.quad((-3, -3, 0), (3, -3, 0), (3, 3, 0), (-3, 3, 0))
+        c.create_instance([(c.create_mesh(P, I), floor_m, False)])
+        Pq, Iq = scenes.quad((-0.8, -0.8, 0), (0.8, -0.8, 0), (0.8, 0.8, 0), (-0.8, 0.8, 0))
+        uv = np.array([[0, 0], [1, 0], [1, 1], [0, 1]], np.float32)
+        T = np.zeros((3, 4), np.float32); T[:, :3] = np.diag([1.0, -1.0, -1.0]); T[:, 3] = (0.0, 0.0, 2.0)     # facing down
+        c.create_instance([(c.create_mesh(Pq, Iq, texcoords=uv), light_m, True)], transform=T)
+        s = c.create_sensor(40, 32); l = c.create_lens(c.make_lens((-5, 0.0, 2.5), (0.9, 0, -0.436), (0, 0, 1), 0.9))
+        c.set_pipeline(samples_per_run=1, max_bounces=3, env_samples_per_bounce=0, mesh_samples_per_bounce=2)
+        def shoot(stage):
+            c.clear_sensor(s); c.render(s, l, launches=4); films[name, stage] = c.sensor_data(s).copy()
+        shoot(0)
+        if name == "gpu": c.L.HdMoonshineSetMaterialEmissive(c.h, light_m, e1)
+        else:
+            d = orc.MsneMaterialDesc(flat, e1, scenes.LAMBERT, grey, 0, 0, 1.5); c.L.OrcSetMaterial(c.h, light_m, C.byref(d))
+        shoot(1)
+        big = c.create_texture(big_image, 64, 64, "r32g32b32a32_sfloat")     # the texel pool grows: descriptors change
+        c.create_instance([(c.create_mesh(Pq * 0.5, Iq, texcoords=uv), c.create_material(scenes.LAMBERT, flat, black, color=big), False)],
+                          transform=np.array([[1, 0, 0, 1.5], [0, 1, 0, 1.0], [0, 0, 1, 0.5]], np.float32))
+        shoot(2)
+    for stage in range(3):
+        assert_film_equal(films["gpu", stage], films["orc", stage], "light stage %d" % stage)
+    assert not np.array_equal(films["gpu", 0], films["gpu", 1])
+
+
+@pytest.mark.gpu
 def test_triangle_attribute_records_survive_pool_growth(orc, gpu_api):
     """the TriAttr records sit in the same slots as the triangle records and move with them: meshes with normals / texcoords added to a live scene
     (first a small one, then one that outgrows the pools, then one without attributes, then a second textured one) render like the oracle at every stage"""
