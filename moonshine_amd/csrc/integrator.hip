@@ -54,8 +54,9 @@ __global__ __launch_bounds__(SHADE_BLOCK) void k_raygen(ShardView sh, CameraCons
         f2 r2; r2.x = rng_float(rng); r2.y = rng_float(rng);
         f3 O, D;
         camera_generate_ray(cam, uv, r2, O, D);
-        st.ro[i] = make_float4(O.x, O.y, O.z, u2f(0u)); st.rd[i] = make_float4(D.x, D.y, D.z, 0.0f);
-        st.tp[i] = make_float4(1.0f, 1.0f, 1.0f, 0.0f); st.lr[i] = make_float4(0.0f, 0.0f, 0.0f, u2f(rng)); st.sq[i] = make_uint2(slot, 0u);
+        // a camera path starts with throughput 1, radiance 0 and its queue index as its slot: only the ray and the RNG state (in rd.w, which nothing else uses) are
+        // written — 32 B per path instead of 80; the first k_shade (first_pass) fills in the rest itself
+        st.ro[i] = make_float4(O.x, O.y, O.z, u2f(0u)); st.rd[i] = make_float4(D.x, D.y, D.z, u2f(rng));
     }
 }
 
@@ -115,7 +116,7 @@ __device__ __forceinline__ f3 estimate_direct_mis(const Frame& frame, const LSam
 
 __global__ __launch_bounds__(SHADE_BLOCK, 3) void k_shade(SceneView sc, PipelineOpts opts, PathState cur, HitBuf hits, PathState nxt, ShadowQueue shq,
                                                          const float4* c_prev /* light-sample contributions of the previous bounce */,
-                                                         float4* lbuf, BounceCounters* cnt /* [0]: this bounce, [1]: the next */) {
+                                                         float4* lbuf, BounceCounters* cnt /* [0]: this bounce, [1]: the next */, uint32_t first_pass /* the queue is k_raygen's */) {
     const uint32_t n = cnt[0].n_paths;
     const uint32_t max_bounces = opts.max_bounces, env_n = opts.env_samples, mesh_n = opts.mesh_samples;
     const bool have_lights = !(sc.alias_count == 0 || sc.alias_sum == 0.0f);                  // MeshLights::sample returns pdf 0 without them (light.hlsl:131)
@@ -143,7 +144,10 @@ __global__ __launch_bounds__(SHADE_BLOCK, 3) void k_shade(SceneView sc, Pipeline
             const uint32_t i0 = base_i + threadIdx.x;
             if (i0 < n) {
                 const float4 ro_own = cur.ro[i0];
-                s_ro[threadIdx.x] = ro_own; s_rd[threadIdx.x] = cur.rd[i0]; s_tp[threadIdx.x] = cur.tp[i0]; s_lr[threadIdx.x] = cur.lr[i0]; s_sq[threadIdx.x] = cur.sq[i0];
+                const float4 rd_own = cur.rd[i0];
+                s_ro[threadIdx.x] = ro_own; s_rd[threadIdx.x] = rd_own;
+                if (first_pass) { s_tp[threadIdx.x] = make_float4(1.0f, 1.0f, 1.0f, 0.0f); s_lr[threadIdx.x] = make_float4(0.0f, 0.0f, 0.0f, rd_own.w); s_sq[threadIdx.x] = make_uint2(i0, 0u); }
+                else { s_tp[threadIdx.x] = cur.tp[i0]; s_lr[threadIdx.x] = cur.lr[i0]; s_sq[threadIdx.x] = cur.sq[i0]; }
                 const uint32_t fl = f2u(ro_own.w);
                 if (!(fl & (PATH_FLAG_MASKED | PATH_FLAG_DEAD))) {
                     if (fl & PATH_FLAG_ZOMBIE) cat = 0u;
@@ -496,8 +500,8 @@ void launch_shade_probe(hipStream_t s, const SceneView& sc, int fn, const float*
 void launch_raygen(hipStream_t s, int grid, const ShardView& sh, const CameraConsts& cam, const PipelineOpts& o, uint32_t sample_base, uint32_t s_count, const PathState& st, BounceCounters* cnt) {
     hipLaunchKernelGGL(k_raygen, dim3(grid), dim3(SHADE_BLOCK), 0, s, sh, cam, o, sample_base, s_count, st, cnt);
 }
-void launch_shade(hipStream_t s, int grid, const SceneView& sc, const PipelineOpts& o, const PathState& cur, const HitBuf& hits, const PathState& nxt, const ShadowQueue& q, const float4* c_prev, float4* lbuf, BounceCounters* cnt) {
-    hipLaunchKernelGGL(k_shade, dim3(grid), dim3(SHADE_BLOCK), 0, s, sc, o, cur, hits, nxt, q, c_prev, lbuf, cnt);
+void launch_shade(hipStream_t s, int grid, const SceneView& sc, const PipelineOpts& o, const PathState& cur, const HitBuf& hits, const PathState& nxt, const ShadowQueue& q, const float4* c_prev, float4* lbuf, BounceCounters* cnt, bool first_pass) {
+    hipLaunchKernelGGL(k_shade, dim3(grid), dim3(SHADE_BLOCK), 0, s, sc, o, cur, hits, nxt, q, c_prev, lbuf, cnt, first_pass ? 1u : 0u);
 }
 void launch_light_tris(hipStream_t s, const SceneView& sc, uint32_t indexed_attributes, uint32_t n_instances, LightTri* out) {
     hipLaunchKernelGGL(k_light_tris, dim3((sc.alias_count + 1 + 255) / 256), dim3(256), 0, s, sc, indexed_attributes, n_instances, out);
