@@ -84,12 +84,18 @@ def cpu_baseline(a):
                            "sample": "%s at 480x270, 1 spp; %d rays in %.2f s on 1 thread" % (a.scene.upper(), rays1, dt1)}}
 
 
-def newest_counters(scene):
-    """profiles/rNN*_counters_<scene>.json: per-RAY figures from the committed rocprofv3 PMC passes of this command (HBM bytes,
-    VALU instructions, issue-busy fraction, lanes per instruction) — per ray, so they apply at any --steps"""
+def committed_counters(scene):
+    """profiles/<tag>_counters_<scene>.json of the NEWEST tag that has this scene: per-RAY figures from the committed rocprofv3 PMC passes of this
+    command (HBM bytes, VALU instructions by class, lanes per instruction) — per ray, so they apply at any --steps.  Returns (dict, file name)."""
     d = os.path.join(ROOT, "profiles")
     fs = sorted(f for f in os.listdir(d) if f.endswith("_counters_%s.json" % scene))
     return (json.load(open(os.path.join(d, fs[-1]))), fs[-1]) if fs else (None, None)
+
+
+def valu_calibration():
+    """profiles/r03_valu_calibration.json: issue cycles per wave-instruction by class, measured by tools/valu_microbench.hip on this part"""
+    f = os.path.join(ROOT, "profiles", "r03_valu_calibration.json")
+    return json.load(open(f)) if os.path.exists(f) else None
 
 
 def main():
@@ -174,6 +180,15 @@ def main():
         times.append(time.perf_counter() - t0)
     st = ctx.stats()          # sums over the repeats (every repeat traces the same rays: same sample indices)
     R = len(times)
+    # attribution pass (outside the timed region): the same K steps once more with the kernels in STREAM ORDER, so that each kernel's HIP-event
+    # duration is exclusive (in the timed repeats k_trace_shadow(b) overlaps k_trace_closest(b+1) on a second stream and both durations include
+    # the other's share of the SIMDs).  The roofline's kernel and its launch durations come from this pass: they do not depend on --steps.
+    ctx.reset_stats(); ctx.set_profiling(kernel_events=2, traversal_counters=False)
+    ctx.clear_sensor(sensor); sync()
+    ctx.render(sensor, lens, launches=a.steps, readback=False)
+    sync()
+    sa = ctx.stats()
+    ctx.set_profiling(kernel_events=True, traversal_counters=False)
 
     tt = torch.tensor(times + [float(st["closest_rays"]) / R, float(st["shadow_rays"]) / R, float(st["samples"]) / R], dtype=torch.float64, device="cuda")
     if world > 1:
@@ -195,31 +210,54 @@ def main():
         unit_bytes = {"k_trace_closest": fx["V_n_closest"] * 80 + fx["V_t_closest"] * 48 + 48,
                       "k_trace_shadow": fx["V_n_shadow"] * 80 + fx["V_t_shadow"] * 48 + 48,
                       "k_shade": fx["B_hit"] + 288.0}
-        # this rank's per-kernel time (HIP events on the stream each kernel is launched on), launches and units, summed over the repeats
-        kms = {"k_trace_closest": st["trace_closest_ms"], "k_trace_shadow": st["trace_shadow_ms"], "k_shade": st["shade_ms"]}
-        kln = {"k_trace_closest": st["trace_closest_launches"], "k_trace_shadow": st["trace_shadow_launches"], "k_shade": st["shade_launches"]}
-        kun = {"k_trace_closest": float(st["closest_rays"]), "k_trace_shadow": float(st["shadow_rays"]), "k_shade": float(st["closest_rays"])}
-        dom = max(KERNELS, key=lambda k: kms[k])          # the dominant kernel is whichever took the most time in THIS run
+        # per-kernel time, launches and units of THIS rank in the attribution pass (HIP events on the stream each kernel is launched on, kernels in stream order)
+        kms = {"k_trace_closest": sa["trace_closest_ms"], "k_trace_shadow": sa["trace_shadow_ms"], "k_shade": sa["shade_ms"]}
+        kln = {"k_trace_closest": sa["trace_closest_launches"], "k_trace_shadow": sa["trace_shadow_launches"], "k_shade": sa["shade_launches"]}
+        kun = {"k_trace_closest": float(sa["closest_rays"]), "k_trace_shadow": float(sa["shadow_rays"]), "k_shade": float(sa["closest_rays"])}
+        dom = max(KERNELS, key=lambda k: kms[k])          # the dominant kernel: most exclusive time
         nl = max(int(kln[dom]), 1)
         avg_ms = kms[dom] / nl
         bytes_per_launch = unit_bytes[dom] * kun[dom] / nl
-        achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
-        roof = {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
-                "frac": achieved / (HBM_PEAK / 1e9), "traffic": None, "algorithmic_bytes_per_launch": bytes_per_launch,
-                "bytes_per_unit": unit_bytes[dom], "units_per_launch": kun[dom] / nl, "avg_launch_ms": avg_ms, "launches": nl,
-                "note": "k_trace_closest(b+1) and k_trace_shadow(b) overlap on two streams: per-kernel durations include co-residency"}
-        cnt, cnt_file = newest_counters(a.scene if a.env == "constant" else a.scene + "_sky")
-        if cnt and dom in cnt["kernels"]:
-            k = cnt["kernels"][dom]
-            roof["traffic"] = k["hbm_bytes_per_unit"] * kun[dom] / nl           # measured HBM bytes per launch (PMC, per unit x this run's units)
-            roof["valu"] = {"issue_busy_frac": k["valu_issue_busy_frac"], "lanes_per_instruction": k["lanes_per_valu_instruction"],
-                            "thread_instructions_per_unit": k["valu_thread_instructions_per_unit"], "wave_instructions_per_unit": k["valu_wave_instructions_per_unit"],
-                            "source": "profiles/" + cnt_file}
-        if roof["traffic"] and avg_ms > 0:
-            roof["traffic_frac"] = roof["traffic"] / (avg_ms * 1e-3) / HBM_PEAK    # measured HBM bytes against the same peak
-        if roof["frac"] > 1.0:
-            roof["note"] += ("; frac > 1: most of the algorithmic bytes are re-reads of BVH nodes that L2 / Infinity Cache serve (the scene's BVH is smaller than the cache), "
-                             "so HBM is not what bounds this kernel — measured traffic is `traffic_frac` of peak — VALU issue is (`valu.issue_busy_frac`, `valu.lanes_per_instruction` of 64)")
+        hbm_alg = bytes_per_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0       # algorithmic bytes / launch duration
+        cnt, cnt_file = committed_counters(a.scene if a.env == "constant" else a.scene + "_sky")
+        cal = valu_calibration()
+        ck = cnt["kernels"].get(dom) if cnt else None
+
+        def valu_cycles(k):
+            """issue cycles one unit (ray / path) of kernel k needs on a SIMD: its wave-instructions per unit by class (committed PMC pass) x the calibrated
+            cost of the class; INT32 at its cheaper value and nominal 2 / 4 / 8 cycles: a LOWER bound"""
+            e = cnt["kernels"][k]; cc = cal["class_cycles"]
+            if "valu_class_per_unit" not in e:
+                return None
+            cl = e["valu_class_per_unit"]
+            listed = sum(cl[c] for c in ("FMA_F32", "MUL_F32", "ADD_F32", "INT32", "CVT", "TRANS_F32"))
+            return sum(cl[c] * cc[c] for c in ("FMA_F32", "MUL_F32", "ADD_F32", "INT32", "CVT", "TRANS_F32")) + (e["valu_wave_instructions_per_unit"] - listed) * cc["OTHER"]
+
+        hbm = {"achieved": hbm_alg, "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": hbm_alg / (HBM_PEAK / 1e9), "algorithmic_bytes_per_launch": bytes_per_launch,
+               "bytes_per_unit": unit_bytes[dom]}
+        vc = valu_cycles(dom) if (cnt and cal and ck) else None
+        if vc is not None and hbm["frac"] > 1.0:
+            # the §8(d) HBM figure exceeds the peak: most algorithmic bytes are re-reads that L2 / Infinity Cache serve, HBM is not what bounds this kernel.
+            # What does: vector-instruction ISSUE.  achieved = issue cycles the kernel's instructions need per second (calibrated per class on this part),
+            # peak = 1024 SIMDs x 2.4 GHz.
+            peak = cal["peak_simd_cycles_per_s"]
+            ach = vc * (kun[dom] / nl) / (avg_ms * 1e-3)
+            roof = {"bound": "valu", "kernel": dom, "achieved": ach / 1e9, "peak": peak / 1e9, "unit": "G SIMD-cycles/s", "frac": ach / peak,
+                    "issue_cycles_per_unit": vc, "wave_instructions_per_unit": ck["valu_wave_instructions_per_unit"],
+                    "lanes_per_instruction": ck["lanes_per_valu_instruction"], "class_per_unit": ck["valu_class_per_unit"],
+                    "from": {"instruction_counts": "profiles/" + cnt_file, "cycles_per_class": "profiles/r03_valu_calibration.json"},
+                    "hbm_algorithmic_frac": hbm["frac"], "hbm_algorithmic": hbm}
+        else:
+            roof = dict(hbm, bound="hbm", kernel=dom)
+        roof.update({"units_per_launch": kun[dom] / nl, "avg_launch_ms": avg_ms, "launches": nl, "traffic": None,
+                     "timing": "HIP events around every launch of the kernel in an extra pass of the same K steps with the kernels in stream order (exclusive durations)"})
+        if ck:
+            roof["traffic"] = ck["hbm_bytes_per_unit"] * kun[dom] / nl           # HBM bytes per launch: PMC figure per unit (committed) x this run's units
+            roof["traffic_from"] = "profiles/" + cnt_file + " (FETCH_SIZE x2 + WRITE_SIZE per unit, measured by rocprofv3 on this command) x this run's units per launch"
+            if avg_ms > 0:
+                roof["traffic_frac"] = roof["traffic"] / (avg_ms * 1e-3) / HBM_PEAK
+            if "memory_pipeline" in ck:
+                roof["memory_pipeline"] = dict(ck["memory_pipeline"], **{"from": "profiles/" + cnt_file})
         rates = [rays / t / 1e6 for t in times]
         out = {
             "metric": "Mrays/sec, 1M-tri scene @1080p" if a.scene == "s1" else "Mrays/sec, 10M-tri instanced scene @1080p",
@@ -235,11 +273,13 @@ def main():
             "rays": {"closest": closest, "shadow": shadow, "per_sample": rays / max(samples, 1.0)},
             "roofline": roof,
             "whole_path_roofline_frac": (rays / dt * fx["B_ray"] + samples / dt * (fx["B_shade"] + 32)) / HBM_PEAK / world,
-            "kernel_ms_per_repeat": {k: kms[k] / R for k in KERNELS}, "render_ms_per_repeat": st["render_ms"] / R,
-            "kernel_frac": {k: unit_bytes[k] * kun[k] / max(kms[k] * 1e-3, 1e-12) / HBM_PEAK for k in KERNELS},
+            "kernel_ms_stream_order": {k: kms[k] for k in KERNELS}, "render_ms_stream_order": sa["render_ms"], "render_ms_per_repeat": st["render_ms"] / R,
+            "kernel_hbm_algorithmic_frac": {k: unit_bytes[k] * kun[k] / max(kms[k] * 1e-3, 1e-12) / HBM_PEAK for k in KERNELS},
+            "kernel_valu_frac": ({k: valu_cycles(k) * kun[k] / max(kms[k] * 1e-3, 1e-12) / cal["peak_simd_cycles_per_s"] for k in KERNELS}
+                                 if (cnt and cal and all("valu_class_per_unit" in cnt["kernels"].get(k, {}) for k in KERNELS)) else None),
             # for tools/profile_counters.py: what the counters of a rocprofv3 run of this command have to be divided by
-            "profile_totals": {"closest_rays": warm["closest_rays"] + st["closest_rays"], "shadow_rays": warm["shadow_rays"] + st["shadow_rays"],
-                               "samples": warm["samples"] + st["samples"]},
+            "profile_totals": {"closest_rays": warm["closest_rays"] + st["closest_rays"] + sa["closest_rays"], "shadow_rays": warm["shadow_rays"] + st["shadow_rays"] + sa["shadow_rays"],
+                               "samples": warm["samples"] + st["samples"] + sa["samples"]},
         }
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(a)

@@ -269,7 +269,9 @@ const char* MsneGroupGetLastError(const MsneGroup*);     /* NULL group -> last c
 /* Part 3 — diagnostics for parity tests and profiling (no reference   */
 /* equivalent; never needed by a renderer front end)                   */
 /* ------------------------------------------------------------------ */
-/* kernel_events: bracket every trace/shade launch with HIP events on the render stream (MsneStats *_ms fields);
+/* kernel_events: 1 = bracket every trace/shade launch with HIP events on the stream it is launched on (MsneStats *_ms fields);
+ * 2 = the same with the kernels in stream order (the any-hit kernel of a bounce is not overlapped with the closest-hit kernel of
+ * the next one), so that per-kernel durations are exclusive — what bench.py's roofline attribution pass uses;
  * traversal_counters: count BVH node visits / triangle tests inside the trace kernels. */
 void MsneSetProfiling(HdMoonshine*, int kernel_events, int traversal_counters);
 int MsneGetTraversalCounters(HdMoonshine*, uint64_t out[20]); /* [0..3] closest {nodes,tris}, shadow {nodes,tris}; [4..19] wave-cycle profiles */

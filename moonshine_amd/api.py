@@ -12,7 +12,7 @@ import numpy as np
 from . import tiles
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libmoonshine_amd.so")
+LIB_PATH = os.environ.get("MSNE_LIB") or os.path.join(_HERE, "libmoonshine_amd.so")   # $MSNE_LIB: an experimental build (tools/variant_rates.py)
 _LIB = None
 
 

@@ -148,7 +148,7 @@ struct HdMoonshine {
     // long the overlap buys nothing (S1 x 64 launches: 108.5 ms overlapped, 108.8 ms in stream order) and only blurs per-kernel timings;
     // it pays in the thin tails of a batch, where neither kernel fills the chip.  $MSNE_SERIAL: 1 = always in stream order, 0 = always
     // overlapped, unset = in stream order for the first `serial_bounces` bounces of batches of at least `serial_min_paths` paths.
-    int serial_mode = -1; uint32_t serial_bounces = 4; size_t serial_min_paths = 96u << 20;   // (overlap is worth 2.5 % on a 2-way shard = 67 M paths, 3.6 % at 20 launches = 41 M, 6 % on an 8-way shard)
+    int serial_mode = -1, serial_saved = -2; uint32_t serial_bounces = 4; size_t serial_min_paths = 96u << 20;   // (overlap is worth 2.5 % on a 2-way shard = 67 M paths, 3.6 % at 20 launches = 41 M, 6 % on an 8-way shard)
     int n_pipes = 1;                               // $MSNE_PIPES (measured on S1: more pipes never won — bigger batches beat overlapped smaller ones)
     size_t single_pipe_paths = 48u << 20;          // batches at least this large run on one pipe (tails are negligible there)
     DevBuf<float4> d_lbuf;
@@ -1029,7 +1029,13 @@ void MsneResetStats(HdMoonshine* c) {
 }
 
 // ---- diagnostics used by the parity tests (no reference equivalent) ----
-void MsneSetProfiling(HdMoonshine* c, int kernel_events, int traversal_counters) { LOCK(c); c->profile = kernel_events != 0; c->trace_stats = traversal_counters != 0; }
+void MsneSetProfiling(HdMoonshine* c, int kernel_events, int traversal_counters) {
+    LOCK(c); c->profile = kernel_events != 0; c->trace_stats = traversal_counters != 0;
+    // kernel_events == 2: time the kernels in stream order (k_trace_shadow(b) is not overlapped with k_trace_closest(b+1)), so that the per-kernel
+    // durations are exclusive; 0 / 1 restore the context's own choice ($MSNE_SERIAL or the batch-size rule)
+    if (kernel_events == 2) { if (c->serial_saved == -2) c->serial_saved = c->serial_mode; c->serial_mode = 1; }
+    else if (c->serial_saved != -2) { c->serial_mode = c->serial_saved; c->serial_saved = -2; }
+}
 int MsneGetTraversalCounters(HdMoonshine* c, uint64_t out[20]) {   // [0..3] closest {node visits, tri tests}, shadow {..}; [4..11] closest wave-cycle profile, [12..19] shadow
     LOCK(c);
     if (!c->bind() || !c->d_trace_stats.p) { for (int i = 0; i < 20; i++) out[i] = 0; return 0; }

@@ -180,17 +180,22 @@ __device__ __forceinline__ void step_node(Lane& L, const SceneView& sc, const St
     const uint32_t nz[2] = { sz ? w4.z : w3.x, sz ? w4.w : w3.y }, fz[2] = { sz ? w3.x : w4.z, sz ? w3.y : w4.w };
     // (v_pk_fma_f32 for the {entry, exit} pairs was measured: 24 instructions fewer per node, 3 % slower overall)
     const float tlimit = L.best.t;
-    uint32_t hits8 = 0;
+    // hit <=> f * 1.00001 - n >= 0.  On gfx950 only v_fma / v_mul / v_add / v_sub (f32) and a few integer ops issue in 2 cycles per wave, everything else —
+    // compares, selects, min / max, conversions — in 4 (profiles/r03_valu_microbench.txt): ONE fma, whose sign bit ONE v_alignbit shifts into a mask of
+    // MISS bits, replaces mul + cmp + cndmask + or.  Children 7..0, so that child 0 ends up in bit 0.  (A NaN can only come from a NaN ray; either sign
+    // is fine for it: boxes only gate which triangles are tested.)
+    uint32_t miss8 = 0;
 #pragma unroll
-    for (int i = 0; i < 8; i++) {
+    for (int i = 7; i >= 0; i--) {
         const int wi = i >> 2, sh = (i & 3) * 8;
         const float t0x = __builtin_fmaf((float)((nx[wi] >> sh) & 0xff), ax, bx), t1x = __builtin_fmaf((float)((fx[wi] >> sh) & 0xff), ax, bx);
         const float t0y = __builtin_fmaf((float)((ny[wi] >> sh) & 0xff), ay, by), t1y = __builtin_fmaf((float)((fy[wi] >> sh) & 0xff), ay, by);
         const float t0z = __builtin_fmaf((float)((nz[wi] >> sh) & 0xff), az, bz), t1z = __builtin_fmaf((float)((fz[wi] >> sh) & 0xff), az, bz);
         const float n = fmaxf(fmaxf(t0x, t0y), fmaxf(t0z, 0.0f));
         const float f = fminf(fminf(t1x, t1y), fminf(t1z, tlimit));
-        hits8 |= (n <= f * 1.00001f) ? (1u << i) : 0u;
+        miss8 = __builtin_amdgcn_alignbit(miss8, f2u(__builtin_fmaf(f, 1.00001f, -n)), 31);   // (miss8 << 1) | sign
     }
+    const uint32_t hits8 = ~miss8 & 0xffu;
     // empty slots (inverted boxes) can pass the slack test when the node is tiny against its distance: imask / lmask drop them
     const uint32_t lmask = w1.z & 0xffu;
     const uint32_t ihits = hits8 & imask, lhits = hits8 & lmask;
@@ -477,6 +482,7 @@ __device__ __forceinline__ void trace_wave_loop(const SceneView& sc, uint32_t n,
         }
         lap(3);
         if (STATS && do_n2) cyc[6] += __popcll(__ballot(want_n2));   // node-lane steps
+        if (STATS && !INSTANCED && do_t) cyc[2] += 1;   // (scenes without a TLAS level: slot 2 counts the iterations that ran the triangle body)
         if (do_t && want_t) {
             if (step_tri<ANY_HIT, STATS>(L, sc, nt)) { L.sp = 0; L.sb = 0; L.g1 = 0; L.ta1 = 0; L.tb1 = 0; store(my, L); active = false; }
         }

@@ -1,4 +1,4 @@
-"""Turns the scratch output of tools/profile_round2.sh TAG SCENE (gpurun_out/TAG_SCENE_{trace,fetch,write,sq}) into the files
+"""Turns the scratch output of tools/profile_round3.sh TAG SCENE (gpurun_out/TAG_SCENE_{trace,fetch,write,sq}) into the files
 committed under profiles/ and read by bench.py:   python tools/profile_counters.py TAG SCENE
 
   profiles/TAG_kernel_stats_SCENE.txt   rocprofv3 --kernel-trace --stats table of the bench command + its JSON line
@@ -7,7 +7,11 @@ committed under profiles/ and read by bench.py:   python tools/profile_counters.
                                         /opt/skills/guides/MI355X_MICROARCH.md (both counters are in KB); an upper bound for 16-B gathers
       valu_wave_instructions_per_unit   SQ_INSTS_VALU / units          valu_thread_instructions_per_unit   SQ_THREAD_CYCLES_VALU / units
       lanes_per_valu_instruction        SQ_THREAD_CYCLES_VALU / SQ_INSTS_VALU (of 64)
-      valu_issue_busy_frac              SQ_ACTIVE_INST_VALU (quad-cycles) x 4 / (1024 SIMDs x kernel time x 2.4 GHz)
+      valu_issue_busy_frac              SQ_ACTIVE_INST_VALU (quad-cycles) x 4 / (1024 SIMDs x kernel time x 2.4 GHz) — NOT a utilisation: the counter books one quad-cycle
+                                        per instruction (two for v_rcp) whatever it costs (tools/valu_microbench.hip under the same counters: ACTIVE / INSTS = 1.000), so it
+                                        over-counts the 2-cycle f32 fma / mul / add; kept for comparison with round 2
+      valu_class_per_unit               SQ_INSTS_VALU_{FMA,MUL,ADD}_F32 / INT32 / CVT / TRANS_F32 per unit (pass "valu")
+      memory_pipeline                   TA / TD busy, L1 tag accesses, L1 -> L2 requests, L2 hits / misses per unit (passes "mem", "mem2")
   Counters are summed over ALL dispatches of a kernel in the run (warm-up and every repeat) and divided by the units the same run
   processed (bench.py's `profile_totals`).
 """
@@ -69,7 +73,9 @@ open(os.path.join(ROOT, "profiles", "%s_kernel_stats_%s.txt" % (tag, scene)), "w
 out = {"command": open(G + "_cmd.txt").read().strip(), "unit": {"k_trace_closest": "closest-hit ray", "k_trace_shadow": "shadow ray", "k_shade": "path shaded (= closest-hit ray)"},
        "fetch_correction": "FETCH_SIZE x2 (gfx950 tallies 128-B requests at 64 B; MI355X_MICROARCH.md HBM section), KB -> B x1024", "clock_ghz_assumed": 2.4, "kernels": {}}
 per = {}
-for sub in ("fetch", "write", "sq"):
+for sub in ("fetch", "write", "sq", "valu", "mem", "mem2"):
+    if not os.path.exists(G + "_%s.log" % sub):
+        continue
     tot = bench_line(G + "_%s.log" % sub)["profile_totals"]
     units = {"k_trace_closest": tot["closest_rays"], "k_trace_shadow": tot["shadow_rays"], "k_shade": tot["closest_rays"]}
     val, dur, n = counters(sub)
@@ -89,6 +95,21 @@ for k in KERNELS:
     e["vmem_rd_instructions_per_unit"] = c["SQ_INSTS_VMEM_RD"] / su[k]
     e["wave_cycles_split"] = {"active": c["SQ_ACTIVE_INST_ANY"] / max(c["SQ_WAVE_CYCLES"], 1.0), "wait_inst": c["SQ_WAIT_INST_ANY"] / max(c["SQ_WAVE_CYCLES"], 1.0),
                               "wait_any": c["SQ_WAIT_ANY"] / max(c["SQ_WAVE_CYCLES"], 1.0)}
+    if "valu" in per:   # instruction classes (tools/profile_round3.sh pass "valu"): what bench.py's VALU roofline prices with profiles/r03_valu_calibration.json
+        v, _, _, u = per["valu"]
+        e["valu_class_per_unit"] = {c: v[k]["SQ_INSTS_VALU_" + c] / u[k] for c in ("FMA_F32", "MUL_F32", "ADD_F32", "INT32", "CVT", "TRANS_F32")}
+        e["salu_instructions_per_unit"] = v[k]["SQ_INSTS_SALU"] / u[k]
+    if "mem" in per:    # the vector-memory pipeline: TA / TD busy fractions (summed over the 256 CUs' units, per GRBM_GUI_ACTIVE cycle of one XCD), L1 tag accesses, L1 -> L2 requests
+        v, d, _, u = per["mem"]
+        cyc = v[k]["GRBM_GUI_ACTIVE"] / 8.0    # (the counter sums the 8 XCDs)
+        e["memory_pipeline"] = {"ta_busy_frac": v[k]["TA_TA_BUSY_sum"] / 256.0 / cyc, "td_busy_frac": v[k]["TD_TD_BUSY_sum"] / 256.0 / cyc,
+                                "tcp_pending_stall_frac": v[k]["TCP_PENDING_STALL_CYCLES_sum"] / 256.0 / cyc,
+                                "l1_tag_accesses_per_unit": v[k]["TCP_TOTAL_CACHE_ACCESSES_sum"] / u[k], "l1_to_l2_read_requests_per_unit": v[k]["TCP_TCC_READ_REQ_sum"] / u[k],
+                                "clock_ghz": cyc / max(d[k], 1.0)}
+    if "mem2" in per:
+        v, _, _, u = per["mem2"]
+        e.setdefault("memory_pipeline", {}).update({"l2_hits_per_unit": v[k]["TCC_HIT_sum"] / u[k], "l2_misses_per_unit": v[k]["TCC_MISS_sum"] / u[k],
+                                                     "vmem_read_instructions_per_unit": v[k]["SQ_INSTS_VMEM_RD"] / u[k]})
     out["kernels"][k] = e
 json.dump(out, open(os.path.join(ROOT, "profiles", "%s_counters_%s.json" % (tag, scene)), "w"), indent=1)
 print(json.dumps(out, indent=1))
