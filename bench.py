@@ -25,6 +25,7 @@ import torch  # noqa: E402  (before the HIP library: one HIP runtime per process
 import torch.distributed as dist  # noqa: E402
 
 from moonshine_amd import api, scenes  # noqa: E402
+from moonshine_amd.hostinfo import usable_cores  # noqa: E402
 
 HBM_PEAK = 8.0e12  # B/s, /opt/skills/guides/MI355X_MICROARCH.md "HBM3E peak BW"
 KERNELS = ("k_trace_closest", "k_trace_shadow", "k_shade")
@@ -34,24 +35,6 @@ def build_scene(ctx, a):
     if a.scene == "s2":
         return scenes.s2(ctx, extent=(a.width, a.height))
     return scenes.s1(ctx, extent=(a.width, a.height), env=a.env)
-
-
-def usable_cores():
-    """hardware threads this process may actually use: the affinity mask, capped by the cgroup CPU quota (the GPU boxes show 256 logical
-    CPUs under a 16-CPU quota: 256 runnable threads there are throttled to 16 CPUs' worth of time)"""
-    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-    try:
-        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
-        if quota != "max":
-            n = min(n, max(1, int(int(quota) / int(period))))
-    except Exception:
-        try:
-            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read()); p_ = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
-            if q > 0:
-                n = min(n, max(1, q // p_))
-        except Exception:
-            pass
-    return n
 
 
 def cpu_baseline(a):

@@ -274,6 +274,8 @@ const char* MsneGroupGetLastError(const MsneGroup*);     /* NULL group -> last c
  * the next one), so that per-kernel durations are exclusive — what bench.py's roofline attribution pass uses;
  * traversal_counters: count BVH node visits / triangle tests inside the trace kernels. */
 void MsneSetProfiling(HdMoonshine*, int kernel_events, int traversal_counters);
+/* bytes of texture data the context keeps in HBM: every texture in the format it was created with (MaterialManager.zig:351-390), each rounded up to 16 B */
+uint64_t MsneGetTexelPoolBytes(HdMoonshine*);
 int MsneGetTraversalCounters(HdMoonshine*, uint64_t out[20]); /* [0..3] closest {nodes,tris}, shadow {nodes,tris}; [4..19] wave-cycle profiles */
 /* queue lengths of the last batch, per bounce b: out[4b..4b+3] = {path-queue entries, of which entries without a ray, shadow-queue entries, shadow rays traced}; returns the number of bounces written */
 int MsneGetBounceCounters(HdMoonshine*, uint32_t* out, uint32_t max_bounces);

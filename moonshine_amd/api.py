@@ -132,6 +132,7 @@ SYMBOLS = [
     ("MsneExrSave", C.c_int, [C.c_char_p, _vp, Extent2D]),
     ("MsneGetIoError", C.c_char_p, []),
     ("MsneSetProfiling", None, [_vp, C.c_int, C.c_int]),
+    ("MsneGetTexelPoolBytes", C.c_uint64, [_vp]),
     ("MsneGetTraversalCounters", C.c_int, [_vp, C.POINTER(C.c_uint64)]),
     ("MsneTraceRays", C.c_int, [_vp, _vp, _u32, C.c_int, _vp, _vp]),
     ("MsnePick", C.c_int, [_vp, _u32, _u32, F32x2, _vp]),
@@ -197,6 +198,8 @@ def load_library(path=None):
         raise MoonshineError("libmoonshine_amd.so not built (%s); run `python -m moonshine_amd.build` — there is no CPU fallback" % p)
     L = C.CDLL(p)
     for name, res, args in SYMBOLS:
+        if os.environ.get("MSNE_LIB") and not hasattr(L, name):
+            continue             # an experimental build from an older revision (A/B timing only)
         f = getattr(L, name)   # AttributeError if the .so does not export it
         f.restype = res
         f.argtypes = args
@@ -372,6 +375,9 @@ class Context:
             self._err("MsneUnpackGatheredFilm")
 
     # ---- statistics / diagnostics ----
+    def texel_pool_bytes(self):
+        return int(self.L.MsneGetTexelPoolBytes(self.h))
+
     def set_profiling(self, kernel_events=True, traversal_counters=False):
         self.L.MsneSetProfiling(self.h, int(kernel_events), int(traversal_counters))
 

@@ -293,9 +293,12 @@ def piz_block(lines, words_per_pixel, use_rle=True):
     return struct.pack("<HH", mn, mx) + (bitmap[mn:mx + 1].tobytes() if mn <= mx else b"") + struct.pack("<i", len(huf)) + huf
 
 
-def exr_bytes(rgba, channels="RGB", pixel_type="float", compression="none", piz_rle=True):
-    """(H, W, 4) float32 -> scanline OpenEXR bytes.  channels: subset of 'ABGR' letters; pixel_type float|half;
-    compression none|zips|zip|piz.  Written from the OpenEXR file-layout document, independently of the C++ reader."""
+def exr_bytes(rgba, channels="RGB", pixel_type="float", compression="none", piz_rle=True, tiles=None, levels="one", line_order=0):
+    """(H, W, 4) float32 -> OpenEXR bytes.  channels: subset of 'ABGR' letters; pixel_type float|half; compression none|zips|zip|piz.
+    Scanline file by default; tiles=(tw, th) writes a single-part TILED file (version bit 0x200, `tiles` attribute, one chunk per tile with
+    its {tile x, tile y, level x, level y} coordinates), levels = "one" or "mipmap" (box-filtered lower levels, rounded down, which a reader of the
+    full-resolution image has to step over); line_order 1 = DECREASING_Y (chunks stored bottom-up).  Written from the OpenEXR file-layout
+    document, independently of the C++ reader."""
     a = np.asarray(rgba, np.float32)
     h, w, _ = a.shape
     names = sorted(channels)
@@ -306,20 +309,23 @@ def exr_bytes(rgba, channels="RGB", pixel_type="float", compression="none", piz_
         return name.encode() + b"\0" + typ.encode() + b"\0" + struct.pack("<I", len(data)) + data
     chl = b"".join(n.encode() + b"\0" + struct.pack("<iBBBBii", ptype, 0, 0, 0, 0, 1, 1) for n in names) + b"\0"
     box = struct.pack("<iiii", 0, 0, w - 1, h - 1)
-    hdr = struct.pack("<II", 20000630, 2) + attr("channels", "chlist", chl) + attr("compression", "compression", bytes([comp])) \
-        + attr("dataWindow", "box2i", box) + attr("displayWindow", "box2i", box) + attr("lineOrder", "lineOrder", b"\0") \
+    hdr = struct.pack("<II", 20000630, 2 | (0x200 if tiles else 0)) + attr("channels", "chlist", chl) + attr("compression", "compression", bytes([comp])) \
+        + attr("dataWindow", "box2i", box) + attr("displayWindow", "box2i", box) + attr("lineOrder", "lineOrder", bytes([line_order])) \
         + attr("pixelAspectRatio", "float", struct.pack("<f", 1.0)) + attr("screenWindowCenter", "v2f", struct.pack("<ff", 0, 0)) \
-        + attr("screenWindowWidth", "float", struct.pack("<f", 1.0)) + b"\0"
-    lines = {0: 1, 2: 1, 3: 16, 4: 32}[comp]
+        + attr("screenWindowWidth", "float", struct.pack("<f", 1.0))
+    if tiles:
+        hdr += attr("tiles", "tiledesc", struct.pack("<IIB", tiles[0], tiles[1], {"one": 0, "mipmap": 1}[levels]))   # rounding mode ROUND_DOWN (high nibble 0)
+    hdr += b"\0"
     col = {"R": 0, "G": 1, "B": 2, "A": 3}
-    blocks = []
-    for y0 in range(0, h, lines):
+
+    def pack(img, y0, y1, x0, x1):
+        """the pixels [y0, y1) x [x0, x1) of img as a chunk's data: per line the channels in file order; compressed when that is smaller"""
         raw = bytearray()
         rows = []
-        for y in range(y0, min(y0 + lines, h)):
+        for y in range(y0, y1):
             rows.append([])
             for n in names:
-                v = a[y, :, col[n]]
+                v = img[y, x0:x1, col[n]]
                 enc = (v.astype(np.float16) if ptype == 1 else v).tobytes()
                 raw += enc
                 rows[-1].append(np.frombuffer(enc, "<u2"))
@@ -337,13 +343,37 @@ def exr_bytes(rgba, channels="RGB", pixel_type="float", compression="none", piz_
             z = zlib.compress(d.astype(np.uint8).tobytes())
             if len(z) < len(data):
                 data = z
-        blocks.append((y0, data))
-    table = len(hdr)
-    off = table + 8 * len(blocks)
-    offs, body = [], bytearray()
-    for y0, data in blocks:
-        offs.append(off + len(body))
-        body += struct.pack("<ii", y0, len(data)) + data
+        return data
+
+    chunks = []          # (chunk header bytes, data) in offset-table order
+    if tiles:
+        tw, th = tiles
+        img, lvl = a, 0
+        while True:
+            lh, lw = img.shape[:2]
+            ys = list(range(0, lh, th))
+            for ty, y0 in enumerate(ys):
+                for tx, x0 in enumerate(range(0, lw, tw)):
+                    chunks.append((struct.pack("<iiii", tx, ty, lvl, lvl), pack(img, y0, min(y0 + th, lh), x0, min(x0 + tw, lw))))
+            if levels == "one" or (lw == 1 and lh == 1):
+                break
+            nh, nw = max(lh // 2, 1), max(lw // 2, 1)                      # ROUND_DOWN
+            img = np.stack([img[min(2 * y, lh - 1)] for y in range(nh)])[:, [min(2 * x, lw - 1) for x in range(nw)]] * 0.5 \
+                + np.stack([img[min(2 * y + 1, lh - 1)] for y in range(nh)])[:, [min(2 * x + 1, lw - 1) for x in range(nw)]] * 0.5
+            lvl += 1
+    else:
+        lines = {0: 1, 2: 1, 3: 16, 4: 32}[comp]
+        for y0 in range(0, h, lines):
+            chunks.append((struct.pack("<i", y0), pack(a, y0, min(y0 + lines, h), 0, w)))
+    # the offset table is always in increasing-y (and level) order; DECREASING_Y only changes where the chunks lie in the file
+    order = list(range(len(chunks)))
+    stored = order[::-1] if line_order == 1 else order
+    off = len(hdr) + 8 * len(chunks)
+    offs, body = [0] * len(chunks), bytearray()
+    for k in stored:
+        head, data = chunks[k]
+        offs[k] = off + len(body)
+        body += head + struct.pack("<i", len(data)) + data
     return hdr + b"".join(struct.pack("<Q", o) for o in offs) + bytes(body)
 
 

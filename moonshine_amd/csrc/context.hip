@@ -63,7 +63,7 @@ template <typename T> struct DevBuf {
     DevBuf() = default; DevBuf(const DevBuf&) = delete; DevBuf& operator=(const DevBuf&) = delete;
 };
 
-struct TextureH { uint32_t w, h; std::vector<float> rgba; float first[4]; size_t offset = 0; bool on_device = false; };   // rgba: float RGBA texels until they are on the device, then released
+struct TextureH { uint32_t w, h, format; std::vector<uint8_t> raw; float first[4]; size_t offset = 0; bool on_device = false; };   // raw: the texels in their own format until they are on the device, then released; offset in 16-B units
 struct MeshH {
     DevBuf<float> positions, normals, texcoords; DevBuf<uint32_t> indices;
     std::vector<float> h_positions; std::vector<uint32_t> h_indices;   // host copies for the alias-table areas (Accel.zig:503-519)
@@ -111,7 +111,7 @@ struct HdMoonshine {
     std::vector<SensorH*> sensors;
 
     // device scene tables
-    DevBuf<float4> d_texels; DevBuf<TexDesc> d_texdesc; size_t texels_end = 0;   // texels of the textures already on the device
+    DevBuf<uint4> d_texels; DevBuf<float> d_srgb; DevBuf<TexDesc> d_texdesc; size_t texels_end = 0;   // texel pool (16-B units, each texture in its own format); texels_end: what is already on the device
     DevBuf<MaterialRec> d_materials;
     DevBuf<MeshRec> d_meshes;
     DevBuf<GeometryRec> d_geometries;
@@ -197,12 +197,6 @@ struct HdMoonshine {
 // ---------------- textures ----------------
 namespace msne_host { void parallel_for(uint32_t n, const std::function<void(uint32_t)>& job); }   // host/exr.cpp: the host threads this process may use
 
-static float half_to_float(uint16_t h) {
-    const uint32_t s = (uint32_t)(h >> 15) << 31, e = (h >> 10) & 0x1f, m = h & 0x3ff;
-    if (e == 0) { if (m == 0) return u2f(s); const float f = (float)m * 0x1p-24f; return (h >> 15) ? -f : f; }
-    if (e == 31) return u2f(s | 0x7f800000u | (m << 13));
-    return u2f(s | ((e + 112) << 23) | (m << 13));
-}
 static const float* srgb_lut() {
     struct Lut { float v[256]; Lut() { for (int i = 0; i < 256; i++) { const double x = i / 255.0; v[i] = (float)(x <= 0.04045 ? x / 12.92 : pow((x + 0.055) / 1.055, 2.4)); } } };
     static const Lut lut;   // (initialised once, thread-safely: contexts on different threads create textures concurrently)
@@ -211,28 +205,13 @@ static const float* srgb_lut() {
 static int64_t add_texture(HdMoonshine* c, const void* bytes, uint32_t w, uint32_t h, int fmt) {
     if (!bytes || w == 0 || h == 0) { c->fail("texture: bad arguments"); return -1; }
     if (fmt < 0 || fmt > MSNE_FORMAT_R16G16B16A16_SFLOAT) { c->fail("texture: unknown format"); return -1; }
-    TextureH t; t.w = w; t.h = h; t.rgba.resize((size_t)w * h * 4);
-    const size_t n = (size_t)w * h;
-    const uint8_t* b = (const uint8_t*)bytes; const float* f = (const float*)bytes; const uint16_t* hf = (const uint16_t*)bytes;
-    const float* lut = srgb_lut();
-    auto convert = [&](size_t i0, size_t i1) {
-        for (size_t i = i0; i < i1; i++) {
-            float* o = &t.rgba[4 * i]; o[0] = o[1] = o[2] = 0.0f; o[3] = 1.0f;
-            switch (fmt) {
-                case MSNE_FORMAT_R8G8B8A8_SRGB: o[0] = lut[b[4 * i]]; o[1] = lut[b[4 * i + 1]]; o[2] = lut[b[4 * i + 2]]; o[3] = (float)b[4 * i + 3] / 255.0f; break;
-                case MSNE_FORMAT_R8G8_UNORM: o[0] = (float)b[2 * i] / 255.0f; o[1] = (float)b[2 * i + 1] / 255.0f; break;
-                case MSNE_FORMAT_R8_UNORM: o[0] = (float)b[i] / 255.0f; break;
-                case MSNE_FORMAT_R32G32B32A32_SFLOAT: o[0] = f[4 * i]; o[1] = f[4 * i + 1]; o[2] = f[4 * i + 2]; o[3] = f[4 * i + 3]; break;
-                case MSNE_FORMAT_R32G32_SFLOAT: o[0] = f[2 * i]; o[1] = f[2 * i + 1]; break;
-                case MSNE_FORMAT_R32_SFLOAT: o[0] = f[i]; break;
-                case MSNE_FORMAT_R16G16B16A16_SFLOAT: o[0] = half_to_float(hf[4 * i]); o[1] = half_to_float(hf[4 * i + 1]); o[2] = half_to_float(hf[4 * i + 2]); o[3] = half_to_float(hf[4 * i + 3]); break;
-            }
-        }
-    };
-    constexpr size_t PIECE = 1u << 16;   // texels per piece of work: big textures are converted on all host threads
-    if (n <= PIECE) convert(0, n);
-    else msne_host::parallel_for((uint32_t)((n + PIECE - 1) / PIECE), [&](uint32_t k) { convert((size_t)k * PIECE, std::min(n, ((size_t)k + 1) * PIECE)); });
-    memcpy(t.first, t.rgba.data(), 16);
+    // the texels are kept as they come (MaterialManager.zig:351-390 uploads a texture in its own vk.Format): a lookup decodes what it touches
+    TextureH t; t.w = w; t.h = h; t.format = (uint32_t)fmt;
+    const size_t nbytes = (size_t)w * h * tex_bytes_per_texel((uint32_t)fmt);
+    t.raw.assign((const uint8_t*)bytes, (const uint8_t*)bytes + nbytes);
+    t.raw.resize((nbytes + 15) & ~(size_t)15, 0);   // textures start on 16-B boundaries of the pool
+    const float4 f0 = texel_decode(t.raw.data(), t.format, 0, srgb_lut());
+    t.first[0] = f0.x; t.first[1] = f0.y; t.first[2] = f0.z; t.first[3] = f0.w;
     c->textures.push_back(std::move(t));
     c->textures_dirty = true;
     return (int64_t)c->textures.size() - 1;
@@ -240,27 +219,31 @@ static int64_t add_texture(HdMoonshine* c, const void* bytes, uint32_t w, uint32
 
 // Textures are append-only (the reference never frees one either, MaterialManager.zig): the texel pool grows like the triangle pools — what is already
 // on the device is moved device-to-device, only new textures cross PCIe, and their host copies are released once they are uploaded, so a scene with
-// gigabytes of texels keeps them once, in HBM, as float RGBA (16 B per texel whatever the source format: the decode is paid at creation, not per lookup).
+// gigabytes of texels keeps them once, in HBM, in the source's own format (4 B per sRGB texel, 1 B per metalness / roughness texel, ...).
 bool HdMoonshine::upload_textures() {
-    size_t end = texels_end, total = texels_end;
-    for (auto& t : textures) if (!t.on_device) { t.offset = total; total += (size_t)t.w * t.h; }
-    if (total > 0xFFFFFFFFull) { fail("more than 2^32 texels"); return false; }
+    size_t end = texels_end, total = texels_end;   // in 16-B units
+    for (auto& t : textures) if (!t.on_device) { t.offset = total; total += t.raw.size() / 16; }
+    if (total > 0xFFFFFFFFull) { fail("more than 64 GiB of texels"); return false; }
     if (total > d_texels.n || !d_texels.p) {
-        DevBuf<float4> nt; if (!nt.alloc(total + total / 4 + 16)) { fail("out of device memory (textures)"); return false; }
-        if (end) CHECK_HIP(this, hipMemcpyAsync(nt.p, d_texels.p, end * sizeof(float4), hipMemcpyDeviceToDevice, stream));
+        DevBuf<uint4> nt; if (!nt.alloc(total + total / 4 + 16)) { fail("out of device memory (textures)"); return false; }
+        if (end) CHECK_HIP(this, hipMemcpyAsync(nt.p, d_texels.p, end * sizeof(uint4), hipMemcpyDeviceToDevice, stream));
         CHECK_HIP(this, hipStreamSynchronize(stream));
         std::swap(nt.p, d_texels.p); std::swap(nt.n, d_texels.n);
+    }
+    if (!d_srgb.p) {
+        if (!d_srgb.alloc(256)) { fail("out of device memory (textures)"); return false; }
+        CHECK_HIP(this, hipMemcpyAsync(d_srgb.p, srgb_lut(), 256 * sizeof(float), hipMemcpyHostToDevice, stream));
     }
     std::vector<TexDesc> desc(textures.size());
     for (size_t i = 0; i < textures.size(); i++) {
         TextureH& t = textures[i];
-        desc[i] = TexDesc{ (uint32_t)t.offset, t.w, t.h, 0, make_float4(t.first[0], t.first[1], t.first[2], t.first[3]) };
-        if (!t.on_device) CHECK_HIP(this, hipMemcpyAsync(d_texels.p + t.offset, t.rgba.data(), t.rgba.size() * 4, hipMemcpyHostToDevice, stream));
+        desc[i] = TexDesc{ (uint32_t)t.offset, t.w, t.h, t.format, make_float4(t.first[0], t.first[1], t.first[2], t.first[3]) };
+        if (!t.on_device) CHECK_HIP(this, hipMemcpyAsync(d_texels.p + t.offset, t.raw.data(), t.raw.size(), hipMemcpyHostToDevice, stream));
     }
     if (!d_texdesc.alloc(desc.size())) { fail("out of device memory (textures)"); return false; }
     if (!desc.empty()) CHECK_HIP(this, hipMemcpyAsync(d_texdesc.p, desc.data(), desc.size() * sizeof(TexDesc), hipMemcpyHostToDevice, stream));
     CHECK_HIP(this, hipStreamSynchronize(stream));
-    for (auto& t : textures) if (!t.on_device) { t.on_device = true; std::vector<float>().swap(t.rgba); }
+    for (auto& t : textures) if (!t.on_device) { t.on_device = true; std::vector<uint8_t>().swap(t.raw); }
     texels_end = total;
     textures_dirty = false; lights_dirty = true;   // (the gathered light triangles hold texture descriptors)
     return true;
@@ -540,7 +523,7 @@ bool HdMoonshine::ensure_scene() {
 SceneView HdMoonshine::scene_view() const {
     SceneView v{};
     v.nodes = d_nodes.p; v.tris = d_tris.p; v.tri_attrs = d_tri_attrs.p; v.tlas_items = d_tlas_items.p; v.instances = d_instances.p; v.geometries = d_geometries.p;
-    v.meshes = d_meshes.p; v.materials = d_materials.p; v.textures = d_texdesc.p; v.texels = d_texels.p; v.alias = d_alias.p;
+    v.meshes = d_meshes.p; v.materials = d_materials.p; v.textures = d_texdesc.p; v.texels = d_texels.p; v.srgb_lut = d_srgb.p; v.alias = d_alias.p;
     if (!h_alias.empty()) { v.alias_count = h_alias[0].alias; v.alias_sum = h_alias[0].select; }
     v.light_tris = d_light_tris.p;
     v.env = env; v.tlas_root = tlas_root; v.root_in_blas = root_in_blas;
@@ -1035,6 +1018,12 @@ void MsneSetProfiling(HdMoonshine* c, int kernel_events, int traversal_counters)
     // durations are exclusive; 0 / 1 restore the context's own choice ($MSNE_SERIAL or the batch-size rule)
     if (kernel_events == 2) { if (c->serial_saved == -2) c->serial_saved = c->serial_mode; c->serial_mode = 1; }
     else if (c->serial_saved != -2) { c->serial_mode = c->serial_saved; c->serial_saved = -2; }
+}
+uint64_t MsneGetTexelPoolBytes(HdMoonshine* c) {   // bytes of texels resident in HBM (after the next upload: what has been created so far)
+    LOCK(c);
+    uint64_t n = (uint64_t)c->texels_end * 16u;
+    for (const auto& t : c->textures) if (!t.on_device) n += t.raw.size();
+    return n;
 }
 int MsneGetTraversalCounters(HdMoonshine* c, uint64_t out[20]) {   // [0..3] closest {node visits, tri tests}, shadow {..}; [4..11] closest wave-cycle profile, [12..19] shadow
     LOCK(c);

@@ -93,13 +93,26 @@ static bool gather_and_unpack(MsneGroup* g, SensorHandle sensor) {
         if (hipMalloc(&g->gathered, bytes * n) != hipSuccess) { g->fail("out of device memory (gathered films)"); return false; }
         g->gathered_bytes = bytes * n;
     }
-    if (g->streams.empty()) {
-        g->streams.resize(n, nullptr);
-        for (size_t i = 0; i < n; i++) if (hipSetDevice(g->dev[i]) != hipSuccess || hipStreamCreateWithFlags(&g->streams[i], hipStreamNonBlocking) != hipSuccess) { g->fail("cannot create gather streams"); return false; }
+    if (g->streams.empty()) {   // all or nothing: a half-built set would make the next call run on null streams of the wrong device
+        std::vector<hipStream_t> st(n, nullptr);
+        bool ok = true;
+        for (size_t i = 0; i < n && ok; i++) ok = hipSetDevice(g->dev[i]) == hipSuccess && hipStreamCreateWithFlags(&st[i], hipStreamNonBlocking) == hipSuccess;
+        if (!ok) {
+            for (size_t i = 0; i < n; i++) if (st[i]) { (void)hipSetDevice(g->dev[i]); (void)hipStreamDestroy(st[i]); }
+            g->fail("cannot create gather streams"); return false;
+        }
+        g->streams.swap(st);
     }
-    hipEvent_t e0 = nullptr, e1 = nullptr;
+    struct EventPair {   // destroyed on every way out
+        hipEvent_t e0 = nullptr, e1 = nullptr; int dev;
+        explicit EventPair(int d) : dev(d) {}
+        ~EventPair() { (void)hipSetDevice(dev); if (e0) (void)hipEventDestroy(e0); if (e1) (void)hipEventDestroy(e1); }
+    } ev(g->dev[0]);
+    hipEvent_t& e0 = ev.e0; hipEvent_t& e1 = ev.e1;
     (void)hipSetDevice(g->dev[0]);
     if (hipEventCreate(&e0) == hipSuccess && hipEventCreate(&e1) == hipSuccess) (void)hipEventRecord(e0, g->streams[0]);
+    // communicators that saw a failed collective may be unusable: drop them, the next gather re-initialises
+    auto drop_comms = [&] { for (size_t i = 0; i < g->comms.size(); i++) if (g->comms[i] && g->rccl.CommDestroy) { (void)hipSetDevice(g->dev[i]); (void)g->rccl.CommDestroy(g->comms[i]); } g->comms.clear(); };
     const bool use_rccl = g->distinct && !env_flag("MSNE_GROUP_NO_RCCL");
     if (use_rccl) {
         if (g->comms.empty()) {
@@ -115,8 +128,8 @@ static bool gather_and_unpack(MsneGroup* g, SensorHandle sensor) {
             r = g->rccl.Gather(MsneGetPackedFilmDevicePtr(g->ctx[i], sensor), g->gathered, (size_t)stride * 4, 7 /* ncclFloat */, 0, g->comms[i], g->streams[i]);
         }
         const int r2 = g->rccl.GroupEnd();
-        if (r != 0 || r2 != 0) { g->fail(std::string("ncclGather: ") + (g->rccl.GetErrorString ? g->rccl.GetErrorString(r ? r : r2) : "error")); return false; }
-        for (size_t i = 0; i < n; i++) { (void)hipSetDevice(g->dev[i]); if (hipStreamSynchronize(g->streams[i]) != hipSuccess) { g->fail("gather failed"); return false; } }
+        if (r != 0 || r2 != 0) { g->fail(std::string("ncclGather: ") + (g->rccl.GetErrorString ? g->rccl.GetErrorString(r ? r : r2) : "error")); drop_comms(); return false; }
+        for (size_t i = 0; i < n; i++) { (void)hipSetDevice(g->dev[i]); if (hipStreamSynchronize(g->streams[i]) != hipSuccess) { g->fail("gather failed"); drop_comms(); return false; } }
         g->transport = "rccl";
     } else {
         (void)hipSetDevice(g->dev[0]);
@@ -131,8 +144,6 @@ static bool gather_and_unpack(MsneGroup* g, SensorHandle sensor) {
     }
     (void)hipSetDevice(g->dev[0]);
     if (e0 && e1) { float ms = 0.0f; (void)hipEventRecord(e1, g->streams[0]); if (hipEventSynchronize(e1) == hipSuccess && hipEventElapsedTime(&ms, e0, e1) == hipSuccess) g->gather_ms += ms; }
-    if (e0) (void)hipEventDestroy(e0);
-    if (e1) (void)hipEventDestroy(e1);
     g->gathers++;
     if (MsneUnpackGatheredFilm(g->ctx[0], sensor, g->gathered, (uint32_t)n) != 0) { g->fail(std::string("unpack: ") + MsneGetLastError(g->ctx[0])); return false; }
     return true;

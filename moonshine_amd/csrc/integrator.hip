@@ -71,7 +71,7 @@ __global__ void k_light_tris(SceneView sc, uint32_t indexed_attributes, uint32_t
     r.t0x = 0.0f; r.t0y = 0.0f; r.t1x = 1.0f; r.t1y = 0.0f; r.t2x = 1.0f; r.t2y = 1.0f; r.material = 0;
     r.nx = r.ny = r.nz = 0.0f; r.instance = en.instance;
     for (int k = 0; k < 12; k++) r.to_world[k] = 0.0f;
-    r.emissive.offset = 0; r.emissive.w = 1; r.emissive.h = 1; r.emissive.pad = 0; r.emissive.first = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    r.emissive.offset = 0; r.emissive.w = 1; r.emissive.h = 1; r.emissive.format = TEX_RGBA32F; r.emissive.first = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
     if (en.instance < n_instances) {
         const GeometryRec g = sc.geometries[sc.instances[en.instance].geo_offset + en.geometry];
         const MeshRec mesh = sc.meshes[g.mesh];
@@ -327,7 +327,7 @@ __global__ __launch_bounds__(SHADE_BLOCK, 3) void k_shade(SceneView sc, Pipeline
                         ltoWorld.m[0][0] = u2f(lf.x); ltoWorld.m[0][1] = u2f(lf.y); ltoWorld.m[0][2] = u2f(lf.z); ltoWorld.m[0][3] = u2f(lf.w);
                         ltoWorld.m[1][0] = u2f(lg.x); ltoWorld.m[1][1] = u2f(lg.y); ltoWorld.m[1][2] = u2f(lg.z); ltoWorld.m[1][3] = u2f(lg.w);
                         ltoWorld.m[2][0] = u2f(lh.x); ltoWorld.m[2][1] = u2f(lh.y); ltoWorld.m[2][2] = u2f(lh.z); ltoWorld.m[2][3] = u2f(lh.w);
-                        TexDesc t_light; t_light.offset = li.x; t_light.w = li.y; t_light.h = li.z; t_light.pad = 0u; t_light.first = make_float4(u2f(lj.x), u2f(lj.y), u2f(lj.z), u2f(lj.w));
+                        TexDesc t_light; t_light.offset = li.x; t_light.w = li.y; t_light.h = li.z; t_light.format = li.w; t_light.first = make_float4(u2f(lj.x), u2f(lj.y), u2f(lj.z), u2f(lj.w));
                         const f3 lp0 = F3(u2f(la.x), u2f(la.y), u2f(la.z)), lp1 = F3(u2f(la.w), u2f(lb.x), u2f(lb.y)), lp2 = F3(u2f(lb.z), u2f(lb.w), u2f(lc.x));
                         const f3 lbary = F3(1.0f - bary.x - bary.y, bary.x, bary.y);
                         const f3 at_position = m34_mul_point(ltoWorld, interp3(lbary, lp0, lp1, lp2));

@@ -54,9 +54,39 @@ constexpr uint32_t GEO_SAMPLED = 1u, GEO_HAS_TEXCOORDS = 2u, GEO_HAS_NORMALS = 4
 struct MeshRec { const float* positions; const float* texcoords; const float* normals; const uint32_t* indices; }; // world.hlsl:25-31 (32 B)
 // reference: Material{normal,emissive,type,addr}+variant buffer (MaterialManager.zig:35-77); flattened here to one 32-B record
 struct alignas(16) MaterialRec { uint32_t normal, emissive, type, color, metalness, roughness; float ior; uint32_t pad; };
-// texel offset into SceneView::texels (float4).  `first` repeats texel 0: 1x1 textures — every constant material
-// parameter (World.zig:44-228) — are then served by the descriptor load alone, one dependent load less per fetch
-struct alignas(16) TexDesc { uint32_t offset, w, h, pad; float4 first; };
+// Textures stay in HBM in the format they were created with, as the reference uploads them in their own vk.Format (MaterialManager.zig:351-390):
+// `format` is a MsneTextureFormat, `offset` counts 16-B units into SceneView::texels, a lookup decodes the texels it touches (texel_decode, shade.h).
+// `first` repeats texel 0 DECODED: 1x1 textures — every constant material parameter (World.zig:44-228) — are served by the descriptor load alone.
+constexpr uint32_t TEX_RGBA8_SRGB = 0, TEX_RG8_UNORM = 1, TEX_R8_UNORM = 2, TEX_RGBA32F = 3, TEX_RG32F = 4, TEX_R32F = 5, TEX_RGBA16F = 6;   // == MsneTextureFormat
+MSNE_HD uint32_t tex_bytes_per_texel(uint32_t format) { return format == TEX_RGBA8_SRGB ? 4u : format == TEX_RG8_UNORM ? 2u : format == TEX_R8_UNORM ? 1u : format == TEX_RGBA32F ? 16u : format == TEX_RG32F ? 8u : format == TEX_R32F ? 4u : 8u; }
+struct alignas(16) TexDesc { uint32_t offset, w, h, format; float4 first; };
+MSNE_HD float half_bits_to_float(uint32_t h) {   // IEEE binary16 -> binary32, exact (subnormals included)
+    const uint32_t s = (h >> 15) << 31, e = (h >> 10) & 0x1fu, m = h & 0x3ffu;
+    if (e == 0u) { if (m == 0u) return u2f(s); const float f = (float)m * 0x1p-24f; return (h >> 15) ? -f : f; }
+    if (e == 31u) return u2f(s | 0x7f800000u | (m << 13));
+    return u2f(s | ((e + 112u) << 23) | (m << 13));
+}
+// One texel as the float RGBA the reference's sampler would return for the format: sRGB bytes through the 256-entry table `srgb` the host computed,
+// UNORM bytes / 255, halves and floats as they are; missing channels 0, 0, 0, 1.  Host and device evaluate the same expressions: the descriptor's
+// `first` texel, the test oracle's upload-time decode and a lookup on the GPU agree bit for bit.
+MSNE_HD float4 decode_rgba8_srgb(uint32_t p, const float* srgb) { float4 o; o.x = srgb[p & 255u]; o.y = srgb[(p >> 8) & 255u]; o.z = srgb[(p >> 16) & 255u]; o.w = (float)(p >> 24) / 255.0f; return o; }
+MSNE_HD float4 decode_rg8_unorm(uint32_t p) { float4 o; o.x = (float)(p & 255u) / 255.0f; o.y = (float)((p >> 8) & 255u) / 255.0f; o.z = 0.0f; o.w = 1.0f; return o; }
+MSNE_HD float4 decode_r8_unorm(uint32_t p) { float4 o; o.x = (float)(p & 255u) / 255.0f; o.y = 0.0f; o.z = 0.0f; o.w = 1.0f; return o; }
+MSNE_HD float4 decode_rgba16f(uint32_t lo, uint32_t hi) { float4 o; o.x = half_bits_to_float(lo & 0xffffu); o.y = half_bits_to_float(lo >> 16); o.z = half_bits_to_float(hi & 0xffffu); o.w = half_bits_to_float(hi >> 16); return o; }
+// texel `idx` of a texture whose first byte is `base`
+MSNE_HD float4 texel_decode(const uint8_t* base, uint32_t format, size_t idx, const float* srgb) {
+    float4 o; o.x = 0.0f; o.y = 0.0f; o.z = 0.0f; o.w = 1.0f;
+    switch (format) {
+        case TEX_RGBA8_SRGB: return decode_rgba8_srgb(reinterpret_cast<const uint32_t*>(base)[idx], srgb);
+        case TEX_RG8_UNORM: return decode_rg8_unorm(reinterpret_cast<const uint16_t*>(base)[idx]);
+        case TEX_R8_UNORM: return decode_r8_unorm(base[idx]);
+        case TEX_RGBA32F: { const float* f = reinterpret_cast<const float*>(base) + 4 * idx; o.x = f[0]; o.y = f[1]; o.z = f[2]; o.w = f[3]; break; }
+        case TEX_RG32F: { const float* f = reinterpret_cast<const float*>(base) + 2 * idx; o.x = f[0]; o.y = f[1]; break; }
+        case TEX_R32F: o.x = reinterpret_cast<const float*>(base)[idx]; break;
+        default: { const uint32_t* h = reinterpret_cast<const uint32_t*>(base) + 2 * idx; return decode_rgba16f(h[0], h[1]); }
+    }
+    return o;
+}
 struct AliasEntry { uint32_t alias; float select; uint32_t instance, geometry, primitive; };  // light.hlsl:17-22,112-116 (20 B)
 // What MeshLights::sample (light.hlsl:130-158) needs of alias entry i, gathered once per scene: the object-space vertices and
 // texcoords of the emissive triangle and its material — one record per light sample instead of the chain
@@ -94,7 +124,8 @@ struct SceneView {
     const MeshRec* meshes;
     const MaterialRec* materials;
     const TexDesc* textures;
-    const float4* texels;
+    const uint4* texels;              // texel pool in 16-B units, every texture in its own format (TexDesc)
+    const float* srgb_lut;            // 256 floats: sRGB byte -> linear, as the host computed it
     const AliasEntry* alias;          // entry 0 = header {count, sum}
     uint32_t alias_count; float alias_sum;   // copy of the header: kernel arguments instead of a dependent load per path
     const LightTri* light_tris;       // alias_count + 1 records

@@ -28,18 +28,47 @@ __device__ __forceinline__ float4 sample_bilinear(const float4* texels, uint32_t
     { float top = a.w * (1.0f - fx) + b.w * fx, bot = c.w * (1.0f - fx) + d.w * fx; o.w = top * (1.0f - fy) + bot * fy; }
     return o;
 }
-__device__ __forceinline__ float4 tex_sample(const SceneView& sc, uint32_t idx, f2 uv) {
-    const TexDesc t = sc.textures[idx];
-    if (t.w == 1 && t.h == 1) return t.first;
-    return sample_bilinear(sc.texels + t.offset, t.w, t.h, uv.x, uv.y, false);
+// material textures: the same filter over texels decoded from the texture's own format (TexDesc::format) as they are fetched.  The format is
+// decided ONCE per lookup and the four texels of a case are loaded together (a switch per texel makes four dependent load -> decode chains of them).
+__device__ __forceinline__ float4 sample_bilinear_fmt(const uint4* texels, const float* srgb, uint32_t offset, uint32_t w, uint32_t h, uint32_t fmt, float u, float v) {
+    const uint8_t* base = reinterpret_cast<const uint8_t*>(texels + offset);
+    const float x = u * (float)w - 0.5f, y = v * (float)h - 0.5f;
+    const float fx0 = floor_(x), fy0 = floor_(y);
+    const float fx = x - fx0, fy = y - fy0;
+    const int x0 = (int)fx0, y0 = (int)fy0;
+    const int xa = wrap_repeat(x0, (int)w), xb = wrap_repeat(x0 + 1, (int)w), ya = wrap_repeat(y0, (int)h), yb = wrap_repeat(y0 + 1, (int)h);
+    const size_t ia = (size_t)ya * w + xa, ib = (size_t)ya * w + xb, ic = (size_t)yb * w + xa, id = (size_t)yb * w + xb;
+    float4 a, b, c, d;
+    switch (fmt) {
+        case TEX_RGBA8_SRGB: { const uint32_t* p = reinterpret_cast<const uint32_t*>(base); const uint32_t pa = p[ia], pb = p[ib], pc = p[ic], pd = p[id];
+                               a = decode_rgba8_srgb(pa, srgb); b = decode_rgba8_srgb(pb, srgb); c = decode_rgba8_srgb(pc, srgb); d = decode_rgba8_srgb(pd, srgb); break; }
+        case TEX_RG8_UNORM: { const uint16_t* p = reinterpret_cast<const uint16_t*>(base); const uint32_t pa = p[ia], pb = p[ib], pc = p[ic], pd = p[id];
+                              a = decode_rg8_unorm(pa); b = decode_rg8_unorm(pb); c = decode_rg8_unorm(pc); d = decode_rg8_unorm(pd); break; }
+        case TEX_R8_UNORM: { const uint32_t pa = base[ia], pb = base[ib], pc = base[ic], pd = base[id];
+                             a = decode_r8_unorm(pa); b = decode_r8_unorm(pb); c = decode_r8_unorm(pc); d = decode_r8_unorm(pd); break; }
+        case TEX_RGBA32F: { const float4* p = reinterpret_cast<const float4*>(base); a = p[ia]; b = p[ib]; c = p[ic]; d = p[id]; break; }
+        case TEX_RG32F: { const float2* p = reinterpret_cast<const float2*>(base); const float2 pa = p[ia], pb = p[ib], pc = p[ic], pd = p[id];
+                          a = make_float4(pa.x, pa.y, 0.0f, 1.0f); b = make_float4(pb.x, pb.y, 0.0f, 1.0f); c = make_float4(pc.x, pc.y, 0.0f, 1.0f); d = make_float4(pd.x, pd.y, 0.0f, 1.0f); break; }
+        case TEX_R32F: { const float* p = reinterpret_cast<const float*>(base); const float pa = p[ia], pb = p[ib], pc = p[ic], pd = p[id];
+                         a = make_float4(pa, 0.0f, 0.0f, 1.0f); b = make_float4(pb, 0.0f, 0.0f, 1.0f); c = make_float4(pc, 0.0f, 0.0f, 1.0f); d = make_float4(pd, 0.0f, 0.0f, 1.0f); break; }
+        default: { const uint2* p = reinterpret_cast<const uint2*>(base); const uint2 pa = p[ia], pb = p[ib], pc = p[ic], pd = p[id];
+                   a = decode_rgba16f(pa.x, pa.y); b = decode_rgba16f(pb.x, pb.y); c = decode_rgba16f(pc.x, pc.y); d = decode_rgba16f(pd.x, pd.y); break; }
+    }
+    float4 o;
+    { float top = a.x * (1.0f - fx) + b.x * fx, bot = c.x * (1.0f - fx) + d.x * fx; o.x = top * (1.0f - fy) + bot * fy; }
+    { float top = a.y * (1.0f - fx) + b.y * fx, bot = c.y * (1.0f - fx) + d.y * fx; o.y = top * (1.0f - fy) + bot * fy; }
+    { float top = a.z * (1.0f - fx) + b.z * fx, bot = c.z * (1.0f - fx) + d.z * fx; o.z = top * (1.0f - fy) + bot * fy; }
+    { float top = a.w * (1.0f - fx) + b.w * fx, bot = c.w * (1.0f - fx) + d.w * fx; o.w = top * (1.0f - fy) + bot * fy; }
+    return o;
 }
-__device__ __forceinline__ f3 tex_sample_rgb(const SceneView& sc, uint32_t idx, f2 uv) { float4 o = tex_sample(sc, idx, uv); return F3(o.x, o.y, o.z); }
-// the same lookup from a descriptor that is already in registers: k_shade fetches the (up to five) descriptors of a hit's material
+// the lookup from a descriptor that is already in registers: k_shade fetches the (up to five) descriptors of a hit's material
 // together, before the first of them is needed, instead of one dependent descriptor -> texel chain after the other
 __device__ __forceinline__ float4 tex_sample_desc(const SceneView& sc, const TexDesc& t, f2 uv) {
     if (t.w == 1 && t.h == 1) return t.first;
-    return sample_bilinear(sc.texels + t.offset, t.w, t.h, uv.x, uv.y, false);
+    return sample_bilinear_fmt(sc.texels, sc.srgb_lut, t.offset, t.w, t.h, t.format, uv.x, uv.y);
 }
+__device__ __forceinline__ float4 tex_sample(const SceneView& sc, uint32_t idx, f2 uv) { const TexDesc t = sc.textures[idx]; return tex_sample_desc(sc, t, uv); }
+__device__ __forceinline__ f3 tex_sample_rgb(const SceneView& sc, uint32_t idx, f2 uv) { float4 o = tex_sample(sc, idx, uv); return F3(o.x, o.y, o.z); }
 
 // ---------------- world.hlsl:86-177 ----------------
 struct Attrs { f3 position; f2 texcoord; Frame triangleFrame, frame; };

@@ -8,6 +8,7 @@
 #include <zlib.h>
 #include <atomic>
 #include <thread>
+#include <system_error>
 #include <sched.h>
 #include <cstdio>
 #include <cstdlib>
@@ -149,8 +150,15 @@ static bool huf_uncompress(const uint8_t* src, size_t n, std::vector<uint16_t>& 
     auto bit_at = [&](size_t pos) -> uint32_t { return pos < total ? (br.p[pos >> 3] >> (7 - (pos & 7))) & 1u : 0u; };
     while (br.pos < total) {
         uint32_t sym = 0; int l = 0;
-        uint32_t peek = 0;
-        for (int i = 0; i < FAST; i++) peek = (peek << 1) | bit_at(br.pos + (size_t)i);
+        // the next FAST bits (zero-padded past the end of the stream): one unaligned big-endian window instead of a bit at a time
+        uint32_t peek;
+        {
+            const size_t byte = br.pos >> 3;
+            uint32_t w = 0;
+            for (size_t k = 0; k < 4; k++) w = (w << 8) | (byte + k < br.n ? br.p[byte + k] : 0u);
+            peek = (w << (br.pos & 7)) >> (32 - FAST);
+            if (br.pos + FAST > total) peek &= ~0u << (br.pos + FAST - total);   // bits past `total` inside the last byte read as 0, like bit_at()
+        }
         const uint32_t e = fast[peek];
         if (e && br.pos + (e & 63u) <= total) { sym = e >> 6; l = (int)(e & 63u); }
         else {
@@ -264,9 +272,10 @@ bool exr_load(const std::string& path, Image& img, std::string& err) {
     if (r.u32() != 20000630u) { err = "not an OpenEXR file"; return false; }
     const uint32_t version = r.u32();
     if ((version & 0xff) != 2) { err = "unsupported EXR version"; return false; }
-    if (version & 0x200u) { err = "tiled EXR files are not supported"; return false; }
+    const bool tiled = (version & 0x200u) != 0;   // single-part tiled file: tinyexr's LoadEXRFromMemory (exr.zig:109-110) reads those too
     if (version & 0x1800u) { err = "multi-part / deep EXR files are not supported"; return false; }
     std::vector<Channel> channels; int compression = 0; int32_t dw[4] = { 0, 0, -1, -1 };
+    uint32_t tile_w = 0, tile_h = 0; int level_mode = 0; bool have_tiles = false;
     for (;;) {
         const std::string name = r.str();
         if (!r.ok) { err = "truncated EXR header"; return false; }
@@ -284,11 +293,13 @@ bool exr_load(const std::string& path, Image& img, std::string& err) {
             }
         } else if (name == "compression") compression = a.u8();
         else if (name == "dataWindow") { for (int k = 0; k < 4; k++) dw[k] = a.i32(); }
+        else if (name == "tiles") { tile_w = a.u32(); tile_h = a.u32(); level_mode = a.u8() & 15; have_tiles = a.ok; }
         r.pos += size;
     }
     const int64_t W = (int64_t)dw[2] - dw[0] + 1, H = (int64_t)dw[3] - dw[1] + 1;
     if (W <= 0 || H <= 0 || W > 65536 || H > 65536 || channels.empty()) { err = "bad EXR header"; return false; }
     for (auto& c : channels) if (c.xs != 1 || c.ys != 1) { err = "subsampled EXR channels are not supported"; return false; }
+    if (tiled && (!have_tiles || tile_w == 0 || tile_h == 0 || tile_w > 65536 || tile_h > 65536 || level_mode > 2)) { err = "bad EXR tile description"; return false; }
     int lines_per_block;
     switch (compression) {
         case 0: case 1: case 2: lines_per_block = 1; break;
@@ -296,14 +307,17 @@ bool exr_load(const std::string& path, Image& img, std::string& err) {
         case 4: lines_per_block = 32; break;
         default: err = "EXR compression " + std::to_string(compression) + " is not supported (NONE, RLE, ZIPS, ZIP, PIZ are)"; return false;
     }
-    const size_t nblocks = (size_t)((H + lines_per_block - 1) / lines_per_block);
+    // chunks of the full-resolution image: scanline blocks, or the tiles of level (0, 0) — in the offset table the first tiles_x * tiles_y entries
+    // for every level mode (ONE_LEVEL, MIPMAP_LEVELS: level 0 first; RIPMAP_LEVELS: (0, 0) first); lower-resolution levels are not read, as
+    // tinyexr's simple loader keeps only the first image
+    const size_t tiles_x = tiled ? (size_t)((W + tile_w - 1) / tile_w) : 1, tiles_y = tiled ? (size_t)((H + tile_h - 1) / tile_h) : 0;
+    const size_t nblocks = tiled ? tiles_x * tiles_y : (size_t)((H + lines_per_block - 1) / lines_per_block);
     if (r.pos > file.size() || nblocks > (file.size() - r.pos) / 8) { err = "truncated EXR offset table"; return false; }   // before anything is sized by the header
     std::vector<uint64_t> offsets(nblocks);
     for (auto& o : offsets) o = r.u64();
     if (!r.ok) { err = "truncated EXR offset table"; return false; }
-    size_t line_bytes = 0;
-    std::vector<size_t> ch_off(channels.size());
-    for (size_t c = 0; c < channels.size(); c++) { ch_off[c] = line_bytes; line_bytes += (size_t)W * (channels[c].type == 1 ? 2 : 4); }
+    size_t px_bytes = 0;
+    for (size_t c = 0; c < channels.size(); c++) px_bytes += channels[c].type == 1 ? 2 : 4;
     // which channel feeds which of R,G,B,A (tinyexr: by name; a single channel is replicated)
     int src[4] = { -1, -1, -1, -1 };
     for (size_t c = 0; c < channels.size(); c++) {
@@ -312,18 +326,31 @@ bool exr_load(const std::string& path, Image& img, std::string& err) {
     }
     if (src[0] < 0 && src[1] < 0 && src[2] < 0) { if (channels.size() == 1 || channels[0].name == "Y") src[0] = src[1] = src[2] = 0; else { err = "EXR has no R/G/B channels"; return false; } }
     // a header may claim more pixels than the file can hold: deflate expands at most ~1032:1, RLE 64:1
-    if ((double)line_bytes * (double)H > (double)file.size() * 1100.0) { err = "EXR data window exceeds the file's data"; return false; }
+    if ((double)px_bytes * (double)W * (double)H > (double)file.size() * 1100.0) { err = "EXR data window exceeds the file's data"; return false; }
     img.w = (uint32_t)W; img.h = (uint32_t)H; img.rgba.assign((size_t)W * H * 4, 0.0f);
     for (size_t i = 0; i < (size_t)W * H; i++) img.rgba[4 * i + 3] = 1.0f;
     std::vector<uint8_t> tmp, raw;
     for (size_t b = 0; b < nblocks; b++) {
         if (offsets[b] >= file.size()) { err = "EXR chunk offset outside the file"; return false; }
         Reader c{ file.data(), file.size(), (size_t)offsets[b] };
-        const int32_t y0 = c.i32(); const int32_t dsize = c.i32();
+        // the rectangle of the data window this chunk covers: [col0, col0 + ncols) x [row0, row0 + nlines)
+        int64_t row0, col0 = 0; size_t nlines, ncols = (size_t)W;
+        if (tiled) {
+            const int32_t tx = c.i32(), ty = c.i32(), lx = c.i32(), ly = c.i32();
+            if (!c.ok) { err = "truncated EXR chunk"; return false; }
+            if (lx != 0 || ly != 0) { err = "EXR tile of a lower-resolution level where a full-resolution tile is expected"; return false; }
+            if (tx < 0 || ty < 0 || (size_t)tx >= tiles_x || (size_t)ty >= tiles_y) { err = "EXR tile outside the data window"; return false; }
+            col0 = (int64_t)tx * tile_w; row0 = (int64_t)ty * tile_h;
+            ncols = (size_t)std::min<int64_t>(tile_w, W - col0); nlines = (size_t)std::min<int64_t>(tile_h, H - row0);
+        } else {
+            const int32_t y0 = c.i32();
+            row0 = (int64_t)y0 - dw[1];
+            if (!c.ok || row0 < 0 || row0 >= H) { err = "EXR chunk outside the data window"; return false; }
+            nlines = (size_t)std::min<int64_t>(lines_per_block, H - row0);
+        }
+        const int32_t dsize = c.i32();
         if (!c.ok || dsize < 0 || !c.need((size_t)dsize)) { err = "truncated EXR chunk"; return false; }
-        const int64_t row0 = (int64_t)y0 - dw[1];
-        if (row0 < 0 || row0 >= H) { err = "EXR chunk outside the data window"; return false; }
-        const size_t nlines = (size_t)std::min<int64_t>(lines_per_block, H - row0);
+        const size_t line_bytes = ncols * px_bytes;
         const size_t expect = nlines * line_bytes;
         const uint8_t* data = c.p + c.pos;
         if ((size_t)dsize == expect) { raw.assign(data, data + expect); }      // stored uncompressed (also when compression did not help)
@@ -331,22 +358,26 @@ bool exr_load(const std::string& path, Image& img, std::string& err) {
         else if (compression == 2 || compression == 3) { if (!inflate_all(data, (size_t)dsize, tmp, expect)) { err = "bad ZIP data"; return false; } undo_predictor_and_interleave(tmp, raw); }
         else if (compression == 4) {
             std::vector<int> wpp; for (auto& ch : channels) wpp.push_back(ch.type == 1 ? 1 : 2);
-            if (!piz::decode_block(data, (size_t)dsize, wpp, (size_t)W, nlines, raw) || raw.size() != expect) { err = "bad PIZ data"; return false; }
+            if (!piz::decode_block(data, (size_t)dsize, wpp, ncols, nlines, raw) || raw.size() != expect) { err = "bad PIZ data"; return false; }
         }
         else { err = "EXR chunk size mismatch"; return false; }
         for (size_t l = 0; l < nlines; l++) {
             const uint8_t* line = raw.data() + l * line_bytes;
-            float* out = &img.rgba[(size_t)(row0 + (int64_t)l) * W * 4];
-            for (int k = 0; k < 4; k++) {
-                if (src[k] < 0) continue;
-                const Channel& ch = channels[(size_t)src[k]];
-                const uint8_t* q = line + ch_off[(size_t)src[k]];
-                for (int64_t x = 0; x < W; x++) {
-                    float v;
-                    if (ch.type == 1) { uint16_t hv; memcpy(&hv, q + 2 * x, 2); v = half_to_float(hv); }
-                    else if (ch.type == 2) memcpy(&v, q + 4 * x, 4);
-                    else { uint32_t uv; memcpy(&uv, q + 4 * x, 4); v = (float)uv; }
-                    out[4 * x + k] = v;
+            float* out = &img.rgba[((size_t)(row0 + (int64_t)l) * W + (size_t)col0) * 4];
+            size_t ch_at = 0;
+            for (size_t ci = 0; ci < channels.size(); ci++) {
+                const Channel& ch = channels[ci];
+                const uint8_t* q = line + ch_at;
+                ch_at += ncols * (ch.type == 1 ? 2 : 4);
+                for (int k = 0; k < 4; k++) {
+                    if (src[k] != (int)ci) continue;
+                    for (size_t x = 0; x < ncols; x++) {
+                        float v;
+                        if (ch.type == 1) { uint16_t hv; memcpy(&hv, q + 2 * x, 2); v = half_to_float(hv); }
+                        else if (ch.type == 2) memcpy(&v, q + 4 * x, 4);
+                        else { uint32_t uv; memcpy(&uv, q + 4 * x, 4); v = (float)uv; }
+                        out[4 * x + k] = v;
+                    }
                 }
             }
         }
@@ -358,16 +389,36 @@ static void put_str(std::vector<uint8_t>& o, const char* s) { o.insert(o.end(), 
 template <typename T> static void put(std::vector<uint8_t>& o, T v) { const uint8_t* p = (const uint8_t*)&v; o.insert(o.end(), p, p + sizeof(T)); }
 static void put_attr(std::vector<uint8_t>& o, const char* name, const char* type, const std::vector<uint8_t>& v) { put_str(o, name); put_str(o, type); put<uint32_t>(o, (uint32_t)v.size()); o.insert(o.end(), v.begin(), v.end()); }
 
-void parallel_for(uint32_t n, const std::function<void(uint32_t)>& job) {
-    unsigned nthreads = std::thread::hardware_concurrency();
+// host threads this process may use: hardware threads, capped by the affinity mask AND by the cgroup CPU quota (the GPU boxes show 256 logical CPUs
+// under a 16-CPU quota: more runnable threads than that are only throttled), at most 32
+static unsigned usable_host_threads() {
+    unsigned n = std::thread::hardware_concurrency();
+    if (!n) n = 1;
     cpu_set_t set; CPU_ZERO(&set);
-    if (sched_getaffinity(0, sizeof set, &set) == 0) nthreads = std::min<unsigned>(nthreads ? nthreads : 1u, (unsigned)CPU_COUNT(&set));
-    if (const char* e = getenv("MSNE_HOST_THREADS")) nthreads = (unsigned)std::max(1, atoi(e));   // (1: everything on the calling thread)
-    nthreads = std::max(1u, std::min({ nthreads, 32u, n }));
+    if (sched_getaffinity(0, sizeof set, &set) == 0 && CPU_COUNT(&set) > 0) n = std::min<unsigned>(n, (unsigned)CPU_COUNT(&set));
+    if (FILE* f = fopen("/sys/fs/cgroup/cpu.max", "r")) {   // cgroup v2: "<quota> <period>" or "max <period>"
+        char q[32]; long period = 0;
+        if (fscanf(f, "%31s %ld", q, &period) == 2 && strcmp(q, "max") != 0 && period > 0) n = std::min<unsigned>(n, (unsigned)std::max(1L, atol(q) / period));
+        fclose(f);
+    } else {
+        long quota = -1, period = 0;
+        if (FILE* g = fopen("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "r")) { if (fscanf(g, "%ld", &quota) != 1) quota = -1; fclose(g); }
+        if (FILE* g = fopen("/sys/fs/cgroup/cpu/cpu.cfs_period_us", "r")) { if (fscanf(g, "%ld", &period) != 1) period = 0; fclose(g); }
+        if (quota > 0 && period > 0) n = std::min<unsigned>(n, (unsigned)std::max(1L, quota / period));
+    }
+    if (const char* e = getenv("MSNE_HOST_THREADS")) n = (unsigned)std::max(1, atoi(e));   // (1: everything on the calling thread)
+    return std::max(1u, std::min(n, 32u));
+}
+
+void parallel_for(uint32_t n, const std::function<void(uint32_t)>& job) {
+    static const unsigned host_threads = usable_host_threads();
+    const unsigned nthreads = std::max(1u, std::min(host_threads, n));
     std::atomic<uint32_t> next{ 0 };
     auto worker = [&] { for (uint32_t i; (i = next.fetch_add(1)) < n;) job(i); };
     std::vector<std::thread> pool;
-    for (unsigned t = 1; t < nthreads; t++) pool.emplace_back(worker);
+    pool.reserve(nthreads);
+    // a thread that cannot be started (resource limits) is not an error: what was started is joined, the calling thread does the rest
+    try { for (unsigned t = 1; t < nthreads; t++) pool.emplace_back(worker); } catch (const std::system_error&) {}
     worker();
     for (auto& t : pool) t.join();
 }

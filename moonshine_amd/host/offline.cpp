@@ -54,7 +54,16 @@ int main(int argc, char** argv) {
         else if (k == "--env-samples") opts.env_samples_per_bounce = v; else if (k == "--mesh-samples") opts.mesh_samples_per_bounce = v;
         else if (k == "--gpus") gpus = v; else if (k == "--progressive") progressive = v; else if (k == "--max-sample-count") max_sample_count = v;
         else if (k == "--present-every") present_every = v;
-        else if (k == "--devices") { for (const char* p = argv[a + 1]; *p;) { devices.push_back((int32_t)strtol(p, (char**)&p, 10)); if (*p == ',') p++; } }
+        else if (k == "--devices") {   // a comma-separated list of device ordinals
+            for (const char* p = argv[a + 1]; *p;) {
+                char* end = nullptr;
+                const long d = strtol(p, &end, 10);
+                if (end == p || (*end != ',' && *end != 0) || d < 0) { fprintf(stderr, "bad --devices list '%s' (expected e.g. 0,1,2)\n", argv[a + 1]); return 2; }
+                devices.push_back((int32_t)d);
+                p = *end == ',' ? end + 1 : end;
+                if (*end == ',' && !*p) { fprintf(stderr, "bad --devices list '%s' (trailing comma)\n", argv[a + 1]); return 2; }
+            }
+        }
         else { fprintf(stderr, "unknown option %s\n", k.c_str()); return 2; }
     }
     if (!devices.empty()) gpus = (uint32_t)devices.size();

@@ -1,6 +1,7 @@
 """GPU tests of the file-level boundary: MsneLoadGlb / MsneSetBackgroundExr / MsneSaveSensorExr and the `offline` CLI
 (offline/main.zig:27-203) against the oracle loaded with the same files through tests/shim."""
 import os
+from moonshine_amd.hostinfo import usable_cores
 import subprocess
 
 import numpy as np
@@ -36,7 +37,7 @@ def test_config0_single_triangle(tmp_path, orc, gpu_api):
 def test_gallery_glb_matches_oracle(tmp_path, orc, gpu_api, u32):
     glb, exr = str(tmp_path / "gallery.glb"), str(tmp_path / "sky.exr")
     io.write_gallery(glb, exr, u32=u32)
-    gc = gpu_api.Context(); oc = orc.Context(threads=os.cpu_count())
+    gc = gpu_api.Context(); oc = orc.Context(threads=usable_cores())
     gl, ginfo = gc.load_glb(glb); gc.set_background_exr(exr)
     ol, oinfo = io.oracle_load(orc, oc, glb, exr)
     assert ginfo == oinfo
@@ -64,7 +65,7 @@ def test_offline_cli(tmp_path, orc):
         assert line in r.stdout
     from moonshine_amd import api
     got = api.exr_load(out)
-    oc = orc.Context(threads=os.cpu_count())
+    oc = orc.Context(threads=usable_cores())
     ol, _ = io.oracle_load(orc, oc, glb, exr)
     s = oc.create_sensor(128, 72)
     oc.set_pipeline(samples_per_run=1, max_bounces=8, env_samples_per_bounce=1, mesh_samples_per_bounce=1)
@@ -72,7 +73,6 @@ def test_offline_cli(tmp_path, orc):
     assert np.array_equal(bits(got[..., :3]), bits(oc.sensor_data(s)[..., :3]))
 
 
-@pytest.mark.skipif((os.cpu_count() or 1) < 64, reason="the oracle needs a many-core host for 16.7 M samples (the GPU box has 256 threads)")
 def test_config1_cornell_glb_offline_64spp(tmp_path, orc):
     """BASELINE.json configs[1] end to end: Cornell-box GLB (tools/make_cornell_glb.py) -> `offline` at 512x512, 64 spp, depth 8,
     mesh-light NEE -> EXR, bit-identical to the oracle fed the same GLB"""
@@ -84,7 +84,7 @@ def test_config1_cornell_glb_offline_64spp(tmp_path, orc):
     assert r.returncode == 0, r.stdout + r.stderr
     from moonshine_amd import api
     got = api.exr_load(out)
-    oc = orc.Context(threads=os.cpu_count())
+    oc = orc.Context(threads=usable_cores())
     ol, info = io.oracle_load(orc, oc, glb, exr)
     assert info["triangles"] == 36 and info["instances"] == 8
     s = oc.create_sensor(512, 512)
@@ -103,7 +103,7 @@ def test_config1_cornell_glb_offline_64spp(tmp_path, orc):
 def _oracle_tiles(orc, glb, exr, extent, spp, tiles, film, pipe):
     tx, ty = (extent[0] + 63) // 64, (extent[1] + 63) // 64
     for t in tiles:
-        oc = orc.Context(threads=os.cpu_count(), shard_index=t, shard_count=tx * ty)
+        oc = orc.Context(threads=usable_cores(), shard_index=t, shard_count=tx * ty)
         ol, _ = io.oracle_load(orc, oc, glb, exr)
         s = oc.create_sensor(*extent)
         oc.set_pipeline(**pipe)
@@ -113,7 +113,6 @@ def _oracle_tiles(orc, glb, exr, extent, spp, tiles, film, pipe):
         assert a.size and np.array_equal(bits(a), bits(b)), "tile %d of %s differs from the oracle" % (t, extent)
 
 
-@pytest.mark.skipif((os.cpu_count() or 1) < 64, reason="the oracle needs a many-core host for 256-spp tiles (the GPU box has 256 threads)")
 def test_config2_textured_interior_1080p_256spp(tmp_path, orc):
     """configs[2] (asset substituted): `offline` renders the textured interior at 1920x1080, 256 spp, full MIS, max_bounces 1024
     (the CLI's defaults, offline/main.zig:106-111); three 64x64 tiles of the EXR are bit-identical to the oracle fed the same files"""
@@ -135,7 +134,6 @@ def test_config2_textured_interior_1080p_256spp(tmp_path, orc):
     print(r.stdout)
 
 
-@pytest.mark.skipif((os.cpu_count() or 1) < 64, reason="the oracle needs a many-core host (the GPU box has 256 threads)")
 def test_config3_4k_sharded_eight_ways(tmp_path, orc):
     """configs[3] (asset substituted, and 8 members on this box's ONE GPU instead of 8 GPUs — the gather is a device copy here, ncclGather
     on distinct GPUs): `offline --devices 0,0,0,0,0,0,0,0` at 3840x2160; tiles of the assembled EXR are bit-identical to the oracle"""
@@ -168,7 +166,7 @@ def test_offline_cli_progressive_and_sharded(tmp_path, orc):
     assert "on 3 GPUs (film gather: copy" in r.stdout
     from moonshine_amd import api
     got = api.exr_load(out)
-    oc = orc.Context(threads=os.cpu_count())
+    oc = orc.Context(threads=usable_cores())
     ol, _ = io.oracle_load(orc, oc, glb, exr)
     s = oc.create_sensor(96, 64)
     oc.set_pipeline(samples_per_run=1, max_bounces=8, env_samples_per_bounce=1, mesh_samples_per_bounce=1)

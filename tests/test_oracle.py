@@ -12,6 +12,7 @@ import numpy as np
 import pytest
 
 from moonshine_amd import scenes
+from moonshine_amd.hostinfo import usable_cores
 
 G = os.path.join(os.path.dirname(__file__), "golden")
 
@@ -144,7 +145,7 @@ def test_bsdf_golden_and_properties(orc):
 
 # ---- the reference's furnace tests on the oracle, at the reference's parameters and tolerances ----
 def test_reference_furnace_white_sphere(orc):
-    c = orc.Context(threads=os.cpu_count())
+    c = orc.Context(threads=usable_cores())
     s, l = scenes.furnace_white_sphere(c)
     c.set_pipeline(samples_per_run=512, max_bounces=1024, env_samples_per_bounce=0, mesh_samples_per_bounce=0)   # tests.zig:330-335
     c.render(s, l)
@@ -156,7 +157,7 @@ def test_reference_furnace_white_sphere(orc):
 
 
 def test_reference_furnace_inside_sphere(orc):
-    c = orc.Context(threads=os.cpu_count())
+    c = orc.Context(threads=usable_cores())
     s, l = scenes.furnace_inside_sphere(c)
     c.set_pipeline(samples_per_run=1024, max_bounces=1024, env_samples_per_bounce=0, mesh_samples_per_bounce=0)  # tests.zig:440-445
     c.render(s, l)
@@ -166,7 +167,7 @@ def test_reference_furnace_inside_sphere(orc):
 def test_reference_furnace_inside_sphere_with_mesh_sampling(orc):
     """the reference's fourth furnace test (tests.zig:457-487), disabled there for want of an instance upload path for sampled
     meshes: the emissive sphere is a mesh light, one light sample per bounce with MIS; its stated tolerance is 0.1"""
-    c = orc.Context(threads=os.cpu_count())
+    c = orc.Context(threads=usable_cores())
     s, l = scenes.furnace_inside_sphere(c, sampled=True)
     c.set_pipeline(samples_per_run=512, max_bounces=1024, env_samples_per_bounce=0, mesh_samples_per_bounce=1)   # tests.zig:470-475
     c.render(s, l)
@@ -191,7 +192,7 @@ def test_golden_films(orc):
             ("furnace_inside_16spp", scenes.furnace_inside_sphere, {}, dict(samples_per_run=16, max_bounces=1024, env_samples_per_bounce=0, mesh_samples_per_bounce=0), 1),
             ("s1_mini_64x36_4spp", scenes.s1, dict(extent=(64, 36), grid=2, order=2), dict(samples_per_run=1, max_bounces=8, env_samples_per_bounce=1, mesh_samples_per_bounce=1), 4),
             ("cornell_48_4spp", scenes.cornell, dict(extent=(48, 48)), dict(samples_per_run=2, max_bounces=8, env_samples_per_bounce=0, mesh_samples_per_bounce=1), 2)):
-        c = orc.Context(threads=os.cpu_count())
+        c = orc.Context(threads=usable_cores())
         s, l = builder(c, **kw)
         c.set_pipeline(**pipe)
         c.render(s, l, launches=launches)
@@ -221,7 +222,7 @@ def test_nee_and_plain_estimators_agree(orc):
     """light sampling must not change the expectation (integrator.hlsl:108-181): Cornell with and without mesh NEE."""
     means = []
     for mesh in (0, 1):
-        c = orc.Context(threads=os.cpu_count())
+        c = orc.Context(threads=usable_cores())
         s, l = scenes.cornell(c, extent=(24, 24))
         c.set_pipeline(samples_per_run=1, max_bounces=6, env_samples_per_bounce=0, mesh_samples_per_bounce=mesh)
         c.render(s, l, launches=600 if mesh == 0 else 150)

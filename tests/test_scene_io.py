@@ -3,6 +3,7 @@ The importer is exercised against the oracle through tests/shim (no GPU needed);
 library in tests/test_gpu_io.py."""
 import math
 import os
+import struct
 import subprocess
 import sys
 
@@ -10,6 +11,7 @@ import numpy as np
 import pytest
 
 from moonshine_amd import api, assets, scenes
+from moonshine_amd.hostinfo import usable_cores
 from tests import io_common as io
 
 
@@ -110,6 +112,51 @@ def test_exrdiff_tool(tmp_path):
     assert r.returncode == 1 and "x=4, y=3" in r.stdout
 
 
+@pytest.mark.parametrize("tiles,levels,channels,ptype,comp,order", [
+    ((16, 16), "one", "RGB", "float", "none", 0), ((64, 32), "one", "RGBA", "half", "zip", 0), ((16, 8), "mipmap", "RGB", "float", "zips", 0),
+    ((32, 32), "mipmap", "RGBA", "half", "piz", 0), ((128, 128), "one", "RGB", "float", "piz", 0), ((7, 5), "one", "BGR", "half", "zip", 1),
+    ((16, 16), "mipmap", "RGB", "float", "zip", 1)])
+def test_exr_tiled_reader_against_independent_writer(tmp_path, tiles, levels, channels, ptype, comp, order):
+    """single-part TILED files (what several HDRI tools write by default; tinyexr's LoadEXRFromMemory, exr.zig:109-110, reads them): tiles smaller
+    and larger than the image, partial edge tiles, every compression, mip-mapped files (only the full-resolution level is read), chunks stored
+    bottom-up — against the numpy writer in moonshine_amd/assets.py, and equal to the scanline file of the same picture"""
+    rs = np.random.default_rng(11)
+    yy, xx = np.mgrid[0:45, 0:71]
+    img = np.stack([np.sin(xx / 7.0) + 1.5, (yy / 45.0) ** 2 * 9.0, rs.random((45, 71)) * 3.0, np.full((45, 71), 0.75)], -1).astype(np.float32)
+    p, q = str(tmp_path / "t.exr"), str(tmp_path / "s.exr")
+    data = assets.exr_bytes(img, channels, ptype, comp, tiles=tiles, levels=levels, line_order=order)
+    assert struct.unpack_from("<I", data, 4)[0] == (2 | 0x200) and b"tiles\0tiledesc\0" in data
+    open(p, "wb").write(data)
+    open(q, "wb").write(assets.exr_bytes(img, channels, ptype, comp))
+    got = api.exr_load(p)
+    ref = img.astype(np.float16).astype(np.float32) if ptype == "half" else img.copy()
+    if "A" not in channels:
+        ref[..., 3] = 1.0
+    assert np.array_equal(bits(got), bits(ref)) and np.array_equal(bits(got), bits(api.exr_load(q)))
+
+
+def test_exr_tiled_files_that_must_be_rejected(tmp_path):
+    img = np.ones((20, 20, 4), np.float32)
+    good = assets.exr_bytes(img, "RGB", "float", "zip", tiles=(8, 8), levels="mipmap")
+    p = str(tmp_path / "bad.exr")
+    for bad in (good[:len(good) // 2],                                              # truncated inside the tiles
+                good.replace(b"tiles\0tiledesc\0\x09\0\0\0" + struct.pack("<II", 8, 8), b"tiles\0tiledesc\0\x09\0\0\0" + struct.pack("<II", 0, 8)),   # tile width 0
+                good.replace(b"tiles\0tiledesc\0", b"tilez\0tiledesc\0")):           # tiled bit set, no tile description
+        assert bad != good or len(bad) < len(good)
+        open(p, "wb").write(bad)
+        with pytest.raises(api.MoonshineError):
+            api.exr_load(p)
+    # the first offset points at a tile of level 1: not a full-resolution tile
+    hdr_end = good.index(b"tiles\0tiledesc\0") + 15 + 4 + 9 + 1
+    offs = list(struct.unpack_from("<9Q", good, hdr_end))                # level 0 has 3 x 3 tiles; entry 9 is the first tile of level 1
+    lvl1 = struct.unpack_from("<Q", good, hdr_end + 9 * 8)[0]
+    assert struct.unpack_from("<iiii", good, lvl1)[2:] == (1, 1)
+    swapped = good[:hdr_end] + struct.pack("<Q", lvl1) + good[hdr_end + 8:]
+    open(p, "wb").write(swapped)
+    with pytest.raises(api.MoonshineError):
+        api.exr_load(p)
+
+
 def test_exr_rejects_garbage(tmp_path):
     p = str(tmp_path / "c.exr")
     open(p, "wb").write(b"not an exr at all")
@@ -159,7 +206,7 @@ def rel_l2(a, b):
 def test_gallery_import_rules(tmp_path, orc, u32):
     glb, exr = str(tmp_path / "gallery.glb"), str(tmp_path / "sky.exr")
     io.write_gallery(glb, exr, u32=u32)
-    c = orc.Context(threads=os.cpu_count())
+    c = orc.Context(threads=usable_cores())
     lens, info = io.oracle_load(orc, c, glb, exr)
     assert info["instances"] == 6 and info["meshes"] == 6 and info["materials"] == 6 and info["triangles"] == 4 * 320 + 4
     # texture handles: per material normal+emissive (+color, +metal/rough): Floor 3, Mirror 3, Glass 2, Gold 5, Textured 5, Emitter 3
@@ -182,7 +229,7 @@ def test_interleaved_vertex_buffers_load_like_separate_ones(tmp_path, orc):
     glb, exr = str(tmp_path / "gallery_i.glb"), str(tmp_path / "sky.exr")
     io.write_gallery(glb, exr, interleaved=True)
     assert b'"byteStride":32' in open(glb, "rb").read().replace(b" ", b"")
-    c = orc.Context(threads=os.cpu_count())
+    c = orc.Context(threads=usable_cores())
     lens, info = io.oracle_load(orc, c, glb, exr)
     assert info["triangles"] == 4 * 320 + 4
     s = c.create_sensor(96, 64)
@@ -411,3 +458,13 @@ def test_parsers_survive_mutated_files_under_sanitizers(tmp_path, orc):
     assert "accepted" in out.stdout and int(out.stdout.split()[1]) >= len(seeds)     # the unmutated files all load
     crafted_out = subprocess.run([str(exe)] + [q for q in paths if os.path.basename(q).startswith("c_")], capture_output=True, text=True, env=env, timeout=600)
     assert crafted_out.returncode == 0 and crafted_out.stdout.split()[1] == "0", (crafted_out.stdout[-500:], crafted_out.stderr[-3000:])   # every crafted file is REJECTED
+
+
+@pytest.mark.parametrize("arg", ["0,x", "0;1", "1,", "-1", ","])
+def test_offline_cli_rejects_malformed_device_lists(tmp_path, arg):
+    """`offline --devices` with anything but a comma-separated list of ordinals ends with a message and exit code 2 (it used to loop forever
+    on a non-numeric token); the list is parsed before any GPU is touched, so this runs anywhere"""
+    import subprocess
+    exe = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "moonshine_amd", "offline")
+    r = subprocess.run([exe, str(tmp_path / "a.glb"), str(tmp_path / "a.exr"), str(tmp_path / "o.exr"), "--devices", arg], capture_output=True, text=True, timeout=20)
+    assert r.returncode == 2 and "--devices" in r.stderr, (r.returncode, r.stderr)

@@ -23,6 +23,7 @@ import numpy as np
 import pytest
 
 from moonshine_amd import scenes
+from moonshine_amd.hostinfo import usable_cores
 
 from tests import second_source as ss
 
@@ -632,7 +633,7 @@ def run_furnace(make_ctx):
 
 
 def test_oracle_material_furnaces(orc):
-    run_furnace(lambda: orc.Context(threads=os.cpu_count() or 1))
+    run_furnace(lambda: orc.Context(threads=usable_cores()))
 
 
 @pytest.mark.gpu
@@ -703,7 +704,7 @@ def run_direct_lighting(make_ctx):
 
 
 def test_oracle_direct_lighting_matches_quadrature(orc):
-    run_direct_lighting(lambda: orc.Context(threads=os.cpu_count() or 1))
+    run_direct_lighting(lambda: orc.Context(threads=usable_cores()))
 
 
 @pytest.mark.gpu

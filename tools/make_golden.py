@@ -17,6 +17,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from oracle import orc  # noqa: E402
 from moonshine_amd import scenes  # noqa: E402
+from moonshine_amd.hostinfo import usable_cores
 
 G = os.path.join(ROOT, "tests", "golden")
 os.makedirs(G, exist_ok=True)
@@ -76,18 +77,18 @@ np.save(os.path.join(G, "bsdf.npy"), np.array(rows, np.float32))
 
 # (2) furnace scenes at reduced sample counts (full counts run in the tests themselves)
 for name, builder, spr in (("furnace_white", scenes.furnace_white_sphere, 16), ("furnace_inside", scenes.furnace_inside_sphere, 16)):
-    c = orc.Context(threads=os.cpu_count())
+    c = orc.Context(threads=usable_cores())
     s, l = builder(c)
     c.set_pipeline(samples_per_run=spr, max_bounces=1024, env_samples_per_bounce=0, mesh_samples_per_bounce=0)
     c.render(s, l)
     np.save(os.path.join(G, name + "_16spp.npy"), c.sensor_data(s))
 # S1-mini and Cornell films (all four BSDFs, env + mesh NEE, MIS)
-c = orc.Context(threads=os.cpu_count())
+c = orc.Context(threads=usable_cores())
 s, l = scenes.s1(c, extent=(64, 36), grid=2, order=2)
 c.set_pipeline(samples_per_run=1, max_bounces=8, env_samples_per_bounce=1, mesh_samples_per_bounce=1)
 c.render(s, l, launches=4)
 np.save(os.path.join(G, "s1_mini_64x36_4spp.npy"), c.sensor_data(s))
-c = orc.Context(threads=os.cpu_count())
+c = orc.Context(threads=usable_cores())
 s, l = scenes.cornell(c, extent=(48, 48))
 c.set_pipeline(samples_per_run=2, max_bounces=8, env_samples_per_bounce=0, mesh_samples_per_bounce=1)
 c.render(s, l, launches=2)
@@ -105,7 +106,7 @@ import tempfile  # noqa: E402
 from tests import io_common as io  # noqa: E402
 d = tempfile.mkdtemp()
 io.write_gallery(os.path.join(d, "gallery.glb"), os.path.join(d, "sky.exr"))
-c = orc.Context(threads=os.cpu_count())
+c = orc.Context(threads=usable_cores())
 lens, _ = io.oracle_load(orc, c, os.path.join(d, "gallery.glb"), os.path.join(d, "sky.exr"))
 s = c.create_sensor(96, 64)
 c.set_pipeline(samples_per_run=4, max_bounces=6, env_samples_per_bounce=1, mesh_samples_per_bounce=1)

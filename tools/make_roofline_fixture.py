@@ -3,7 +3,7 @@ BVH (LBVH, 30-bit Morton, leaves <= 4, collapsed to <= 8-wide, ordered traversal
 tests/golden/roofline_<scene>.json:  V_n / V_t = mean BVH-node visits / triangle tests per ray over the run's
 full ray population (closest + shadow), H = mean surface hits per sample.
 
-    python tools/make_roofline_fixture.py s1 [--width 480 --height 270 --spp 4]
+    python tools/make_roofline_fixture.py s1 --width 1920 --height 1080 --spp 64      (the committed fixtures: the full ray population of the bench run)
 """
 import argparse
 import json
@@ -24,7 +24,8 @@ ap.add_argument("--spp", type=int, default=4)
 a = ap.parse_args()
 
 orc.build()
-c = orc.Context(threads=os.cpu_count())
+from moonshine_amd.hostinfo import usable_cores  # noqa: E402
+c = orc.Context(threads=usable_cores())
 t0 = time.time()
 if a.scene == "s1":
     s, l = scenes.s1(c, extent=(a.width, a.height))
