@@ -219,7 +219,9 @@ def main():
         hbm = {"achieved": hbm_alg, "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": hbm_alg / (HBM_PEAK / 1e9), "algorithmic_bytes_per_launch": bytes_per_launch,
                "bytes_per_unit": unit_bytes[dom]}
         vc = valu_cycles(dom) if (cnt and cal and ck) else None
-        if vc is not None and hbm["frac"] > 1.0:
+        valu_frac = vc * (kun[dom] / nl) / (avg_ms * 1e-3) / cal["peak_simd_cycles_per_s"] if (vc is not None and avg_ms > 0) else None
+        # the bound is the resource the kernel is closest to: vector-instruction issue when the §8(d) HBM figure is not a bound at all (> 1) or the lower of the two
+        if valu_frac is not None and (hbm["frac"] > 1.0 or valu_frac >= hbm["frac"]):
             # the §8(d) HBM figure exceeds the peak: most algorithmic bytes are re-reads that L2 / Infinity Cache serve, HBM is not what bounds this kernel.
             # What does: vector-instruction ISSUE.  achieved = issue cycles the kernel's instructions need per second (calibrated per class on this part),
             # peak = 1024 SIMDs x 2.4 GHz.

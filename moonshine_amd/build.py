@@ -17,8 +17,15 @@ OFFLINE = os.path.join(HERE, "offline")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 CXX = os.environ.get("CXX", "g++")
 EXTRA = os.environ.get("MSNE_CXXFLAGS", "").split()
-FLAGS = EXTRA + ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math", "-Wall", "-Wno-unused-function", "-Wno-comment"]
+# -fno-slp-vectorize: the SLP vectoriser packs adjacent scalar f32 multiplies / adds into v_pk_mul_f32 / v_pk_add_f32, which issue in 4 cycles for two
+# operations — no faster than two 2-cycle scalar ones (profiles/r03_valu_microbench.txt) — and cost moves and registers to pair their operands:
+# without it S1 +1.3 %, S2 +5.0 %, and k_shade capped at 128 registers spills 35 instead of 65 (profiles/r03_compiler_flags.txt).  Same IEEE operations either way.
+FLAGS = EXTRA + ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math", "-fno-slp-vectorize", "-Wall", "-Wno-unused-function", "-Wno-comment"]
 HOST_FLAGS = ["-O2", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Wall", "-Wno-comment"]
+
+
+# per-source flags.  trace.hip: the scheduler's max-ILP strategy (S2's closest-hit kernel -2.6 %, S1 and the sky scene within noise; iterative-minreg: -23 %)
+SOURCE_FLAGS = {"trace.hip": ["-mllvm", "-amdgpu-sched-strategy=max-ilp"]}
 
 
 def _stale(out, deps):
@@ -34,13 +41,17 @@ def build(force=False, verbose=False, variant=None, extra_flags=()):
     hdrs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")] + [api_h]
     objdir = os.path.join(HERE, "build" if variant is None else "build_" + variant)
     os.makedirs(objdir, exist_ok=True)
+    # objects built with other flags are stale too
+    stamp, want = os.path.join(objdir, "flags.txt"), " ".join(flags + HOST_FLAGS + [repr(sorted(SOURCE_FLAGS.items()))])
+    if not os.path.exists(stamp) or open(stamp).read() != want:
+        force = True
     objs, procs = [], []
     for src in SOURCES:
         s = os.path.join(CSRC, src)
         o = os.path.join(objdir, src.replace(".hip", ".o"))
         objs.append(o)
         if force or _stale(o, [s] + hdrs):
-            cmd = [HIPCC] + flags + ["-c", s, "-o", o]
+            cmd = [HIPCC] + flags + SOURCE_FLAGS.get(src, []) + ["-c", s, "-o", o]
             if verbose:
                 print(" ".join(cmd))
             procs.append((src, subprocess.Popen(cmd)))
@@ -58,6 +69,7 @@ def build(force=False, verbose=False, variant=None, extra_flags=()):
             raise RuntimeError("compile failed on %s" % src)
     if force or procs or _stale(lib, objs):
         subprocess.check_call([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib] + objs + ["-lz", "-ldl", "-lpthread"])
+    open(stamp, "w").write(want)
     if variant is not None:
         return lib
     cli = os.path.join(HOST, "offline.cpp")

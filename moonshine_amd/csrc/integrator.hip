@@ -114,7 +114,10 @@ __device__ __forceinline__ f3 estimate_direct_mis(const Frame& frame, const LSam
     return F3(0.0f, 0.0f, 0.0f);
 }
 
-__global__ __launch_bounds__(SHADE_BLOCK, 3) void k_shade(SceneView sc, PipelineOpts opts, PathState cur, HitBuf hits, PathState nxt, ShadowQueue shq,
+#ifndef SHADE_WPS
+#define SHADE_WPS 3          // resident waves per SIMD k_shade is register-allocated for (168 registers; 4 = 128 registers and 35 spilled, measured below)
+#endif
+__global__ __launch_bounds__(SHADE_BLOCK, SHADE_WPS) void k_shade(SceneView sc, PipelineOpts opts, PathState cur, HitBuf hits, PathState nxt, ShadowQueue shq,
                                                          const float4* c_prev /* light-sample contributions of the previous bounce */,
                                                          float4* lbuf, BounceCounters* cnt /* [0]: this bounce, [1]: the next */, uint32_t first_pass /* the queue is k_raygen's */) {
     const uint32_t n = cnt[0].n_paths;
