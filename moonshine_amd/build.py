@@ -26,6 +26,9 @@ HOST_FLAGS = ["-O2", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Wall", "-Wno-
 
 # per-source flags.  trace.hip: the scheduler's max-ILP strategy (S2's closest-hit kernel -2.6 %, S1 and the sky scene within noise; iterative-minreg: -23 %)
 SOURCE_FLAGS = {"trace.hip": ["-mllvm", "-amdgpu-sched-strategy=max-ilp"]}
+for _src in list(SOURCE_FLAGS) + ["integrator.hip"]:   # experiments: $MSNE_FLAGS_trace_hip="..." replaces a source's own flags
+    if os.environ.get("MSNE_FLAGS_" + _src.replace(".", "_")) is not None:
+        SOURCE_FLAGS[_src] = os.environ["MSNE_FLAGS_" + _src.replace(".", "_")].split()
 
 
 def _stale(out, deps):
