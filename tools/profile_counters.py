@@ -61,7 +61,9 @@ def short(n):
 
 
 line = bench_line(G + "_trace.log")
-lines = ["# rocprofv3 --kernel-trace --stats --output-format csv -- python3 " + open(G + "_cmd.txt").read().strip() + "   (MI355X)",
+cmd = open(G + "_cmd.txt").read().strip()
+env_, cmd = (cmd.split(" ", 1) if cmd.startswith("MSNE_") else ("", cmd))
+lines = ["# " + (env_ + " " if env_ else "") + "rocprofv3 --kernel-trace --stats --output-format csv -- python3 " + cmd + "   (MI355X)",
          "%-44s %6s %14s %12s %10s %12s %7s" % ("kernel", "calls", "total_ns", "avg_ns", "min_ns", "max_ns", "pct")]
 stats = glob.glob(os.path.join(G + "_trace", "**", "*kernel_stats.csv"), recursive=True)[0]
 for r in csv.DictReader(open(stats)):
