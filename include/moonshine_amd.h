@@ -274,6 +274,8 @@ const char* MsneGroupGetLastError(const MsneGroup*);     /* NULL group -> last c
  * the next one), so that per-kernel durations are exclusive — what bench.py's roofline attribution pass uses;
  * traversal_counters: count BVH node visits / triangle tests inside the trace kernels. */
 void MsneSetProfiling(HdMoonshine*, int kernel_events, int traversal_counters);
+/* out[0] = acceleration-structure rebuilds so far, out[1] = in-place TLAS updates (instance transform edits that left the structure alone, Accel.zig:567-601) */
+void MsneGetAccelStats(HdMoonshine*, uint64_t out[2]);
 /* bytes of texture data the context keeps in HBM: every texture in the format it was created with (MaterialManager.zig:351-390), each rounded up to 16 B */
 uint64_t MsneGetTexelPoolBytes(HdMoonshine*);
 int MsneGetTraversalCounters(HdMoonshine*, uint64_t out[20]); /* [0..3] closest {nodes,tris}, shadow {nodes,tris}; [4..19] wave-cycle profiles */

@@ -133,6 +133,7 @@ SYMBOLS = [
     ("MsneGetIoError", C.c_char_p, []),
     ("MsneSetProfiling", None, [_vp, C.c_int, C.c_int]),
     ("MsneGetTexelPoolBytes", C.c_uint64, [_vp]),
+    ("MsneGetAccelStats", None, [_vp, C.POINTER(C.c_uint64)]),
     ("MsneGetTraversalCounters", C.c_int, [_vp, C.POINTER(C.c_uint64)]),
     ("MsneTraceRays", C.c_int, [_vp, _vp, _u32, C.c_int, _vp, _vp]),
     ("MsnePick", C.c_int, [_vp, _u32, _u32, F32x2, _vp]),
@@ -375,6 +376,11 @@ class Context:
             self._err("MsneUnpackGatheredFilm")
 
     # ---- statistics / diagnostics ----
+    def accel_stats(self):
+        out = (C.c_uint64 * 2)()
+        self.L.MsneGetAccelStats(self.h, out)
+        return {"rebuilds": int(out[0]), "tlas_updates": int(out[1])}
+
     def texel_pool_bytes(self):
         return int(self.L.MsneGetTexelPoolBytes(self.h))
 

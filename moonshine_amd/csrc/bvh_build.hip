@@ -729,4 +729,113 @@ bool bvh_build_tlas(BuildScratch* scratch, hipStream_t s, const TlasInst* insts,
     return ok;
 }
 
+// ---------------- TLAS in-place update (Accel.zig:567-601 recordUpdateSingleTransform: vkCmdBuildAccelerationStructuresKHR in UPDATE mode) ----------------
+// An instance's transform changed: its TLAS leaf gets the box of its newly transformed vertices and the boxes on the way to the root are
+// re-fitted, the tree itself stays as it was built (like the reference's update, its quality degrades with large moves until the next
+// rebuild).  Two link tables, derived from the finished TLAS by one pass over its nodes: parent (node, slot) of every TLAS node and of every
+// TLAS leaf item.
+__global__ void k_tlas_links(const Node8* nodes, uint32_t node_begin, uint32_t node_end, uint32_t item_begin, uint2* node_parent, uint2* item_parent, uint32_t root) {
+    const uint32_t n = node_begin + blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= node_end) return;
+    if (n == root) node_parent[n - node_begin] = make_uint2(MAX_UINT, 0u);
+    const Node8 nd = nodes[n];
+    uint32_t ci = 0, li = 0;
+    for (uint32_t s = 0; s < 8; s++) {
+        if ((nd.imask >> s) & 1u) { node_parent[nd.child_base + ci - node_begin] = make_uint2(n, s); ci++; }
+        else if ((nd.lmask >> s) & 1u) { item_parent[nd.item_base + li - item_begin] = make_uint2(n, s); li++; }
+    }
+}
+
+// the quantisation of k_collapse, for one child box on a node's grid; false when the box does not fit the grid (the node has to be re-gridded)
+__device__ __forceinline__ bool quantise_child(const float origin[3], const uint8_t e[3], const Box& b, uint8_t ql[3], uint8_t qh[3]) {
+    for (int k = 0; k < 3; k++) {
+        const float inv_s = u2f((uint32_t)(254 - e[k]) << 23);
+        const float lo = floorf((b.lo[k] - origin[k]) * inv_s - 1e-3f), hi = ceilf((b.hi[k] - origin[k]) * inv_s + 1e-3f);
+        if (!(lo >= 0.0f) || !(hi <= 255.0f)) return false;
+        ql[k] = (uint8_t)lo; qh[k] = (uint8_t)hi;
+    }
+    return true;
+}
+__device__ __forceinline__ Box dequantise_child(const Node8& nd, uint32_t s) {
+    Box b;
+    const float o[3] = { nd.ox, nd.oy, nd.oz }; const uint8_t e[3] = { nd.ex, nd.ey, nd.ez };
+    for (int k = 0; k < 3; k++) {
+        const float sc = u2f((uint32_t)e[k] << 23);
+        b.lo[k] = o[k] + (float)nd.qlo[k][s] * sc; b.hi[k] = o[k] + (float)nd.qhi[k][s] * sc;
+    }
+    return b;
+}
+
+// ONE thread walks every edit from its leaf to the root (edits may share ancestors; a refit is a few dozen loads and stores per level)
+__global__ void k_tlas_refit(Node8* nodes, uint32_t node_begin, uint32_t item_begin, const uint2* node_parent, const uint2* item_parent,
+                             const uint32_t* edit_items, const Box* edit_boxes, uint32_t n_edits) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    for (uint32_t ed = 0; ed < n_edits; ed++) {
+        Box nb = edit_boxes[ed];
+        uint2 at = item_parent[edit_items[ed] - item_begin];
+        while (at.x != MAX_UINT) {
+            Node8 nd = nodes[at.x];
+            const uint32_t used = (uint32_t)nd.imask | (uint32_t)nd.lmask;
+            float origin[3] = { nd.ox, nd.oy, nd.oz }; uint8_t e[3] = { nd.ex, nd.ey, nd.ez };
+            uint8_t ql[3], qh[3];
+            if (quantise_child(origin, e, nb, ql, qh)) { for (int k = 0; k < 3; k++) { nd.qlo[k][at.y] = ql[k]; nd.qhi[k][at.y] = qh[k]; } }
+            else {   // the child left the node's grid: a new grid over the union of all children (the others from their quantised boxes: conservative)
+                Box cb[8]; Box u;
+                for (int k = 0; k < 3; k++) { u.lo[k] = 3.0e38f; u.hi[k] = -3.0e38f; }
+                for (uint32_t s = 0; s < 8; s++) if ((used >> s) & 1u) {
+                    cb[s] = s == at.y ? nb : dequantise_child(nd, s);
+                    for (int k = 0; k < 3; k++) { u.lo[k] = fminf(u.lo[k], cb[s].lo[k]); u.hi[k] = fmaxf(u.hi[k], cb[s].hi[k]); }
+                }
+                nd.ox = u.lo[0]; nd.oy = u.lo[1]; nd.oz = u.lo[2];
+                for (int k = 0; k < 3; k++) {   // smallest power of two s with ext/s <= 254, as k_collapse chooses it
+                    const float ext = u.hi[k] - u.lo[k];
+                    int ex = 1;
+                    if (ext > 0.0f) { const float q = ext / 254.0f; ex = (int)((f2u(q) >> 23) & 0xff) + 1; }
+                    if (ex < 1) ex = 1;
+                    if (ex > 254) ex = 254;
+                    e[k] = (uint8_t)ex; origin[k] = u.lo[k];
+                }
+                nd.ex = e[0]; nd.ey = e[1]; nd.ez = e[2];
+                for (uint32_t s = 0; s < 8; s++) if ((used >> s) & 1u) {
+                    uint8_t a[3], b[3];
+                    if (!quantise_child(origin, e, cb[s], a, b)) for (int k = 0; k < 3; k++) { a[k] = 0; b[k] = 255; }   // (cannot happen: the grid spans the union)
+                    for (int k = 0; k < 3; k++) { nd.qlo[k][s] = a[k]; nd.qhi[k][s] = b[k]; }
+                }
+            }
+            nodes[at.x] = nd;
+            // what the parent has to bound: the union of this node's children as the traversal sees them
+            for (int k = 0; k < 3; k++) { nb.lo[k] = 3.0e38f; nb.hi[k] = -3.0e38f; }
+            for (uint32_t s = 0; s < 8; s++) if ((used >> s) & 1u) {
+                const Box c = dequantise_child(nd, s);
+                for (int k = 0; k < 3; k++) { nb.lo[k] = fminf(nb.lo[k], c.lo[k]); nb.hi[k] = fmaxf(nb.hi[k], c.hi[k]); }
+            }
+            at = node_parent[at.x - node_begin];
+        }
+    }
+}
+
+void bvh_tlas_links(hipStream_t s, const Node8* nodes, uint32_t node_begin, uint32_t node_end, uint32_t item_begin, uint2* node_parent, uint2* item_parent, uint32_t root) {
+    if (node_end > node_begin) hipLaunchKernelGGL(k_tlas_links, dim3((node_end - node_begin + 255) / 256), dim3(256), 0, s, nodes, node_begin, node_end, item_begin, node_parent, item_parent, root);
+}
+
+// insts / meshes describe the n_edits edited instances (their NEW transforms), edit_items their TLAS leaf items
+bool bvh_refit_tlas(hipStream_t s, const TlasInst* insts, const TlasMesh* meshes, uint32_t nmeshes, const uint32_t* edit_items, uint32_t n_edits,
+                    Node8* nodes, uint32_t node_begin, uint32_t item_begin, const uint2* node_parent, const uint2* item_parent) {
+    if (n_edits == 0) return true;
+    TlasInst* dinst = nullptr; TlasMesh* dmesh = nullptr; uint32_t* ditems = nullptr; Box* dboxes = nullptr;
+    HIPCHK(hipMalloc(&dinst, (size_t)n_edits * sizeof(TlasInst)));
+    HIPCHK(hipMalloc(&dboxes, (size_t)n_edits * sizeof(Box)));
+    HIPCHK(hipMalloc(&dmesh, (size_t)std::max(nmeshes, 1u) * sizeof(TlasMesh)));
+    HIPCHK(hipMalloc(&ditems, (size_t)n_edits * 4));
+    HIPCHK(hipMemcpyAsync(dinst, insts, (size_t)n_edits * sizeof(TlasInst), hipMemcpyHostToDevice, s));
+    if (nmeshes) HIPCHK(hipMemcpyAsync(dmesh, meshes, (size_t)nmeshes * sizeof(TlasMesh), hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemcpyAsync(ditems, edit_items, (size_t)n_edits * 4, hipMemcpyHostToDevice, s));
+    hipLaunchKernelGGL(k_instance_boxes, dim3(n_edits), dim3(256), 0, s, dinst, dmesh, n_edits, dboxes);
+    hipLaunchKernelGGL(k_tlas_refit, dim3(1), dim3(64), 0, s, nodes, node_begin, item_begin, node_parent, item_parent, ditems, dboxes, n_edits);
+    HIPCHK(hipStreamSynchronize(s));
+    (void)hipFree(dinst); (void)hipFree(dmesh); (void)hipFree(ditems); (void)hipFree(dboxes);
+    return true;
+}
+
+
 }  // namespace msne

@@ -408,6 +408,60 @@ def test_sharded_film_equals_unsharded(gpu_api):
     assert np.array_equal(got.view(np.uint32), ref.view(np.uint32))
 
 
+def test_instance_transform_edits_update_the_tlas_in_place(orc, gpu_api):
+    """hydra.zig:499-505 + Accel.zig:567-601: a transform edit of an instance is applied at the next render by an in-place UPDATE of the TLAS (leaf box from the
+    newly transformed vertices, boxes re-fitted up to the root, instance record overwritten) — no rebuild — and the film and every probe ray equal the oracle's,
+    which rebuilds from scratch: small moves, moves far outside the scene (the ancestors' grids are re-made), rotations with scale, several edits sharing ancestors,
+    the same instance edited twice, edits between consecutive renders.  Edits that change the structure (to / from the identity, many at once) still rebuild."""
+    dims = (5, 4, 3)
+    gc = gpu_api.Context(); oc = orc.Context(threads=8)
+    sg, lg = scenes.s2(gc, extent=(96, 54), dims=dims, order=2); so, lo = scenes.s2(oc, extent=(96, 54), dims=dims, order=2)
+    for c in (gc, oc):
+        c.set_pipeline(samples_per_run=1, max_bounces=4, env_samples_per_bounce=1, mesh_samples_per_bounce=1)
+        c.render(sg if c is gc else so, lg if c is gc else lo, launches=2)
+    assert_film_equal(gc.sensor_data(sg), oc.sensor_data(so), "before any edit")
+    base = gc.accel_stats()
+    assert base == {"rebuilds": 1, "tlas_updates": 0}
+    rs = np.random.default_rng(5)
+
+    def xf(scale, axis, angle, pos):
+        T = np.zeros((3, 4), np.float32); T[:, :3] = (scenes._rot(axis, angle) * scale).astype(np.float32); T[:, 3] = pos
+        return T
+    rounds = [
+        [(7, xf(0.8, (0, 0, 1), 0.3, (0.4, -1.1, 2.0)))],                                                   # one small move
+        [(3, xf(1.7, (1, 1, 0), 1.1, (14.0, -9.0, 11.0))), (4, xf(0.5, (1, 0, 1), 2.0, (-3.0, 2.0, 1.5)))],   # far outside the old bounds + a neighbour
+        [(k, xf(0.6 + 0.3 * rs.random(), tuple(rs.normal(size=3)), rs.random() * 6.0, tuple(rs.normal(size=3) * 4.0 + (0, 0, 4)))) for k in rs.choice(60, 12, replace=False)],
+        [(3, xf(0.9, (0, 1, 0), 0.2, (0.0, 0.0, 3.0))), (3, xf(1.0, (0, 1, 0), 0.7, (-1.0, 0.5, 2.5)))],      # twice before one render: the last one counts
+    ]
+    for n, edits in enumerate(rounds):
+        for h, T in edits:
+            gc.set_instance_transform(int(h), T); oc.set_instance_transform(int(h), T)
+        gc.render(sg, lg, launches=2); oc.render(so, lo, launches=2)
+        assert gc.accel_stats() == {"rebuilds": 1, "tlas_updates": n + 1}, (n, gc.accel_stats())
+        assert_film_equal(gc.sensor_data(sg), oc.sensor_data(so), "after edit round %d" % n)
+        _check_rays(oc, gc, _random_rays(300, 40 + n, radius=12.0))
+    # an identity transform joins the merged world BLAS: structure changes, rebuild
+    I = np.eye(3, 4, dtype=np.float32)
+    gc.set_instance_transform(9, I); oc.set_instance_transform(9, I)
+    gc.render(sg, lg, launches=1); oc.render(so, lo, launches=1)
+    assert gc.accel_stats() == {"rebuilds": 2, "tlas_updates": len(rounds)}
+    assert_film_equal(gc.sensor_data(sg), oc.sensor_data(so), "after the identity edit")
+    # ... and leaving it again
+    T = xf(0.7, (0, 0, 1), 0.5, (1.0, 1.0, 5.0))
+    gc.set_instance_transform(9, T); oc.set_instance_transform(9, T)
+    gc.render(sg, lg, launches=1); oc.render(so, lo, launches=1)
+    assert gc.accel_stats()["rebuilds"] == 3
+    assert_film_equal(gc.sensor_data(sg), oc.sensor_data(so), "after leaving the identity")
+    _check_rays(oc, gc, _random_rays(200, 77, radius=10.0))
+    # the emitter is a sampled light: its world-space areas are in the alias table, so moving it rebuilds
+    nlight = dims[0] * dims[1] * dims[2] + 1
+    TL = np.eye(3, 4, dtype=np.float32); TL[:, 3] = (0.5, 0.0, -0.5)
+    gc.set_instance_transform(nlight, TL); oc.set_instance_transform(nlight, TL)
+    gc.render(sg, lg, launches=1); oc.render(so, lo, launches=1)
+    assert gc.accel_stats()["rebuilds"] == 4
+    assert_film_equal(gc.sensor_data(sg), oc.sensor_data(so), "after moving the light")
+
+
 def test_hydra_abi_smoke(gpu_api):
     """the 24 reference entry points (hydra/moonshine.h:72-95) drive a render exactly as hydra/*.cpp would."""
     import ctypes as C
