@@ -2,7 +2,7 @@
 // TLAS (engine/hrtsystem/Accel.zig:94-184 makeBlases, :484 TLAS build, :629-679 recordRebuild).
 //
 // Pipeline (all HIP kernels, host only sequences launches and reads round / level counts):
-//   k_prim_boxes / k_bounds → k_morton (30-bit) → LSD radix sort 4 x 8 bit (k_radix_hist / _scan / _scatter)
+//   k_prim_boxes / k_bounds → k_morton (63-bit: 21 bits per axis) → stable LSD radix sort, 4 x 8 bit on the low word then 4 x 8 bit on the high word (k_radix_hist / _scan / _scatter)
 //   → PLOC rounds (k_ploc_nn / _mark / _scan / _merge: bottom-up agglomerative clustering, boxes come with the merges)
 //   → k_collapse (level-synchronous collapse to 8-wide in octant slot order, one item per leaf, quantised 80-B nodes)
 //   → k_emit_tris / k_emit_items.
@@ -23,13 +23,6 @@ struct Box { float lo[3]; float hi[3]; };
 __device__ __forceinline__ uint32_t float_to_ordered(float f) { uint32_t u = f2u(f); return (u & 0x80000000u) ? ~u : (u | 0x80000000u); }
 __host__ __device__ __forceinline__ float ordered_to_float(uint32_t u) { return u2f((u & 0x80000000u) ? (u & 0x7fffffffu) : ~u); }
 
-__device__ __forceinline__ uint32_t expand_bits10(uint32_t v) {
-    v = (v * 0x00010001u) & 0xFF0000FFu;
-    v = (v * 0x00000101u) & 0x0F00F00Fu;
-    v = (v * 0x00000011u) & 0xC30C30C3u;
-    v = (v * 0x00000005u) & 0x49249249u;
-    return v;
-}
 
 // ---------------- primitive boxes ----------------
 // triangles of one BLAS: geometry g -> mesh; prim boxes + source records
@@ -105,21 +98,32 @@ __global__ void k_gather_u32(const uint32_t* src, const uint32_t* idx, uint32_t 
     if (i < n) out[i] = src[idx[i]];
 }
 
-__global__ void k_morton(const Box* boxes, uint32_t n, const uint32_t* bounds_all, const uint32_t* seg /* nullptr: one segment */, uint32_t* keys, uint32_t* idx) {
+// 63-bit Morton codes: 21 bits per axis of the primitive's centre inside its segment's bounds (a 30-bit code puts ~60 primitives of a 64 M-triangle scene in
+// one cell — more than PLOC's search radius — and the sort then leaves them in input order).  Low word -> keys, high word (31 bits) -> keys_hi.
+__device__ __forceinline__ unsigned long long expand_bits21(unsigned long long x) {
+    x &= 0x1fffffull;
+    x = (x | x << 32) & 0x1f00000000ffffull;
+    x = (x | x << 16) & 0x1f0000ff0000ffull;
+    x = (x | x << 8) & 0x100f00f00f00f00full;
+    x = (x | x << 4) & 0x10c30c30c30c30c3ull;
+    x = (x | x << 2) & 0x1249249249249249ull;
+    return x;
+}
+__global__ void k_morton(const Box* boxes, uint32_t n, const uint32_t* bounds_all, const uint32_t* seg /* nullptr: one segment */, uint32_t* keys, uint32_t* keys_hi, uint32_t* idx) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const Box b = boxes[i];
     const uint32_t* bounds = bounds_all + (seg ? 6 * (size_t)seg[i] : 0);
-    uint32_t code = 0;
+    unsigned long long code = 0;
     for (int k = 0; k < 3; k++) {
         const float lo = ordered_to_float(bounds[k]), hi = ordered_to_float(bounds[3 + k]);
         const float ext = hi - lo;
         const float c = (b.lo[k] + b.hi[k]) * 0.5f;
         float x = ext > 0.0f ? (c - lo) / ext : 0.0f;
-        x = fminf(fmaxf(x * 1024.0f, 0.0f), 1023.0f);
-        code |= expand_bits10((uint32_t)x) << (2 - k);
+        x = fminf(fmaxf(x * 2097152.0f, 0.0f), 2097151.0f);
+        code |= expand_bits21((unsigned long long)(uint32_t)x) << (2 - k);
     }
-    keys[i] = code; idx[i] = i;
+    keys[i] = (uint32_t)code; keys_hi[i] = (uint32_t)(code >> 32); idx[i] = i;
 }
 
 // exclusive prefix sum over the 1024 threads of a workgroup (wave shuffles + one LDS hop); returns the thread's exclusive prefix, `total` = sum of all
@@ -553,7 +557,7 @@ static bool build_from_boxes(BuildScratch& S, hipStream_t s, uint32_t n, uint32_
         HIPCHK(hipMemcpyAsync(S.bounds, init_bounds, sizeof init_bounds, hipMemcpyHostToDevice, s));
         hipLaunchKernelGGL(k_bounds, dim3(std::min<uint32_t>((n + 255) / 256, 1024)), dim3(256), 0, s, S.boxes, n, S.bounds);
     }
-    hipLaunchKernelGGL(k_morton, dim3((n + 255) / 256), dim3(256), 0, s, S.boxes, n, d_bounds, segmented ? S.seg : nullptr, S.keys, S.idx);
+    hipLaunchKernelGGL(k_morton, dim3((n + 255) / 256), dim3(256), 0, s, S.boxes, n, d_bounds, segmented ? S.seg : nullptr, S.keys, S.nn /* high words, by primitive (free until PLOC) */, S.idx);
     uint32_t *ka = S.keys, *kb = S.keys2, *va = S.idx, *vb = S.idx2;
     auto radix_pass = [&](int shift) {
         hipLaunchKernelGGL(k_radix_hist, dim3(ntiles), dim3(256), 0, s, ka, n, shift, S.ghist, ntiles);
@@ -561,6 +565,8 @@ static bool build_from_boxes(BuildScratch& S, hipStream_t s, uint32_t n, uint32_
         hipLaunchKernelGGL(k_radix_scatter, dim3(ntiles), dim3(64), 0, s, ka, va, n, shift, S.ghist, ntiles, kb, vb);
         std::swap(ka, kb); std::swap(va, vb);
     };
+    for (int pass = 0; pass < 4; pass++) radix_pass(pass * 8);                       // low word
+    hipLaunchKernelGGL(k_gather_u32, dim3((n + 255) / 256), dim3(256), 0, s, S.nn, va, n, ka);   // the sort is stable: four more passes on the high word, in the order reached so far
     for (int pass = 0; pass < 4; pass++) radix_pass(pass * 8);
     if (segmented) {   // the sort is stable: further passes on the segment number bring every segment back together, in Morton order inside
         int bits = 0; while ((1ull << bits) < nseg) bits++;
