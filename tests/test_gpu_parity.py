@@ -939,6 +939,19 @@ def test_traversal_stack_spill_path(tmp_path):
     assert out.returncode == 0 and "SPILL_OK" in out.stdout, out.stdout[-1500:] + out.stderr[-3000:]
 
 
+@pytest.mark.gpu
+def test_fine_morton_codes(tmp_path):
+    """the builder switches from 10 to 21 bits per axis (63-bit codes, eight sort passes) above 4 M primitives — no test scene is that large, so a second
+    process forces the fine codes ($MSNE_MORTON_BITS=21) on S1 and the instanced S2 (single and segmented builds, TLAS): films and ray counts like the oracle's"""
+    import subprocess, sys, os
+    from moonshine_amd import api
+    script = tmp_path / "morton_worker.py"
+    script.write_text(SPILL_WORKER)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, str(script), root, api.LIB_PATH], capture_output=True, text=True, timeout=900, env=dict(os.environ, MSNE_MORTON_BITS="21"))
+    assert out.returncode == 0 and "SPILL_OK" in out.stdout, out.stdout[-1500:] + out.stderr[-3000:]
+
+
 def _odd_scene(c, extent, ior, aperture):
     """texture coordinates far outside [0, 1] (negative, > 1, 1e4: the sampler's wrap rule), non-square and 1-texel-wide textures,
     an emissive texture on a sampled mesh, glass with the given ior, a thin lens with a large aperture"""
