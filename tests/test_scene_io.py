@@ -379,6 +379,8 @@ def test_parsers_survive_mutated_files_under_sanitizers(tmp_path, orc):
     for comp in ("none", "zips", "zip"):
         seeds["exr_" + comp] = assets.exr_bytes(exr_rgba, "RGBA", "half" if comp == "zips" else "float", comp)
     seeds["exr_piz"] = assets.exr_bytes(_piz_images()["smooth"][:40, :23], "RGB", "half", "piz")
+    seeds["exr_tiled"] = assets.exr_bytes(exr_rgba, "RGBA", "float", "zip", tiles=(4, 4), levels="mipmap")
+    seeds["exr_tiledpiz"] = assets.exr_bytes(_piz_images()["smooth"][:40, :23], "RGB", "half", "piz", tiles=(16, 16), line_order=1)
     seeds["png"] = open(os.path.join(THIRD, "python_logo.png"), "rb").read()
     seeds["png2"] = _png_adam7(13, 9, 6, 8, np.random.default_rng(1).integers(0, 256, (9, 13, 4)).astype(np.uint32))
     rs = np.random.default_rng(2024)
