@@ -113,7 +113,7 @@ def _oracle_tiles(orc, glb, exr, extent, spp, tiles, film, pipe):
         assert a.size and np.array_equal(bits(a), bits(b)), "tile %d of %s differs from the oracle" % (t, extent)
 
 
-def test_config2_textured_interior_1080p_256spp(tmp_path, orc):
+def test_config2_asset_substituted_textured_interior_1080p_256spp(tmp_path, orc):
     """configs[2] (asset substituted): `offline` renders the textured interior at 1920x1080, 256 spp, full MIS, max_bounces 1024
     (the CLI's defaults, offline/main.zig:106-111); three 64x64 tiles of the EXR are bit-identical to the oracle fed the same files"""
     glb, exr, out = str(tmp_path / "bath.glb"), str(tmp_path / "sky.exr"), str(tmp_path / "out.exr")
@@ -131,10 +131,10 @@ def test_config2_textured_interior_1080p_256spp(tmp_path, orc):
     assert film.shape == (1080, 1920, 4) and (~ok).sum() <= 20 and 0.05 < float(film[..., :3][ok].mean()) < 5.0
     _oracle_tiles(orc, glb, exr, (1920, 1080), 256, (8 * 30 + 14, 11 * 30 + 9, 14 * 30 + 22), film,
                   dict(samples_per_run=1, max_bounces=1024, env_samples_per_bounce=1, mesh_samples_per_bounce=1))
-    print(r.stdout)
+    print("configs[2]: ASSET SUBSTITUTED (Salle de bain is not available: tests/io_common.py:write_bathroom_standin)\n" + r.stdout)
 
 
-def test_config3_4k_sharded_eight_ways(tmp_path, orc):
+def test_config3_asset_substituted_4k_sharded_eight_members_on_one_gpu(tmp_path, orc):
     """configs[3] (asset substituted, and 8 members on this box's ONE GPU instead of 8 GPUs — the gather is a device copy here, ncclGather
     on distinct GPUs): `offline --devices 0,0,0,0,0,0,0,0` at 3840x2160; tiles of the assembled EXR are bit-identical to the oracle"""
     glb, exr, out = str(tmp_path / "bath.glb"), str(tmp_path / "sky.exr"), str(tmp_path / "out.exr")
@@ -148,7 +148,7 @@ def test_config3_4k_sharded_eight_ways(tmp_path, orc):
     assert film.shape == (2160, 3840, 4) and (~np.isfinite(film[..., :3]).all(-1)).sum() <= 20
     _oracle_tiles(orc, glb, exr, (3840, 2160), 32, (17 * 60 + 28, 25 * 60 + 41, 33 * 60 + 59), film,
                   dict(samples_per_run=1, max_bounces=8, env_samples_per_bounce=1, mesh_samples_per_bounce=1))
-    print(r.stdout)
+    print("configs[3]: ASSET SUBSTITUTED, and 8 members on ONE GPU (device-copy gather instead of ncclGather)\n" + r.stdout)
 
 
 def test_offline_cli_progressive_and_sharded(tmp_path, orc):
