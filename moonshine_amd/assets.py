@@ -296,7 +296,7 @@ def piz_block(lines, words_per_pixel, use_rle=True):
 def exr_bytes(rgba, channels="RGB", pixel_type="float", compression="none", piz_rle=True, tiles=None, levels="one", line_order=0):
     """(H, W, 4) float32 -> OpenEXR bytes.  channels: subset of 'ABGR' letters; pixel_type float|half; compression none|zips|zip|piz.
     Scanline file by default; tiles=(tw, th) writes a single-part TILED file (version bit 0x200, `tiles` attribute, one chunk per tile with
-    its {tile x, tile y, level x, level y} coordinates), levels = "one" or "mipmap" (box-filtered lower levels, rounded down, which a reader of the
+    its {tile x, tile y, level x, level y} coordinates), levels = "one", "mipmap" or "ripmap" (box-filtered lower levels, rounded down, which a reader of the
     full-resolution image has to step over); line_order 1 = DECREASING_Y (chunks stored bottom-up).  Written from the OpenEXR file-layout
     document, independently of the C++ reader."""
     a = np.asarray(rgba, np.float32)
@@ -314,7 +314,7 @@ def exr_bytes(rgba, channels="RGB", pixel_type="float", compression="none", piz_
         + attr("pixelAspectRatio", "float", struct.pack("<f", 1.0)) + attr("screenWindowCenter", "v2f", struct.pack("<ff", 0, 0)) \
         + attr("screenWindowWidth", "float", struct.pack("<f", 1.0))
     if tiles:
-        hdr += attr("tiles", "tiledesc", struct.pack("<IIB", tiles[0], tiles[1], {"one": 0, "mipmap": 1}[levels]))   # rounding mode ROUND_DOWN (high nibble 0)
+        hdr += attr("tiles", "tiledesc", struct.pack("<IIB", tiles[0], tiles[1], {"one": 0, "mipmap": 1, "ripmap": 2}[levels]))   # rounding mode ROUND_DOWN (high nibble 0)
     hdr += b"\0"
     col = {"R": 0, "G": 1, "B": 2, "A": 3}
 
@@ -346,7 +346,28 @@ def exr_bytes(rgba, channels="RGB", pixel_type="float", compression="none", piz_
         return data
 
     chunks = []          # (chunk header bytes, data) in offset-table order
-    if tiles:
+    if tiles and levels == "ripmap":      # every (lx, ly) combination of halvings, ly outer, lx inner; level (0, 0) first
+        tw, th = tiles
+
+        def half(im, axis):
+            n = im.shape[axis]; m = max(n // 2, 1)
+            i0 = [min(2 * k, n - 1) for k in range(m)]; i1 = [min(2 * k + 1, n - 1) for k in range(m)]
+            return (np.take(im, i0, axis) + np.take(im, i1, axis)) * 0.5
+        row, ly = a, 0
+        while True:
+            img, lx = row, 0
+            while True:
+                lh, lw = img.shape[:2]
+                for ty, y0 in enumerate(range(0, lh, th)):
+                    for tx, x0 in enumerate(range(0, lw, tw)):
+                        chunks.append((struct.pack("<iiii", tx, ty, lx, ly), pack(img, y0, min(y0 + th, lh), x0, min(x0 + tw, lw))))
+                if lw == 1:
+                    break
+                img = half(img, 1); lx += 1
+            if row.shape[0] == 1:
+                break
+            row = half(row, 0); ly += 1
+    elif tiles:
         tw, th = tiles
         img, lvl = a, 0
         while True:

@@ -115,7 +115,7 @@ def test_exrdiff_tool(tmp_path):
 @pytest.mark.parametrize("tiles,levels,channels,ptype,comp,order", [
     ((16, 16), "one", "RGB", "float", "none", 0), ((64, 32), "one", "RGBA", "half", "zip", 0), ((16, 8), "mipmap", "RGB", "float", "zips", 0),
     ((32, 32), "mipmap", "RGBA", "half", "piz", 0), ((128, 128), "one", "RGB", "float", "piz", 0), ((7, 5), "one", "BGR", "half", "zip", 1),
-    ((16, 16), "mipmap", "RGB", "float", "zip", 1)])
+    ((16, 16), "mipmap", "RGB", "float", "zip", 1), ((32, 16), "ripmap", "RGBA", "float", "zip", 0), ((8, 8), "ripmap", "RGB", "half", "piz", 1)])
 def test_exr_tiled_reader_against_independent_writer(tmp_path, tiles, levels, channels, ptype, comp, order):
     """single-part TILED files (what several HDRI tools write by default; tinyexr's LoadEXRFromMemory, exr.zig:109-110, reads them): tiles smaller
     and larger than the image, partial edge tiles, every compression, mip-mapped files (only the full-resolution level is read), chunks stored
