@@ -18,8 +18,8 @@
 //    run with more lanes; a node visited with a not yet shortened ray costs a few extra visits, never a wrong result;
 //  * entering an instance (reload the world-space direction, transform, shear constants) is a "space body" that a wave runs when
 //    SPACE_MIN_LANES lanes wait for it or nothing else can be done; the lane puts the world-space half of its ray (origin, reciprocal
-//    direction, octant: 7 registers) aside and takes it back inline when it pops the instance's sentinel — leaving costs no body and no
-//    wait.  The two-level instantiations run 5 waves per SIMD (96 registers) for that; scenes without a TLAS level run an
+//    direction, octant: 7 registers) aside and takes it back inline when its stack is back at the height of the entry (Lane::ret_sp: no sentinel
+//    entry, no second pop) — leaving costs no body and no wait.  The two-level instantiations run 5 waves per SIMD (96 registers) for that; scenes without a TLAS level run an
 //    instantiation without any of it at 6 waves per SIMD (80 registers).
 // Box tests use fmaf and a relative slack (they only gate which triangles are tested); the triangle test is
 // the watertight Woop–Benthin–Wald test evaluated op-for-op like the test oracle, and equal-t ties resolve
@@ -44,7 +44,7 @@ constexpr int TRACE_BLOCK = 256;
 constexpr uint32_t SPACE_MIN_LANES = TRACE_SPACE_MIN_LANES;
 constexpr int STACK_LDS = TRACE_STACK_LDS;   // group entries per lane kept in LDS (2 words each); 6 x (24 KB + 2 KB table) fit the CU's 160 KB
 constexpr int STACK_SPILL = 128 - STACK_LDS; // further entries per lane in HBM (2 words each)
-constexpr uint32_t GRP_NODE = 0u, GRP_INST = 1u << 16, GRP_SENTINEL = 2u << 16, GRP_KIND_MASK = 3u << 16;
+constexpr uint32_t GRP_NODE = 0u, GRP_INST = 1u << 16, GRP_KIND_MASK = 3u << 16;
 
 struct RayK { int kx, ky, kz; float Sx, Sy, Sz; };
 
@@ -105,7 +105,7 @@ struct Lane {
     uint32_t cur_inst;
     int sp, sb;        // stack entries live in rows [sb, sp): sb moves up when the bottom entry is handed to an idle lane (launch tails)
     uint32_t own;      // closest-hit tails: bits 0..5 = the lane that owns this ray (itself unless this lane searches a handed-over piece), bits 8.. = pieces still out
-    bool in_blas;
+    int ret_sp;        // two-level scenes: >= 0 while the lane is inside an instance = the stack height at which the instance's subtree is exhausted; -1 at world level
     f3 wo, wid; uint32_t woct;   // two-level scenes: the world-space origin / reciprocal direction / octant, put aside while the lane is inside an instance
 };
 
@@ -135,7 +135,7 @@ __device__ __forceinline__ void lane_set_space(Lane& L, f3 o, f3 d) {
 __device__ __forceinline__ bool lane_begin(Lane& L, const SceneView& sc, f3 o, f3 d, float tmax) {
     lane_set_space(L, o, d);
     L.best.inst = MAX_UINT; L.best.tri = 0; L.best.t = tmax; L.best.u = 0.0f; L.best.v = 0.0f;
-    L.sp = 0; L.sb = 0; L.in_blas = sc.root_in_blas != 0u; L.cur_inst = WORLD_INSTANCE;   // only used when the root IS the world BLAS
+    L.sp = 0; L.sb = 0; L.ret_sp = -1; L.cur_inst = WORLD_INSTANCE;   // (cur_inst: only used when the root IS the world BLAS)
     L.g0 = sc.tlas_root; L.g1 = sc.tlas_root != MAX_UINT ? (GRP_NODE | 0x0101u) : 0u;   // a group of one: the root itself
     L.ta0 = 0; L.ta1 = 0; L.tb0 = 0; L.tb1 = 0;
     return sc.tlas_root != MAX_UINT;
@@ -164,7 +164,7 @@ __device__ __forceinline__ uint32_t group_take(Lane& L, const StackRef& S, const
 // internal node: 5 x 16-B loads, 8 quantised box tests → 8 hit bits.  Straight-line code, no per-child entries:
 // the hit internal children become the lane's new group, the hit leaves its leaf group (BLAS) or an instance group (TLAS).
 template <bool STATS>
-__device__ __forceinline__ void step_node(Lane& L, const SceneView& sc, const StackRef& S, uint32_t node, unsigned long long& nv) {
+__device__ __forceinline__ void step_node(Lane& L, const SceneView& sc, const StackRef& S, uint32_t node, bool in_blas /* the node belongs to a BLAS: its leaves are triangles */, unsigned long long& nv) {
     const uint4* np = reinterpret_cast<const uint4*>(sc.nodes + node);
     const uint4 w0 = np[0], w1 = np[1], w2 = np[2], w3 = np[3], w4 = np[4];
     if (STATS) nv++;
@@ -200,7 +200,7 @@ __device__ __forceinline__ void step_node(Lane& L, const SceneView& sc, const St
     const uint32_t lmask = w1.z & 0xffu;
     const uint32_t ihits = hits8 & imask, lhits = hits8 & lmask;
     L.g0 = w1.x; L.g1 = GRP_NODE | (imask << 8) | ihits;
-    if (L.in_blas) {   // hit leaves = one triangle each: they queue up behind the group under test (the caller guarantees tb is free)
+    if (in_blas) {   // hit leaves = one triangle each: they queue up behind the group under test (the caller guarantees tb is free)
         const bool a_free = (L.ta1 & 0xffu) == 0u;
         const uint32_t n0 = w1.y, n1 = (lmask << 8) | lhits;
         L.tb0 = a_free ? L.tb0 : n0; L.tb1 = a_free ? L.tb1 : n1;
@@ -327,22 +327,21 @@ __device__ __forceinline__ void trace_wave_loop(const SceneView& sc, uint32_t n,
         bool piece_done = false;   // closest-hit tails: this lane finished a handed-over piece of another lane's ray
         if (active && !(L.g1 & 0xffu)) {
             const bool has_t = (L.ta1 & 0xffu) != 0u;
-            if (L.sp == L.sb) {
-                if (!has_t) {
-                    if (ANY_HIT || L.own == lane) { store(my, L); active = false; }   // (an owner with pieces out — own >> 8 != 0 — waits for them)
-                    else if ((L.own & 63u) != lane) piece_done = true;
-                }
-            } else {
-                lane_pop(L, S);
-                if (__builtin_expect((L.g1 & GRP_KIND_MASK) == GRP_SENTINEL, 0)) {   // leaving an instance: back to the world-space ray
-                    if (has_t) { L.sp++; L.g1 = 0u; }   // ... but only once the triangles queued in instance space are done: un-pop
-                    else {
-                        if (L.g0 & 1u) { L.o = L.wo; L.id = L.wid; L.octbase = L.woct; }   // back to the world-space ray kept aside at entry (the shear constants stay stale: every entry recomputes them)
-                        L.in_blas = false; L.g1 = 0u;
-                        if (L.sp == L.sb) { if (ANY_HIT || L.own == lane) { store(my, L); active = false; } }   // (sentinels only exist on owners' own stacks below sb... see (b'))
-                        else lane_pop(L, S);   // what lies under a sentinel is a TLAS-level group (two levels only), never another sentinel
+            // leaving an instance needs no stack entry and no body: when the stack is back at the height of the entry the instance's subtree is exhausted, and —
+            // once the triangles queued in instance space are tested — the lane takes back the world-space half of its ray (the shear constants stay stale:
+            // every entry recomputes them) and pops at TLAS level in the same iteration
+            bool wait_t = false;
+            if (INSTANCED && L.ret_sp >= 0 && L.sp == L.ret_sp) {
+                if (has_t) wait_t = true;
+                else { L.o = L.wo; L.id = L.wid; L.octbase = L.woct; L.ret_sp = -1; }
+            }
+            if (!wait_t) {
+                if (L.sp == L.sb) {
+                    if (!has_t) {
+                        if (ANY_HIT || L.own == lane) { store(my, L); active = false; }   // (an owner with pieces out — own >> 8 != 0 — waits for them)
+                        else if ((L.own & 63u) != lane) piece_done = true;
                     }
-                }
+                } else lane_pop(L, S);
             }
         }
         if (!ANY_HIT) {   // finished pieces report to the lane that owns the ray: its best hit absorbs theirs (all in one wave: no atomics)
@@ -387,7 +386,7 @@ __device__ __forceinline__ void trace_wave_loop(const SceneView& sc, uint32_t n,
         // to the lane that owns the ray (see (a)); the owner stores the hit when no piece is out.
         if (wq.exhausted) {
             const unsigned long long busy = __ballot(active);
-            const bool give = active && L.sp > L.sb && (sc.root_in_blas != 0u || !L.in_blas);   // only entries that live in world space
+            const bool give = active && L.sp > L.sb && L.ret_sp < 0;   // only entries that live in world space
             const unsigned long long donors = __ballot(give), idle = ~busy;
             const uint32_t nthief = (uint32_t)__popcll(idle), ndon = (uint32_t)__popcll(donors);
             if (ndon != 0u && nthief >= 8u) {
@@ -400,7 +399,7 @@ __device__ __forceinline__ void trace_wave_loop(const SceneView& sc, uint32_t n,
                 const float sx = __shfl(L.rk.Sx, dl), sy = __shfl(L.rk.Sy, dl), sz = __shfl(L.rk.Sz, dl);
                 const float bt = __shfl(L.best.t, dl);
                 const uint32_t ob = __shfl(L.octbase, dl), ci = __shfl(L.cur_inst, dl), dmy = __shfl(my, dl);
-                const int dib = __shfl((int)L.in_blas, dl), dsb = __shfl(L.sb, dl);
+                const int dsb = __shfl(L.sb, dl);
                 const uint32_t downer = (uint32_t)__shfl((int)L.own, dl) & 63u;   // the donor may itself be searching a piece
                 const bool thief = !active && rth < npair;
                 if (thief) {
@@ -413,7 +412,7 @@ __device__ __forceinline__ void trace_wave_loop(const SceneView& sc, uint32_t n,
                     L.o = F3(ox, oy, oz); L.id = F3(ix, iy, iz);
                     L.rk.kx = kx; L.rk.ky = ky; L.rk.kz = kz; L.rk.Sx = sx; L.rk.Sy = sy; L.rk.Sz = sz;
                     L.best.inst = MAX_UINT; L.best.tri = 0; L.best.t = bt; L.best.u = 0.0f; L.best.v = 0.0f;
-                    L.octbase = ob; L.cur_inst = ci; L.in_blas = dib != 0; my = dmy;
+                    L.octbase = ob; L.cur_inst = ci; L.ret_sp = -1; my = dmy;
                     L.sp = 0; L.sb = 0; L.ta1 = 0; L.tb1 = 0; L.own = downer;
                     active = true;
                 }
@@ -460,7 +459,7 @@ __device__ __forceinline__ void trace_wave_loop(const SceneView& sc, uint32_t n,
                 f3 o, d; float tmax;
                 (void)load(my, o, d, tmax);   // the world-space direction is not kept in registers
                 L.wo = L.o; L.wid = L.id; L.woct = L.octbase;
-                lane_push(L, S, 1u, GRP_SENTINEL);
+                L.ret_sp = L.sp;   // (the rest of the instance group is already on the stack: group_take above)
                 if (!ident) {   // t is preserved: d is not renormalised.  (Identity: M·(o,1) = o and M·d = d exactly — only the shear constants are recomputed)
                     m34 M;
                     M.m[0][0] = r0.x; M.m[0][1] = r0.y; M.m[0][2] = r0.z; M.m[0][3] = r0.w;
@@ -470,7 +469,7 @@ __device__ __forceinline__ void trace_wave_loop(const SceneView& sc, uint32_t n,
                     o = oi; d = di;
                 }
                 lane_set_space(L, o, d);
-                L.in_blas = true; L.cur_inst = new_inst; L.g0 = root; L.g1 = GRP_NODE | 0x0101u;   // a group of one: the BLAS root
+                L.cur_inst = new_inst; L.g0 = root; L.g1 = GRP_NODE | 0x0101u;   // a group of one: the BLAS root
             }
         }
         // lanes that just entered hold their BLAS root, lanes that just left hold a TLAS group: they visit it in this iteration
@@ -478,7 +477,7 @@ __device__ __forceinline__ void trace_wave_loop(const SceneView& sc, uint32_t n,
         const bool do_n2 = INSTANCED && do_s ? __ballot(want_n2) != 0ull : do_n;
         if (do_n2 && want_n2) {
             const uint32_t idx = group_take(L, S, lut);
-            step_node<STATS>(L, sc, S, idx, nv);
+            step_node<STATS>(L, sc, S, idx, INSTANCED ? (L.ret_sp >= 0 || sc.root_in_blas != 0u) : true, nv);
         }
         lap(3);
         if (STATS && do_n2) cyc[6] += __popcll(__ballot(want_n2));   // node-lane steps
