@@ -213,7 +213,7 @@ __device__ __forceinline__ void step_node(Lane& L, const SceneView& sc, const St
 
 // ONE triangle of the group under test per call (any order: every hit leaf of a visited node is tested).
 // Returns true when an any-hit ray is finished.
-template <bool ANY_HIT, bool STATS>
+template <bool ANY_HIT, bool STATS, bool INSTANCED>
 __device__ __forceinline__ bool step_tri(Lane& L, const SceneView& sc, unsigned long long& nt) {
     const uint32_t low = L.ta1 & (0u - L.ta1);   // lowest hit bit (the caller guarantees there is one)
     const uint32_t idx = L.ta0 + __popc((L.ta1 >> 8) & (low - 1u));
@@ -224,7 +224,7 @@ __device__ __forceinline__ bool step_tri(Lane& L, const SceneView& sc, unsigned 
     if (STATS) nt++;
     float t, u, v;
     const bool hit = tri_intersect(L.o, L.rk, F3(u2f(a.x), u2f(a.y), u2f(a.z)), F3(u2f(a.w), u2f(b.x), u2f(b.y)), F3(u2f(b.z), u2f(b.w), u2f(c.x)), t, u, v);
-    const uint32_t inst = L.cur_inst == WORLD_INSTANCE ? c.w : L.cur_inst;   // world BLAS: the triangle record names its instance
+    const uint32_t inst = (!INSTANCED || L.cur_inst == WORLD_INSTANCE) ? c.w : L.cur_inst;   // world BLAS (the only one of a scene without a TLAS level): the triangle record names its instance
     if (ANY_HIT) {
         const bool done = hit && t < L.best.t;
         L.best.inst = done ? inst : L.best.inst;
@@ -483,7 +483,7 @@ __device__ __forceinline__ void trace_wave_loop(const SceneView& sc, uint32_t n,
         if (STATS && do_n2) cyc[6] += __popcll(__ballot(want_n2));   // node-lane steps
         if (STATS && !INSTANCED && do_t) cyc[2] += 1;   // (scenes without a TLAS level: slot 2 counts the iterations that ran the triangle body)
         if (do_t && want_t) {
-            if (step_tri<ANY_HIT, STATS>(L, sc, nt)) { L.sp = 0; L.sb = 0; L.g1 = 0; L.ta1 = 0; L.tb1 = 0; store(my, L); active = false; }
+            if (step_tri<ANY_HIT, STATS, INSTANCED>(L, sc, nt)) { L.sp = 0; L.sb = 0; L.g1 = 0; L.ta1 = 0; L.tb1 = 0; store(my, L); active = false; }
         }
         lap(4);
         if (STATS) cyc[5] += __popcll(__ballot(active));   // active lanes at the end of the iteration
