@@ -120,9 +120,13 @@ __device__ __forceinline__ void lane_push(Lane& L, const StackRef& S, uint32_t e
 }
 __device__ __forceinline__ void lane_pop(Lane& L, const StackRef& S) {
     L.sp--;
+    // the LDS entry is read unconditionally (two ds_read) and overwritten in the rare spill case: written as if / else the compiler selects between the two
+    // ADDRESSES and issues one flat_load pair for both — every pop then goes through the flat path
+    const int e = L.sp < STACK_LDS ? L.sp : STACK_LDS - 1;
+    L.g0 = S.lds[(2 * e) * TRACE_BLOCK + threadIdx.x]; L.g1 = S.lds[(2 * e + 1) * TRACE_BLOCK + threadIdx.x];
     if (__builtin_expect(L.sp >= STACK_LDS, 0)) {
         L.g0 = S.spill[(size_t)(2 * (L.sp - STACK_LDS)) * S.spill_stride]; L.g1 = S.spill[(size_t)(2 * (L.sp - STACK_LDS) + 1) * S.spill_stride];
-    } else { L.g0 = S.lds[(2 * L.sp) * TRACE_BLOCK + threadIdx.x]; L.g1 = S.lds[(2 * L.sp + 1) * TRACE_BLOCK + threadIdx.x]; }
+    }
 }
 
 __device__ __forceinline__ void lane_set_space(Lane& L, f3 o, f3 d) {
