@@ -33,6 +33,27 @@ def test_config0_single_triangle(tmp_path, orc, gpu_api):
     assert np.array_equal(bits(imgs[0]), bits(imgs[1]))
 
 
+def test_offline_with_a_tiled_mipmapped_environment(tmp_path):
+    """the `offline` CLI (offline/main.zig:27-50) fed the SAME HDR environment as a scanline ZIP file and as a tiled, mip-mapped PIZ file written bottom-up
+    (what several HDRI tools produce; tinyexr's loader — exr.zig:109-110 — takes level 0 of those): identical output files, pixel for pixel"""
+    glb, sky = str(tmp_path / "gallery.glb"), str(tmp_path / "sky.exr")
+    io.write_gallery(glb, sky)
+    from moonshine_amd import api, assets
+    env = api.exr_load(sky)
+    scan, tiled = str(tmp_path / "scan.exr"), str(tmp_path / "tiled.exr")
+    open(scan, "wb").write(assets.exr_bytes(env, "RGB", "float", "zip"))
+    open(tiled, "wb").write(assets.exr_bytes(env, "RGB", "float", "piz", tiles=(32, 16), levels="mipmap", line_order=1))
+    exe = os.path.join(ROOT, "moonshine_amd", "offline")
+    outs = []
+    for e in (scan, tiled):
+        out = str(tmp_path / (os.path.basename(e) + ".out.exr"))
+        r = subprocess.run([exe, glb, e, out, "4", "--width", "96", "--height", "64", "--max-bounces", "4"], capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stdout + r.stderr
+        outs.append(api.exr_load(out))
+    assert np.isfinite(outs[0]).all() and float(outs[0][..., :3].mean()) > 0.01
+    assert np.array_equal(bits(outs[0]), bits(outs[1]))
+
+
 @pytest.mark.parametrize("u32", [False, True])
 def test_gallery_glb_matches_oracle(tmp_path, orc, gpu_api, u32):
     glb, exr = str(tmp_path / "gallery.glb"), str(tmp_path / "sky.exr")
