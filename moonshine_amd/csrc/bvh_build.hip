@@ -225,7 +225,11 @@ __device__ __forceinline__ float box_area(const Box& b) {
 // for the partner with the smallest merged surface area; mutual choices merge.  Candidate pairs are ordered by
 // (area, min index, max index), a key both ends agree on, so the globally best pair is always mutual and every round
 // makes progress.  Node ids and output slots come from prefix sums (no atomics): the tree is deterministic.
-constexpr int PLOC_RADIUS = 16;
+// The radius: 16 looked best when PLOC went in (round 1), but a sweep over the bench scenes says 4 — S2 3298 Mrays/s against 3128 at 16 (3225 at 3, 3210 at 6), S1 and
+// the 16 M-triangle grid +0.3 … +0.9 %, the stand-in unchanged (profiles/r03_ploc_radius.txt).  A wider search finds a smaller merged box for the pair at hand but
+// leaves stragglers that join late and high up in the tree.  Picking among candidate radii by the tree's surface-area cost was tried and does not pay: the cost ranks
+// the trees roughly (tools/bvh_sah.py) but not finely — the cheapest TLAS by area (radius 3) traced 3.4 % slower than the radius-4 one.
+constexpr int PLOC_RADIUS = 4;
 constexpr int PLOC_BLOCK = 256;
 
 // Round state lives on the device so that the host can queue several rounds without reading anything back: round r reads slot r & 1
