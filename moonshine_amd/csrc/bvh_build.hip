@@ -8,12 +8,15 @@
 //   → k_emit_tris / k_emit_items.
 // The same builder serves BLAS (items = triangles) and TLAS (items = instances).
 #include "msne_device.h"
+#include "../host/host.h"
 #include <vector>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <algorithm>
 #include <new>
+#include <atomic>
+#include <exception>
 
 namespace msne {
 
@@ -203,11 +206,29 @@ struct BinTree {
     float* cost;                             // [7 per node] cost[k-1] = cheapest way to put the subtree into k slots of a wide node (k = 1..7)
     uint8_t* split;                          // [8 per node] split[j-1], j = 2..8: slots given to the left child when the subtree is spread over j slots
                                              //              (0: k slots are not worth it, use j - 1); split[0] unused
+    uint32_t* count;                         // primitives below the node (the weights of the top-down stage)
 };
 // Optimal collapse of the binary tree into 8-wide nodes (Ylitie, Karras, Laine 2017, section 3.1) for leaves of one
 // primitive — every primitive is tested in the same place whatever the cut, so only node visits count:
 // cost(n, 1) = area(n) + spread(n, 8); spread(n, j) = min over k of cost(left, k) + cost(right, j - k);
 // cost(n, j) = min(spread(n, j), cost(n, j - 1)); cost(primitive, j) = 0.
+// cl / cr: the children's tables (zeros for a primitive); cn_out[k-1] = cost(n, k), split_out as in BinTree::split.
+__host__ __device__ inline void collapse_table(const float cl[7], const float cr[7], float area, float cn_out[7], uint8_t split_out[8]) {
+    float spread[9]; uint8_t arg[9];
+    for (int j = 2; j <= 8; j++) {
+        float best = 3.0e38f; int bk = 1;
+        for (int k = 1; k < j; k++) if (k <= 7 && j - k <= 7) { const float v = cl[k - 1] + cr[j - k - 1]; if (v < best) { best = v; bk = k; } }
+        spread[j] = best; arg[j] = (uint8_t)bk;
+    }
+    float cn[8];
+    cn[1] = area + spread[8];
+    split_out[0] = 0; split_out[7] = arg[8];
+    for (int j = 2; j <= 7; j++) {
+        if (spread[j] < cn[j - 1]) { cn[j] = spread[j]; split_out[j - 1] = arg[j]; }
+        else { cn[j] = cn[j - 1]; split_out[j - 1] = 0; }
+    }
+    for (int k = 0; k < 7; k++) cn_out[k] = cn[k + 1];
+}
 
 
 __global__ void k_gather_boxes(const Box* boxes, const uint32_t* idx, uint32_t n, Box* sorted) {
@@ -215,7 +236,7 @@ __global__ void k_gather_boxes(const Box* boxes, const uint32_t* idx, uint32_t n
     if (i < n) sorted[i] = boxes[idx[i]];
 }
 
-__device__ __forceinline__ float box_area(const Box& b) {
+__host__ __device__ __forceinline__ float box_area(const Box& b) {
     const float dx = b.hi[0] - b.lo[0], dy = b.hi[1] - b.lo[1], dz = b.hi[2] - b.lo[2];
     return dx * dy + dy * dz + dz * dx;
 }
@@ -322,20 +343,11 @@ __global__ __launch_bounds__(PLOC_BLOCK) void k_ploc_merge(const uint32_t* cref,
             float cl[7], cr[7];
             if (ref & REF_LEAF) { for (int k = 0; k < 7; k++) cl[k] = 0.0f; } else for (int k = 0; k < 7; k++) cl[k] = t.cost[7 * (size_t)ref + k];
             if (rj & REF_LEAF) { for (int k = 0; k < 7; k++) cr[k] = 0.0f; } else for (int k = 0; k < 7; k++) cr[k] = t.cost[7 * (size_t)rj + k];
-            float spread[9]; uint8_t arg[9];
-            for (int j = 2; j <= 8; j++) {
-                float best = 3.0e38f; int bk = 1;
-                for (int k = 1; k < j; k++) if (k <= 7 && j - k <= 7) { const float v = cl[k - 1] + cr[j - k - 1]; if (v < best) { best = v; bk = k; } }
-                spread[j] = best; arg[j] = (uint8_t)bk;
-            }
-            float cn[8];
-            cn[1] = box_area(b) + spread[8];
-            t.split[8 * (size_t)id + 0] = 0; t.split[8 * (size_t)id + 7] = arg[8];
-            for (int j = 2; j <= 7; j++) {
-                if (spread[j] < cn[j - 1]) { cn[j] = spread[j]; t.split[8 * (size_t)id + j - 1] = arg[j]; }
-                else { cn[j] = cn[j - 1]; t.split[8 * (size_t)id + j - 1] = 0; }
-            }
-            for (int k = 0; k < 7; k++) t.cost[7 * (size_t)id + k] = cn[k + 1];
+            float cn[7]; uint8_t sp[8];
+            collapse_table(cl, cr, box_area(b), cn, sp);
+            for (int k = 0; k < 7; k++) t.cost[7 * (size_t)id + k] = cn[k];
+            for (int k = 0; k < 8; k++) t.split[8 * (size_t)id + k] = sp[k];
+            t.count[id] = ((ref & REF_LEAF) ? 1u : t.count[ref]) + ((rj & REF_LEAF) ? 1u : t.count[rj]);
         }
         ref = id;
     }
@@ -494,11 +506,94 @@ __global__ void k_emit_items(const uint32_t* item_src, uint32_t item_begin, uint
 // ---------------- host orchestration ----------------
 #define HIPCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "moonshine_amd: HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); return false; } } while (0)
 
+// ---------------- the top of the tree: top-down, on the host ----------------
+// PLOC sees neighbours in Morton order only, and near the top of the tree that order says little about space: the last few thousand clusters are
+// handed to the host, which splits them top-down by the surface-area heuristic with a full sweep over the three axes (cost of a split = area(L) x primitives(L)
+// + area(R) x primitives(R)) and writes the resulting binary nodes, with their collapse tables, behind the ones PLOC made.
+struct TopCluster { uint32_t ref; Box box; float cost[7]; uint32_t count; };   // cost: the subtree's collapse table (zeros for a primitive)
+
+__global__ void k_top_gather(const uint32_t* cref, const Box* cbox, uint32_t c, BinTree t, TopCluster* out) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= c) return;
+    TopCluster o;
+    o.ref = cref[i]; o.box = cbox[i];
+    if (o.ref & REF_LEAF) { for (int k = 0; k < 7; k++) o.cost[k] = 0.0f; o.count = 1u; }
+    else { for (int k = 0; k < 7; k++) o.cost[k] = t.cost[7 * (size_t)o.ref + k]; o.count = t.count[o.ref]; }
+    out[i] = o;
+}
+
+// Host copy of the binary tree's tables, indexed by node id like BinTree's (the top-down stages write into it; whole ranges are uploaded afterwards).
+struct HostTree { std::vector<uint32_t> left, right; std::vector<Box> box; std::vector<float> cost; std::vector<uint8_t> split; };
+
+// One top-down build over m elements (clusters or primitives).  Node ids come from `ids` (as many as the build makes: m - 1), so that a subtree can be
+// rebuilt in the ids it had; several builders may run on different threads over disjoint ids of one HostTree.  The elements are sorted once along every
+// axis; a node is the same range [a, b) of the three orders, and a split partitions the other two orders stably, which keeps them sorted: O(m log m).
+struct TopDown {
+    HostTree& T; const uint32_t* ids; uint32_t used = 0;
+    const TopCluster* cl = nullptr;
+    std::vector<uint32_t> ord[3], tmp, count_r; std::vector<uint8_t> right_side; std::vector<float> area_r;
+    struct Sub { uint32_t ref; Box box; float cost[7]; uint32_t count; };
+    TopDown(HostTree& t, const uint32_t* ids_) : T(t), ids(ids_) {}
+    static void grow(Box& b, const Box& o) { for (int k = 0; k < 3; k++) { b.lo[k] = std::min(b.lo[k], o.lo[k]); b.hi[k] = std::max(b.hi[k], o.hi[k]); } }
+    Sub run(const TopCluster* elements, uint32_t m) {
+        cl = elements;
+        tmp.resize(m); count_r.resize(m); right_side.resize(m); area_r.resize(m);
+        std::vector<float> key(m);
+        for (int axis = 0; axis < 3; axis++) {
+            ord[axis].resize(m);
+            for (uint32_t i = 0; i < m; i++) { ord[axis][i] = i; key[i] = cl[i].box.lo[axis] + cl[i].box.hi[axis]; }
+            std::sort(ord[axis].begin(), ord[axis].end(), [&](uint32_t x, uint32_t y) { return key[x] < key[y] || (key[x] == key[y] && x < y); });
+        }
+        return build(0, m, 0);
+    }
+    Sub build(uint32_t a, uint32_t b, uint32_t depth) {
+        if (b - a == 1) { const TopCluster& c = cl[ord[0][a]]; Sub r; r.ref = c.ref; r.box = c.box; r.count = c.count; for (int k = 0; k < 7; k++) r.cost[k] = c.cost[k]; return r; }
+        // equal costs (coincident boxes): the more even split.  Below MAX_SWEEP_DEPTH levels of lopsided splits the rest is halved along axis 0 — the
+        // recursion stays shallow whatever the input
+        constexpr uint32_t MAX_SWEEP_DEPTH = 64;
+        const uint32_t mid = a + (b - a) / 2;
+        auto off = [&](uint32_t i) { return i > mid ? i - mid : mid - i; };
+        double best = 1e300; int best_axis = 0; uint32_t best_at = mid;
+        for (int axis = 0; axis < 3 && depth < MAX_SWEEP_DEPTH; axis++) {
+            const uint32_t* o = ord[axis].data();
+            Box bx; for (int k = 0; k < 3; k++) { bx.lo[k] = 3.0e38f; bx.hi[k] = -3.0e38f; }
+            uint32_t cnt = 0;
+            for (uint32_t i = b; i-- > a + 1;) { grow(bx, cl[o[i]].box); cnt += cl[o[i]].count; area_r[i] = box_area(bx); count_r[i] = cnt; }
+            for (int k = 0; k < 3; k++) { bx.lo[k] = 3.0e38f; bx.hi[k] = -3.0e38f; }
+            cnt = 0;
+            for (uint32_t i = a + 1; i < b; i++) {   // elements [a, i) go left
+                grow(bx, cl[o[i - 1]].box); cnt += cl[o[i - 1]].count;
+                const double c = (double)box_area(bx) * cnt + (double)area_r[i] * count_r[i];
+                if (c < best || (c == best && off(i) < off(best_at))) { best = c; best_axis = axis; best_at = i; }
+            }
+        }
+        for (uint32_t i = a; i < b; i++) right_side[ord[best_axis][i]] = i >= best_at;
+        for (int axis = 0; axis < 3; axis++) {
+            if (axis == best_axis) continue;
+            uint32_t* o = ord[axis].data();
+            uint32_t nl = a, nr = 0;
+            for (uint32_t i = a; i < b; i++) { const uint32_t e = o[i]; if (right_side[e]) tmp[nr++] = e; else o[nl++] = e; }
+            for (uint32_t i = 0; i < nr; i++) o[nl + i] = tmp[i];
+        }
+        const Sub l = build(a, best_at, depth + 1);
+        const Sub r = build(best_at, b, depth + 1);
+        Sub o; o.box = l.box; grow(o.box, r.box); o.count = l.count + r.count;
+        uint8_t sp[8];
+        collapse_table(l.cost, r.cost, box_area(o.box), o.cost, sp);
+        const uint32_t id = ids[used++];
+        o.ref = id;
+        T.left[id] = l.ref; T.right[id] = r.ref; T.box[id] = o.box;
+        for (int k = 0; k < 7; k++) T.cost[7 * (size_t)id + k] = o.cost[k];
+        for (int k = 0; k < 8; k++) T.split[8 * (size_t)id + k] = sp[k];
+        return o;
+    }
+};
+
 struct BuildScratch {
     uint32_t cap = 0;
     Box *boxes = nullptr, *sorted = nullptr, *ibox = nullptr;
     uint32_t *keys = nullptr, *keys2 = nullptr, *idx = nullptr, *idx2 = nullptr, *ghist = nullptr, *bounds = nullptr;
-    uint32_t *left = nullptr, *right = nullptr; float* cost = nullptr; uint8_t* split = nullptr;
+    uint32_t *left = nullptr, *right = nullptr, *count = nullptr; float* cost = nullptr; uint8_t* split = nullptr;
     CollapseWork *wa = nullptr, *wb = nullptr;
     uint32_t* next_count = nullptr;
     Box *cba = nullptr, *cbb = nullptr;                                       // PLOC cluster boxes (ping-pong)
@@ -506,7 +601,7 @@ struct BuildScratch {
     uint2* bbase = nullptr;
     uint32_t *seg = nullptr, *csa = nullptr, *csb = nullptr;                   // batched builds: segment of every primitive / cluster (ping-pong)
     void release() {
-        void* p[] = { boxes, sorted, ibox, keys, keys2, idx, idx2, ghist, bounds, left, right, cost, split, wa, wb, next_count,
+        void* p[] = { boxes, sorted, ibox, keys, keys2, idx, idx2, ghist, bounds, left, right, count, cost, split, wa, wb, next_count,
                       cba, cbb, cra, crb, nn, pflags, bsum, totals, bbase, seg, csa, csb };
         for (void* q : p) if (q) (void)hipFree(q);
         *this = BuildScratch();
@@ -519,7 +614,7 @@ struct BuildScratch {
         HIPCHK(hipMalloc(&boxes, N * sizeof(Box))); HIPCHK(hipMalloc(&sorted, N * sizeof(Box))); HIPCHK(hipMalloc(&ibox, N * sizeof(Box)));
         HIPCHK(hipMalloc(&keys, N * 4)); HIPCHK(hipMalloc(&keys2, N * 4)); HIPCHK(hipMalloc(&idx, N * 4)); HIPCHK(hipMalloc(&idx2, N * 4));
         HIPCHK(hipMalloc(&ghist, (size_t)ntiles * 256 * 4)); HIPCHK(hipMalloc(&bounds, 6 * 4));
-        HIPCHK(hipMalloc(&left, N * 4)); HIPCHK(hipMalloc(&right, N * 4)); HIPCHK(hipMalloc(&cost, N * 28)); HIPCHK(hipMalloc(&split, N * 8));
+        HIPCHK(hipMalloc(&left, N * 4)); HIPCHK(hipMalloc(&right, N * 4)); HIPCHK(hipMalloc(&count, N * 4)); HIPCHK(hipMalloc(&cost, N * 28)); HIPCHK(hipMalloc(&split, N * 8));
         HIPCHK(hipMalloc(&wa, N * sizeof(CollapseWork))); HIPCHK(hipMalloc(&wb, N * sizeof(CollapseWork)));
         HIPCHK(hipMalloc(&next_count, 4));
         const size_t nb = (N + PLOC_BLOCK - 1) / PLOC_BLOCK;
@@ -539,11 +634,20 @@ void bvh_scratch_destroy(BuildScratch* s) { if (s) { s->release(); delete s; } }
 void bvh_scratch_release(BuildScratch* s) { if (s) s->release(); }
 size_t bvh_scratch_capacity(const BuildScratch* s) { return s ? s->cap : 0; }
 
+// How many clusters PLOC leaves for the top-down stage (0: none, PLOC merges down to the roots).  $MSNE_SAH_TOP overrides.
+static uint32_t top_clusters(uint32_t n, uint32_t nseg) {
+    static const int forced = [] { const char* e = getenv("MSNE_SAH_TOP"); return e ? atoi(e) : -1; }();
+    const uint32_t m = forced >= 0 ? (uint32_t)forced : 4096u;
+    if (m < 2 || nseg > m / 2) return 0;   // (many small trees in one batch: their tops are a handful of clusters each)
+    (void)n;
+    return m;
+}
+
 // Builds `nseg` wide BVHs over the n boxes in S.boxes — segment j = boxes [seg_first[j], seg_first[j + 1]), none empty; nseg == 1: one tree over
 // all of them.  Nodes are appended at *node_counter (device), items at *item_counter; item_src[pos] = source box index for final item position pos.
 // Returns the root node index and the root box of every segment (host).
 static bool build_from_boxes(BuildScratch& S, hipStream_t s, uint32_t n, uint32_t nseg, const uint32_t* seg_first /* host, nseg + 1 */, Node8* nodes, uint32_t* node_counter, uint32_t node_capacity,
-                             uint32_t* item_counter, uint32_t* item_src, uint32_t* roots_out, Box* root_boxes) {
+                             uint32_t* item_counter, uint32_t* item_src, uint32_t* roots_out, Box* root_boxes) try {
     const uint32_t ntiles = (n + RS_TILE - 1) / RS_TILE;
     const bool segmented = nseg > 1;
     uint32_t* d_segfirst = nullptr; uint32_t* d_bounds = S.bounds;
@@ -584,7 +688,7 @@ static bool build_from_boxes(BuildScratch& S, hipStream_t s, uint32_t n, uint32_
         for (int shift = 0; shift < bits; shift += 8) radix_pass(shift);
     }
     hipLaunchKernelGGL(k_gather_boxes, dim3((n + 255) / 256), dim3(256), 0, s, S.boxes, va, n, S.sorted);
-    BinTree t{ S.left, S.right, S.ibox, S.cost, S.split };
+    BinTree t{ S.left, S.right, S.ibox, S.cost, S.split, S.count };
     std::vector<uint32_t> root_refs(nseg);
     if (n >= 2) {
         HIPCHK(hipMemcpyAsync(S.cba, S.sorted, (size_t)n * sizeof(Box), hipMemcpyDeviceToDevice, s));
@@ -599,10 +703,14 @@ static bool build_from_boxes(BuildScratch& S, hipStream_t s, uint32_t n, uint32_
         constexpr uint32_t PLOC_GROUP = 8;
         PlocState st0{ n, 0u, 0u, 0u };
         HIPCHK(hipMemcpyAsync(S.totals, &st0, sizeof st0, hipMemcpyHostToDevice, s));
-        uint32_t c = n, round = 0;
-        while (c > nseg) {
+        uint32_t c = n, round = 0, node_base = 0;
+        // (each round at most halves the clusters: `group` rounds from c leave at least c >> group)
+        const uint32_t stop = std::max(nseg, top_clusters(n, nseg));
+        while (c > stop) {
             const uint32_t nb = (c + PLOC_BLOCK - 1) / PLOC_BLOCK;
-            for (uint32_t g = 0; g < PLOC_GROUP; g++, round++) {
+            uint32_t group = PLOC_GROUP;
+            if (stop > nseg) { group = 1; while (group < PLOC_GROUP && (c >> (group + 1)) >= stop) group++; }
+            for (uint32_t g = 0; g < group; g++, round++) {
                 const PlocState* cur = S.totals + (round & 1u); PlocState* nxt = S.totals + ((round + 1u) & 1u);
                 hipLaunchKernelGGL(k_ploc_nn, dim3(nb), dim3(PLOC_BLOCK), 0, s, ba, sa, cur, radius, S.nn);
                 hipLaunchKernelGGL(k_ploc_mark, dim3(nb), dim3(PLOC_BLOCK), 0, s, S.nn, cur, S.pflags, S.bsum);
@@ -614,11 +722,75 @@ static bool build_from_boxes(BuildScratch& S, hipStream_t s, uint32_t n, uint32_
             HIPCHK(hipMemcpyAsync(&now, S.totals + (round & 1u), sizeof now, hipMemcpyDeviceToHost, s));
             HIPCHK(hipStreamSynchronize(s));
             if (now.stuck || now.c >= c || now.c < nseg) { fprintf(stderr, "moonshine_amd: PLOC made no progress\n"); return false; }
-            c = now.c;
+            c = now.c; node_base = now.node_base;
         }
-        HIPCHK(hipMemcpyAsync(root_refs.data(), ra, (size_t)nseg * 4, hipMemcpyDeviceToHost, s));
-        HIPCHK(hipMemcpyAsync(root_boxes, ba, (size_t)nseg * sizeof(Box), hipMemcpyDeviceToHost, s));
-        HIPCHK(hipStreamSynchronize(s));
+        if (c > nseg) {   // the rest top-down on the host
+            TopCluster* dtop = nullptr;
+            HIPCHK(hipMalloc(&dtop, (size_t)c * sizeof(TopCluster)));
+            struct FreeTop { TopCluster* p; ~FreeTop() { (void)hipFree(p); } } free_top{ dtop };
+            hipLaunchKernelGGL(k_top_gather, dim3((c + 255) / 256), dim3(256), 0, s, ra, ba, c, t, dtop);
+            std::vector<TopCluster> cl(c); std::vector<uint32_t> cseg_h(segmented ? c : 0u);
+            HIPCHK(hipMemcpyAsync(cl.data(), dtop, (size_t)c * sizeof(TopCluster), hipMemcpyDeviceToHost, s));
+            if (segmented) HIPCHK(hipMemcpyAsync(cseg_h.data(), sa, (size_t)c * 4, hipMemcpyDeviceToHost, s));
+            const uint32_t total = node_base + (c - nseg);   // binary nodes when all is done
+            if (total > n) { fprintf(stderr, "moonshine_amd: binary node count out of range\n"); return false; }
+            HostTree T;
+            T.left.resize(total); T.right.resize(total); T.box.resize(total); T.cost.resize(7 * (size_t)total); T.split.resize(8 * (size_t)total);
+            static const bool rebuild_bottom = [] { const char* e = getenv("MSNE_SAH_BOTTOM"); return e ? atoi(e) != 0 : true; }();
+            std::vector<Box> prim_box;
+            if (rebuild_bottom && node_base) {
+                prim_box.resize(n);
+                HIPCHK(hipMemcpyAsync(T.left.data(), t.left, (size_t)node_base * 4, hipMemcpyDeviceToHost, s));
+                HIPCHK(hipMemcpyAsync(T.right.data(), t.right, (size_t)node_base * 4, hipMemcpyDeviceToHost, s));
+                HIPCHK(hipMemcpyAsync(prim_box.data(), S.sorted, (size_t)n * sizeof(Box), hipMemcpyDeviceToHost, s));
+            }
+            HIPCHK(hipStreamSynchronize(s));
+            if (rebuild_bottom && node_base) {
+                // every PLOC cluster is rebuilt top-down over its own primitives, in the node ids it had
+                std::atomic<bool> failed{ false };
+                msne_host::parallel_for(c, [&](uint32_t i) { try {
+                    TopCluster& k = cl[i];
+                    if (k.ref & REF_LEAF) return;
+                    std::vector<uint32_t> ids, stack{ k.ref }; std::vector<TopCluster> el;
+                    ids.reserve(k.count); el.reserve(k.count);
+                    while (!stack.empty()) {
+                        const uint32_t r = stack.back(); stack.pop_back();
+                        if (r & REF_LEAF) { TopCluster e; e.ref = r; e.box = prim_box[r & ~REF_LEAF]; for (int q = 0; q < 7; q++) e.cost[q] = 0.0f; e.count = 1u; el.push_back(e); }
+                        else { ids.push_back(r); stack.push_back(T.right[r]); stack.push_back(T.left[r]); }
+                    }
+                    std::sort(ids.begin(), ids.end());
+                    TopDown td(T, ids.data());
+                    const TopDown::Sub r = td.run(el.data(), (uint32_t)el.size());
+                    k.ref = r.ref; k.box = r.box; for (int q = 0; q < 7; q++) k.cost[q] = r.cost[q];
+                } catch (const std::exception&) { failed = true; } });
+                if (failed) { fprintf(stderr, "moonshine_amd: out of host memory in the BVH builder\n"); return false; }
+            }
+            std::vector<uint32_t> top_ids(c - nseg);
+            for (uint32_t i = 0; i < c - nseg; i++) top_ids[i] = node_base + i;
+            TopDown top(T, top_ids.data());
+            for (uint32_t a = 0, j = 0; a < c; j++) {   // the clusters of a segment are contiguous
+                uint32_t b = a + 1;
+                while (segmented && b < c && cseg_h[b] == cseg_h[a]) b++;
+                if (!segmented) b = c;
+                if (j >= nseg || (segmented && cseg_h[a] != j)) { fprintf(stderr, "moonshine_amd: builder lost a segment\n"); return false; }
+                const TopDown::Sub r = top.run(cl.data() + a, b - a);
+                root_refs[j] = r.ref; root_boxes[j] = r.box;
+                a = b;
+            }
+            const uint32_t first = (rebuild_bottom && node_base) ? 0u : node_base, made = total - first;   // the range of ids the host wrote
+            if (made) {
+                HIPCHK(hipMemcpyAsync(t.left + first, T.left.data() + first, (size_t)made * 4, hipMemcpyHostToDevice, s));
+                HIPCHK(hipMemcpyAsync(t.right + first, T.right.data() + first, (size_t)made * 4, hipMemcpyHostToDevice, s));
+                HIPCHK(hipMemcpyAsync(t.box + first, T.box.data() + first, (size_t)made * sizeof(Box), hipMemcpyHostToDevice, s));
+                HIPCHK(hipMemcpyAsync(t.cost + 7 * (size_t)first, T.cost.data() + 7 * (size_t)first, (size_t)made * 28, hipMemcpyHostToDevice, s));
+                HIPCHK(hipMemcpyAsync(t.split + 8 * (size_t)first, T.split.data() + 8 * (size_t)first, (size_t)made * 8, hipMemcpyHostToDevice, s));
+                HIPCHK(hipStreamSynchronize(s));   // (pageable host vectors about to go out of scope)
+            }
+        } else {
+            HIPCHK(hipMemcpyAsync(root_refs.data(), ra, (size_t)nseg * 4, hipMemcpyDeviceToHost, s));
+            HIPCHK(hipMemcpyAsync(root_boxes, ba, (size_t)nseg * sizeof(Box), hipMemcpyDeviceToHost, s));
+            HIPCHK(hipStreamSynchronize(s));
+        }
     } else {
         root_refs[0] = REF_LEAF | 0u;
         HIPCHK(hipMemcpyAsync(root_boxes, S.sorted, sizeof(Box), hipMemcpyDeviceToHost, s));
@@ -645,6 +817,9 @@ static bool build_from_boxes(BuildScratch& S, hipStream_t s, uint32_t n, uint32_
         std::swap(cur, nxt);
     }
     return true;
+} catch (const std::exception& e) {   // (host vectors of the top-down stages)
+    fprintf(stderr, "moonshine_amd: BVH build failed on the host: %s\n", e.what());
+    return false;
 }
 
 // BLASes over the triangles of geometry lists (Accel.zig:94-184; one BLAS per unique mesh list, :315-343) — ALL the BLASes a rebuild needs in one pass, as the

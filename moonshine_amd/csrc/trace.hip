@@ -401,7 +401,9 @@ __device__ __forceinline__ void trace_wave_loop(const SceneView& sc, uint32_t n,
                 const float ix = __shfl(L.id.x, dl), iy = __shfl(L.id.y, dl), iz = __shfl(L.id.z, dl);
                 const int kx = __shfl(L.rk.kx, dl), ky = __shfl(L.rk.ky, dl), kz = __shfl(L.rk.kz, dl);
                 const float sx = __shfl(L.rk.Sx, dl), sy = __shfl(L.rk.Sy, dl), sz = __shfl(L.rk.Sz, dl);
-                const float bt = __shfl(L.best.t, dl);
+                // the donor's best hit so far goes along whole: a piece that meets the same distance again (coincident triangles) must break the tie against it
+                const float bt = __shfl(L.best.t, dl), bu = __shfl(L.best.u, dl), bv = __shfl(L.best.v, dl);
+                const uint32_t binst = (uint32_t)__shfl((int)L.best.inst, dl), btri = (uint32_t)__shfl((int)L.best.tri, dl);
                 const uint32_t ob = __shfl(L.octbase, dl), ci = __shfl(L.cur_inst, dl), dmy = __shfl(my, dl);
                 const int dsb = __shfl(L.sb, dl);
                 const uint32_t downer = (uint32_t)__shfl((int)L.own, dl) & 63u;   // the donor may itself be searching a piece
@@ -415,7 +417,7 @@ __device__ __forceinline__ void trace_wave_loop(const SceneView& sc, uint32_t n,
                     }
                     L.o = F3(ox, oy, oz); L.id = F3(ix, iy, iz);
                     L.rk.kx = kx; L.rk.ky = ky; L.rk.kz = kz; L.rk.Sx = sx; L.rk.Sy = sy; L.rk.Sz = sz;
-                    L.best.inst = MAX_UINT; L.best.tri = 0; L.best.t = bt; L.best.u = 0.0f; L.best.v = 0.0f;
+                    L.best.inst = binst; L.best.tri = btri; L.best.t = bt; L.best.u = bu; L.best.v = bv;
                     L.octbase = ob; L.cur_inst = ci; L.ret_sp = -1; my = dmy;
                     L.sp = 0; L.sb = 0; L.ta1 = 0; L.tb1 = 0; L.own = downer;
                     active = true;

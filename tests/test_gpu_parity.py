@@ -952,6 +952,58 @@ def test_fine_morton_codes(tmp_path):
     assert out.returncode == 0 and "SPILL_OK" in out.stdout, out.stdout[-1500:] + out.stderr[-3000:]
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("top", ["0", "48"])
+def test_builder_stages(tmp_path, top):
+    """the BVH builder hands PLOC's last 4096 clusters to a top-down surface-area build on the host and rebuilds every cluster the same way; the test scenes have fewer
+    primitives than that in most meshes, so second processes run S1 and the instanced S2 with $MSNE_SAH_TOP=48 (PLOC, cluster rebuilds and a top tree in every mesh, the
+    segmented batch build included) and =0 (PLOC alone, as rounds 1-2 built): films and ray counts like the oracle's — results do not depend on the tree"""
+    import subprocess, sys, os
+    from moonshine_amd import api
+    script = tmp_path / "builder_worker.py"
+    script.write_text(SPILL_WORKER)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, str(script), root, api.LIB_PATH], capture_output=True, text=True, timeout=900, env=dict(os.environ, MSNE_SAH_TOP=top))
+    assert out.returncode == 0 and "SPILL_OK" in out.stdout, out.stdout[-1500:] + out.stderr[-3000:]
+
+
+@pytest.mark.gpu
+def test_builder_on_piles_of_identical_boxes(orc, gpu_api):
+    """what a surface-area sweep cannot split: 6000 copies of one triangle (every candidate split costs the same: the builder must halve, not peel one off per level),
+    plus 3000 triangles along a line with geometrically shrinking sizes (lopsided splits level after level: the depth guard) — hit records equal the oracle's, and
+    the tie among the copies goes to primitive 0"""
+    tri = np.array([[-1, -1, 0], [1, -1, 0], [0, 1, 0]], np.float32)
+    pile_idx = np.tile(np.array([[0, 1, 2]], np.uint32), (6000, 1))
+    k = np.arange(3000)
+    size = (0.97 ** k).astype(np.float32)[:, None, None]
+    pos = np.cumsum(np.concatenate([[0.0], (0.97 ** k[:-1]) * 1.2])).astype(np.float32)
+    chain = (tri[None] * size * 0.5 + np.stack([pos + 3.0, np.zeros(3000, np.float32), np.zeros(3000, np.float32)], 1)[:, None, :]).reshape(-1, 3).astype(np.float32)
+    chain_idx = np.arange(9000, dtype=np.uint32).reshape(-1, 3)
+    rs = np.random.default_rng(9)
+    rays = []
+    for _ in range(1500):
+        x = rs.uniform(-1.2, 1.2) if rs.random() < 0.4 else rs.uniform(2.5, float(pos[-1]) + 3.5)
+        o = np.array([x + rs.normal() * 0.3, rs.normal() * 0.3, 2.0 + rs.random()], np.float32)
+        d = np.array([x, rs.uniform(-0.4, 0.4) * (0.3 if x > 2 else 1.0), 0.0], np.float32) - o; d /= np.linalg.norm(d)
+        rays.append([*o, *d, 1e12])
+    rays = np.array(rays, np.float32)
+    ctxs = []
+    for c in (orc.Context(threads=8), gpu_api.Context()):
+        mat = c.create_material(scenes.LAMBERT, c.solid_texture(0.5, 0.5), c.solid_texture(0.0, 0.0, 0.0), color=c.solid_texture(0.8, 0.8, 0.8))
+        c.create_instance([(c.create_mesh(tri, pile_idx), mat, False)])
+        c.create_instance([(c.create_mesh(chain, chain_idx), mat, False)])
+        c.set_pipeline(samples_per_run=1, max_bounces=1, env_samples_per_bounce=0, mesh_samples_per_bounce=0)
+        s = c.create_sensor(8, 8); l = c.create_lens(c.make_lens((0, 0, 5), (0, 0, -1), (0, 1, 0), 0.5))
+        c.render(s, l)
+        ctxs.append(c)
+    oc, gc = ctxs
+    _check_rays(oc, gc, rays)
+    ids, _ = gc.trace_rays(rays, any_hit=False)
+    pile = (ids[:, 0] == 1) & (ids[:, 1] == 0)
+    assert pile.sum() > 100 and (ids[pile][:, 3] == 0).all()
+    assert ((ids[:, 0] == 1) & (ids[:, 1] == 1)).sum() > 100
+
+
 def _odd_scene(c, extent, ior, aperture):
     """texture coordinates far outside [0, 1] (negative, > 1, 1e4: the sampler's wrap rule), non-square and 1-texel-wide textures,
     an emissive texture on a sampled mesh, glass with the given ior, a thin lens with a large aperture"""

@@ -1,6 +1,6 @@
 """Surface-area cost of the wide BVHs the library builds (read back with MsneDebugReadBvh): expected node visits and triangle tests of a random ray that hits the
 root box = sum of box areas over the root's area, internal nodes and leaf boxes separately, per tree (every BLAS and the TLAS of the scene) — to see how the
-builder's knobs ($MSNE_PLOC_RADIUS, $MSNE_MORTON_BITS) move the trees, next to the measured rate.   python tools/bvh_sah.py [s1|s2|sky]"""
+builder's knobs ($MSNE_PLOC_RADIUS, $MSNE_MORTON_BITS, $MSNE_SAH_TOP) move the trees, next to the measured rate.   python tools/bvh_sah.py [s1|s2|sky]"""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
 import numpy as np
@@ -52,7 +52,7 @@ for n in range(len(N)):
     k = pc[imask[n]]
     if k: is_child[child_base[n]:child_base[n] + k] = True
 for n in np.flatnonzero(~is_child): roots.add(int(n))
-print("PLOC radius %s, Morton bits %s" % (os.environ.get("MSNE_PLOC_RADIUS", "16"), os.environ.get("MSNE_MORTON_BITS", "auto")))
+print("PLOC radius %s, Morton bits %s, top-down stage over %s clusters" % (os.environ.get("MSNE_PLOC_RADIUS", "4"), os.environ.get("MSNE_MORTON_BITS", "auto"), os.environ.get("MSNE_SAH_TOP", "4096")))
 for r in sorted(roots):
     ai, al, nn, nl = tree_cost(r)
     if nn + nl < 4: continue
