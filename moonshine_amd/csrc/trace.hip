@@ -258,8 +258,11 @@ struct WaveQueue {
     bool exhausted;
     __device__ WaveQueue(uint32_t n_, uint32_t* head_) : n(n_), head(head_), exhausted(false) {
         const uint32_t nwaves = gridDim.x * (TRACE_BLOCK / 64);
-        uint32_t c = (n / (nwaves * 4u) + 63u) & ~63u;   // (16-ray chunks for short queues were measured: more, emptier waves — slower)
-        chunk = c < 64u ? 64u : (c > 256u ? 256u : c);   // 256: a launch ends when its last wave ends, one chunk (~0.2 ms) after the first
+        uint32_t c = (n / (nwaves * 4u) + 32u) & ~63u;   // (16-ray chunks for short queues were measured: more, emptier waves — slower)
+        // What the static first chunks do not cover is drained through ONE atomic word: with 64-ray chunks that caps a launch at ~5.6 Grays/s, so a queue
+        // that needs the atomic at all is cut into chunks of at least 128 (0.8 M any-hit rays: 223 -> 160 us, 1.6 M: 316 -> 234; an 8-way shard of 20 launches 6.01 -> 5.76 ms)
+        const uint32_t lo = n <= nwaves * 64u ? 64u : 128u;
+        chunk = c < lo ? lo : (c > 256u ? 256u : c);   // 256: a launch ends when its last wave ends, one chunk (~0.2 ms) after the first
         nwaves_chunk = nwaves * chunk;
         const uint32_t wave = blockIdx.x * (TRACE_BLOCK / 64) + (threadIdx.x >> 6);
         pos = wave * chunk; end = pos + chunk;
