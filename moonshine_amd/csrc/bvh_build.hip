@@ -736,7 +736,9 @@ static bool build_from_boxes(BuildScratch& S, hipStream_t s, uint32_t n, uint32_
             if (total > n) { fprintf(stderr, "moonshine_amd: binary node count out of range\n"); return false; }
             HostTree T;
             T.left.resize(total); T.right.resize(total); T.box.resize(total); T.cost.resize(7 * (size_t)total); T.split.resize(8 * (size_t)total);
-            static const bool rebuild_bottom = [] { const char* e = getenv("MSNE_SAH_BOTTOM"); return e ? atoi(e) != 0 : true; }();
+            // (the cluster rebuilds keep 100 B of host memory per primitive for their duration: beyond 48 M primitives only the top tree is made here)
+            static const bool rebuild_wanted = [] { const char* e = getenv("MSNE_SAH_BOTTOM"); return e ? atoi(e) != 0 : true; }();
+            const bool rebuild_bottom = rebuild_wanted && n <= (48u << 20);
             std::vector<Box> prim_box;
             if (rebuild_bottom && node_base) {
                 prim_box.resize(n);
