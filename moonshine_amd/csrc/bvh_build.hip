@@ -16,6 +16,7 @@
 #include <algorithm>
 #include <new>
 #include <atomic>
+#include <chrono>
 #include <exception>
 
 namespace msne {
@@ -725,6 +726,10 @@ static bool build_from_boxes(BuildScratch& S, hipStream_t s, uint32_t n, uint32_
             c = now.c; node_base = now.node_base;
         }
         if (c > nseg) {   // the rest top-down on the host
+            static const bool timing = getenv("MSNE_BUILD_TIMING") != nullptr;
+            const auto t_begin = std::chrono::steady_clock::now(); auto t_prev = t_begin;
+            double t_ms[4] = { 0, 0, 0, 0 };   // fetch, cluster rebuilds, top tree, upload
+            auto lap = [&](int k) { const auto now = std::chrono::steady_clock::now(); t_ms[k] += std::chrono::duration<double, std::milli>(now - t_prev).count(); t_prev = now; };
             TopCluster* dtop = nullptr;
             HIPCHK(hipMalloc(&dtop, (size_t)c * sizeof(TopCluster)));
             struct FreeTop { TopCluster* p; ~FreeTop() { (void)hipFree(p); } } free_top{ dtop };
@@ -747,6 +752,7 @@ static bool build_from_boxes(BuildScratch& S, hipStream_t s, uint32_t n, uint32_
                 HIPCHK(hipMemcpyAsync(prim_box.data(), S.sorted, (size_t)n * sizeof(Box), hipMemcpyDeviceToHost, s));
             }
             HIPCHK(hipStreamSynchronize(s));
+            lap(0);
             if (rebuild_bottom && node_base) {
                 // every PLOC cluster is rebuilt top-down over its own primitives, in the node ids it had
                 std::atomic<bool> failed{ false };
@@ -767,6 +773,7 @@ static bool build_from_boxes(BuildScratch& S, hipStream_t s, uint32_t n, uint32_
                 } catch (const std::exception&) { failed = true; } });
                 if (failed) { fprintf(stderr, "moonshine_amd: out of host memory in the BVH builder\n"); return false; }
             }
+            lap(1);
             std::vector<uint32_t> top_ids(c - nseg);
             for (uint32_t i = 0; i < c - nseg; i++) top_ids[i] = node_base + i;
             TopDown top(T, top_ids.data());
@@ -779,6 +786,7 @@ static bool build_from_boxes(BuildScratch& S, hipStream_t s, uint32_t n, uint32_
                 root_refs[j] = r.ref; root_boxes[j] = r.box;
                 a = b;
             }
+            lap(2);
             const uint32_t first = (rebuild_bottom && node_base) ? 0u : node_base, made = total - first;   // the range of ids the host wrote
             if (made) {
                 HIPCHK(hipMemcpyAsync(t.left + first, T.left.data() + first, (size_t)made * 4, hipMemcpyHostToDevice, s));
@@ -788,6 +796,9 @@ static bool build_from_boxes(BuildScratch& S, hipStream_t s, uint32_t n, uint32_
                 HIPCHK(hipMemcpyAsync(t.split + 8 * (size_t)first, T.split.data() + 8 * (size_t)first, (size_t)made * 8, hipMemcpyHostToDevice, s));
                 HIPCHK(hipStreamSynchronize(s));   // (pageable host vectors about to go out of scope)
             }
+            lap(3);
+            if (timing && n >= 4096u) fprintf(stderr, "moonshine_amd builder: %u primitives in %u trees, %u clusters to the host: fetch %.2f ms, cluster rebuilds %.2f ms, top tree %.2f ms, upload %.2f ms\n",
+                                              n, nseg, c, t_ms[0], t_ms[1], t_ms[2], t_ms[3]);
         } else {
             HIPCHK(hipMemcpyAsync(root_refs.data(), ra, (size_t)nseg * 4, hipMemcpyDeviceToHost, s));
             HIPCHK(hipMemcpyAsync(root_boxes, ba, (size_t)nseg * sizeof(Box), hipMemcpyDeviceToHost, s));
