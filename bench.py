@@ -206,15 +206,18 @@ def main():
         cal = valu_calibration()
         ck = cnt["kernels"].get(dom) if cnt else None
 
-        def valu_cycles(k):
+        def valu_cycles(k, low=False):
             """issue cycles one unit (ray / path) of kernel k needs on a SIMD: its wave-instructions per unit by class (committed PMC pass) x the calibrated
-            cost of the class; INT32 at its cheaper value and nominal 2 / 4 / 8 cycles: a LOWER bound"""
+            cost of the class (nominal 2 / 4 / 8 cycles; INT32 at 2).  The instructions NO class counter books ("OTHER": selects, compares, min / max at 4 cycles, but
+            also and / or / xor / shifts right / moves at 2 — profiles/r03_valu_classes.txt) are priced at 4, or with low=True at 4 - 2 x the two-cycle share counted
+            in the kernels' ISA."""
             e = cnt["kernels"][k]; cc = cal["class_cycles"]
             if "valu_class_per_unit" not in e:
                 return None
             cl = e["valu_class_per_unit"]
             listed = sum(cl[c] for c in ("FMA_F32", "MUL_F32", "ADD_F32", "INT32", "CVT", "TRANS_F32"))
-            return sum(cl[c] * cc[c] for c in ("FMA_F32", "MUL_F32", "ADD_F32", "INT32", "CVT", "TRANS_F32")) + (e["valu_wave_instructions_per_unit"] - listed) * cc["OTHER"]
+            other = cc["OTHER"] - (2.0 * cal.get("other_two_cycle_share", {}).get("value", 0.0) if low else 0.0)
+            return sum(cl[c] * cc[c] for c in ("FMA_F32", "MUL_F32", "ADD_F32", "INT32", "CVT", "TRANS_F32")) + (e["valu_wave_instructions_per_unit"] - listed) * other
 
         hbm = {"achieved": hbm_alg, "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": hbm_alg / (HBM_PEAK / 1e9), "algorithmic_bytes_per_launch": bytes_per_launch,
                "bytes_per_unit": unit_bytes[dom]}
@@ -228,6 +231,7 @@ def main():
             peak = cal["peak_simd_cycles_per_s"]
             ach = vc * (kun[dom] / nl) / (avg_ms * 1e-3)
             roof = {"bound": "valu", "kernel": dom, "achieved": ach / 1e9, "peak": peak / 1e9, "unit": "G SIMD-cycles/s", "frac": ach / peak,
+                    "frac_low": valu_cycles(dom, low=True) * (kun[dom] / nl) / (avg_ms * 1e-3) / peak, "issue_cycles_per_unit_low": valu_cycles(dom, low=True),
                     "issue_cycles_per_unit": vc, "wave_instructions_per_unit": ck["valu_wave_instructions_per_unit"],
                     "lanes_per_instruction": ck["lanes_per_valu_instruction"], "class_per_unit": ck["valu_class_per_unit"],
                     "from": {"instruction_counts": "profiles/" + cnt_file, "cycles_per_class": "profiles/r03_valu_calibration.json"},
