@@ -633,7 +633,7 @@ static bool build_from_boxes(BuildScratch& S, hipStream_t s, uint32_t n, uint32_
         }
         if (c > nseg) {   // the rest top-down on the host
             static const bool timing = getenv("MSNE_BUILD_TIMING") != nullptr;
-            const auto t_begin = std::chrono::steady_clock::now(); auto t_prev = t_begin;
+            auto t_prev = std::chrono::steady_clock::now();
             double t_ms[4] = { 0, 0, 0, 0 };   // fetch, cluster rebuilds, top tree, upload
             auto lap = [&](int k) { const auto now = std::chrono::steady_clock::now(); t_ms[k] += std::chrono::duration<double, std::milli>(now - t_prev).count(); t_prev = now; };
             TopCluster* dtop = nullptr;
