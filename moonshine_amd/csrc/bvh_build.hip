@@ -544,8 +544,9 @@ size_t bvh_scratch_capacity(const BuildScratch* s) { return s ? s->cap : 0; }
 // How many clusters PLOC leaves for the top-down stage (0: none, PLOC merges down to the roots).  $MSNE_SAH_TOP overrides.
 static uint32_t top_clusters(uint32_t n, uint32_t nseg) {
     static const int forced = [] { const char* e = getenv("MSNE_SAH_TOP"); return e ? atoi(e) : -1; }();
-    const uint32_t m = forced >= 0 ? (uint32_t)forced : 4096u;
-    if (m < 2 || nseg > m / 2) return 0;   // (many small trees in one batch: their tops are a handful of clusters each)
+    // 4096 for one tree; a batch of trees gets ~4 clusters each, up to 32768 — beyond 16384 trees in one batch PLOC builds them whole
+    const uint32_t m = forced >= 0 ? (uint32_t)forced : std::min<uint32_t>(std::max<uint32_t>(4096u, 4u * nseg), 32768u);
+    if (m < 2 || nseg > m / 2) return 0;
     (void)n;
     return m;
 }
