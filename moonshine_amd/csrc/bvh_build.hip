@@ -556,6 +556,9 @@ static uint32_t top_clusters(uint32_t n, uint32_t nseg) {
 // Returns the root node index and the root box of every segment (host).
 static bool build_from_boxes(BuildScratch& S, hipStream_t s, uint32_t n, uint32_t nseg, const uint32_t* seg_first /* host, nseg + 1 */, Node8* nodes, uint32_t* node_counter, uint32_t node_capacity,
                              uint32_t* item_counter, uint32_t* item_src, uint32_t* roots_out, Box* root_boxes) try {
+    static const bool phase_timing = getenv("MSNE_BUILD_TIMING") != nullptr;
+    auto ph_prev = std::chrono::steady_clock::now(); double ph_ms[4] = { 0, 0, 0, 0 };   // sort, PLOC, host stages, collapse
+    auto phase = [&](int k) { if (!phase_timing) return; (void)hipStreamSynchronize(s); const auto now = std::chrono::steady_clock::now(); ph_ms[k] += std::chrono::duration<double, std::milli>(now - ph_prev).count(); ph_prev = now; };
     const uint32_t ntiles = (n + RS_TILE - 1) / RS_TILE;
     const bool segmented = nseg > 1;
     uint32_t* d_segfirst = nullptr; uint32_t* d_bounds = S.bounds;
@@ -596,6 +599,7 @@ static bool build_from_boxes(BuildScratch& S, hipStream_t s, uint32_t n, uint32_
         for (int shift = 0; shift < bits; shift += 8) radix_pass(shift);
     }
     hipLaunchKernelGGL(k_gather_boxes, dim3((n + 255) / 256), dim3(256), 0, s, S.boxes, va, n, S.sorted);
+    phase(0);
     BinTree t{ S.left, S.right, S.ibox, S.cost, S.split, S.count };
     std::vector<uint32_t> root_refs(nseg);
     if (n >= 2) {
@@ -632,6 +636,7 @@ static bool build_from_boxes(BuildScratch& S, hipStream_t s, uint32_t n, uint32_
             if (now.stuck || now.c >= c || now.c < nseg) { fprintf(stderr, "moonshine_amd: PLOC made no progress\n"); return false; }
             c = now.c; node_base = now.node_base;
         }
+        phase(1);
         if (c > nseg) {   // the rest top-down on the host
             static const bool timing = getenv("MSNE_BUILD_TIMING") != nullptr;
             auto t_prev = std::chrono::steady_clock::now();
@@ -647,13 +652,13 @@ static bool build_from_boxes(BuildScratch& S, hipStream_t s, uint32_t n, uint32_
             const uint32_t total = node_base + (c - nseg);   // binary nodes when all is done
             if (total > n) { fprintf(stderr, "moonshine_amd: binary node count out of range\n"); return false; }
             HostTree T;
-            T.left.resize(total); T.right.resize(total); T.box.resize(total); T.cost.resize(7 * (size_t)total); T.split.resize(8 * (size_t)total);
+            T.alloc(total);
             // (the cluster rebuilds keep 100 B of host memory per primitive for their duration: beyond 48 M primitives only the top tree is made here)
             static const bool rebuild_wanted = [] { const char* e = getenv("MSNE_SAH_BOTTOM"); return e ? atoi(e) != 0 : true; }();
             const bool rebuild_bottom = rebuild_wanted && n <= (48u << 20);
-            std::vector<Box> prim_box;
+            RawArray<Box> prim_box;
             if (rebuild_bottom && node_base) {
-                prim_box.resize(n);
+                prim_box.alloc(n);
                 HIPCHK(hipMemcpyAsync(T.left.data(), t.left, (size_t)node_base * 4, hipMemcpyDeviceToHost, s));
                 HIPCHK(hipMemcpyAsync(T.right.data(), t.right, (size_t)node_base * 4, hipMemcpyDeviceToHost, s));
                 HIPCHK(hipMemcpyAsync(prim_box.data(), S.sorted, (size_t)n * sizeof(Box), hipMemcpyDeviceToHost, s));
@@ -715,6 +720,7 @@ static bool build_from_boxes(BuildScratch& S, hipStream_t s, uint32_t n, uint32_
         root_refs[0] = REF_LEAF | 0u;
         HIPCHK(hipMemcpyAsync(root_boxes, S.sorted, sizeof(Box), hipMemcpyDeviceToHost, s));
     }
+    phase(2);
     // one wide root node per segment
     uint32_t root_wide = 0;
     HIPCHK(hipMemcpyAsync(&root_wide, node_counter, 4, hipMemcpyDeviceToHost, s));
@@ -736,6 +742,8 @@ static bool build_from_boxes(BuildScratch& S, hipStream_t s, uint32_t n, uint32_
         HIPCHK(hipStreamSynchronize(s));
         std::swap(cur, nxt);
     }
+    phase(3);
+    if (phase_timing && n >= 4096u) fprintf(stderr, "moonshine_amd builder: %u primitives: sort %.2f ms, PLOC %.2f ms, host stages %.2f ms, collapse %.2f ms\n", n, ph_ms[0], ph_ms[1], ph_ms[2], ph_ms[3]);
     return true;
 } catch (const std::exception& e) {   // (host vectors of the top-down stages)
     fprintf(stderr, "moonshine_amd: BVH build failed on the host: %s\n", e.what());

@@ -3,6 +3,7 @@
 #pragma once
 #include <algorithm>
 #include <cstdint>
+#include <memory>
 #include <vector>
 #if defined(__HIPCC__)
 #define BVH_HD __host__ __device__
@@ -44,7 +45,19 @@ BVH_HD inline void collapse_table(const float cl[7], const float cr[7], float ar
 struct TopCluster { uint32_t ref; Box box; float cost[7]; uint32_t count; };   // cost: the subtree's collapse table (zeros for a primitive)
 
 // Host copy of the binary tree's tables, indexed by node id like BinTree's (the top-down stages write into it; whole ranges are uploaded afterwards).
-struct HostTree { std::vector<uint32_t> left, right; std::vector<Box> box; std::vector<float> cost; std::vector<uint8_t> split; };
+// (storage that is NOT zero-filled when it is made: every entry is written before it is read, and for a million primitives the fill alone takes milliseconds)
+template <class V> struct RawArray {
+    std::unique_ptr<V[]> p; size_t n = 0;
+    void alloc(size_t m) { p.reset(new V[m]); n = m; }
+    void fill(V v) { for (size_t i = 0; i < n; i++) p[i] = v; }
+    V& operator[](size_t i) { return p[i]; }
+    const V& operator[](size_t i) const { return p[i]; }
+    V* data() { return p.get(); }
+};
+struct HostTree {
+    RawArray<uint32_t> left, right; RawArray<Box> box; RawArray<float> cost; RawArray<uint8_t> split;
+    void alloc(size_t nodes) { left.alloc(nodes); right.alloc(nodes); box.alloc(nodes); cost.alloc(7 * nodes); split.alloc(8 * nodes); }
+};
 
 // One top-down build over m elements (clusters or primitives).  Node ids come from `ids` (as many as the build makes: m - 1), so that a subtree can be
 // rebuilt in the ids it had; several builders may run on different threads over disjoint ids of one HostTree.  The elements are sorted once along every

@@ -16,7 +16,7 @@ extern "C" int topdown_build(const float* boxes /* 6 per element: lo xyz, hi xyz
     }
     const uint32_t total = id_base + (n - 1);
     HostTree T;
-    T.left.assign(total, 0xFFFFFFFFu); T.right.assign(total, 0xFFFFFFFFu); T.box.resize(total); T.cost.assign(7 * (size_t)total, -1.0f); T.split.assign(8 * (size_t)total, 0xFF);
+    T.alloc(total); T.left.fill(0xFFFFFFFFu); T.right.fill(0xFFFFFFFFu); T.cost.fill(-1.0f); T.split.fill(0xFF);
     std::vector<uint32_t> ids(n - 1);
     for (uint32_t i = 0; i + 1 < n; i++) ids[i] = id_base + i;
     TopDown td(T, ids.data());
