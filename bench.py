@@ -5,6 +5,11 @@ packed film.  A "step" = one launch of the hot path = one sample per pixel over 
 
     python bench.py --gpus 1 --steps 64 --warmup 4 [--scene s2] [--env sky]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+    python bench.py --gpus N ...                 (no launcher: bench.py starts the N ranks itself as CHILD processes, before it touches the GPU)
+    python bench.py --gpus N --launcher group    (one process: the library's own MsneGroup — one context per GPU, native ncclGather, csrc/group.hip)
+
+`transport` in the line says what moved the films: "rccl" (torch.distributed nccl backend or the library's ncclGather between distinct GPUs), "gloo" (ranks that
+had to share a GPU: host memory), "copy" (group members sharing a GPU: device-to-device copies), "none" (one rank).  `ranks_seen` / `devices_seen` are counted, not assumed.
 
 Timed region: EXACTLY `steps` steps, bracketed by barrier + synchronize on both sides, max over ranks.  The region is
 repeated `--repeats` times (default 5, SURVEY.md §8(d): "median of >= 5 runs") on a cleared sensor; `value` is the median
@@ -81,8 +86,85 @@ def valu_calibration():
     return json.load(open(f)) if os.path.exists(f) else None
 
 
+def launch_ranks(a):
+    """`python bench.py --gpus N` without a launcher: start the N ranks as CHILD processes (torch.distributed.run, rendezvous on 127.0.0.1) and relay rank 0's
+    line.  Nothing in this process has touched the GPU yet (torch.cuda.device_count() does not initialise it) and this process is never replaced by another.
+    With fewer GPUs than ranks (a one-GPU box) the ranks share devices and gather through host memory (gloo) — labelled as such in the line."""
+    import socket
+    import subprocess
+    ndev = torch.cuda.device_count()
+    env = dict(os.environ)
+    if ndev < a.gpus and "MSNE_BENCH_BACKEND" not in env:
+        env["MSNE_BENCH_BACKEND"] = "gloo"
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(a.gpus), "--master-addr", "127.0.0.1", "--master-port", str(port),
+           os.path.abspath(__file__)] + sys.argv[1:]
+    p = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    for line in p.stdout:
+        sys.stdout.write(line); sys.stdout.flush()
+    raise SystemExit(p.wait())
+
+
+def run_group(a):
+    """--launcher group: the library's own multi-GPU driver (csrc/group.hip) — one context per GPU inside THIS process, one host thread per member, tiles sharded
+    over the members, ncclGather of the packed films (device copies when members share a GPU), k_unpack_film on member 0.  Timed region: MsneGroupRender of
+    exactly K steps (render on every member + gather + unpack; it returns when the assembled film is complete), bracketed by device synchronisation."""
+    ndev = max(torch.cuda.device_count(), 1)
+    devices = [i % ndev for i in range(a.gpus)]
+    g = api.Group(devices)
+    sensor, lens = g.build(lambda c: build_scene(c, a))
+    g.set_pipeline(samples_per_run=1, max_bounces=8, env_samples_per_bounce=1, mesh_samples_per_bounce=1)
+    for c in g.members:
+        c.set_profiling(kernel_events=False, traversal_counters=False)
+        c.reserve(sensor, max(a.steps, a.warmup))
+
+    def sync():
+        for d in sorted(set(devices)):
+            torch.cuda.synchronize(d)
+    if a.warmup:
+        g.render(sensor, lens, launches=a.warmup)
+    for c in g.members:
+        c.reset_stats()
+    times = []
+    for _ in range(max(a.repeats, 1)):
+        for c in g.members:
+            c.clear_sensor(sensor)
+        sync()
+        t0 = time.perf_counter()
+        g.render(sensor, lens, launches=a.steps)
+        sync()
+        times.append(time.perf_counter() - t0)
+    R = len(times)
+    st = [c.stats() for c in g.members]
+    closest, shadow, samples = (sum(float(s[k]) for s in st) / R for k in ("closest_rays", "shadow_rays", "samples"))
+    rays, dt = closest + shadow, statistics.median(times)
+    if a.dump_film:
+        np.save(a.dump_film, g.sensor_data(sensor))
+    rates = [rays / t / 1e6 for t in times]
+    print(json.dumps({
+        "metric": "Mrays/sec, 1M-tri scene @1080p" if a.scene == "s1" else "Mrays/sec, 10M-tri instanced scene @1080p",
+        "value": rays / dt / 1e6, "unit": "Mrays/s", "n_gpus": a.gpus, "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3,
+        "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": workload_name(a), "sharding": "16x16 image tiles, tile t -> member t mod %d, one gather of the packed film (MsneGroup, one process)" % a.gpus},
+        "launcher": "group", "transport": g.transport(), "ranks_seen": len(g.members), "devices_seen": len(set(devices)),
+        "repeats": R, "repeat_values": rates, "spread": (max(rates) - min(rates)) / statistics.median(rates),
+        "msamples_per_s": samples / dt / 1e6, "rays": {"closest": closest, "shadow": shadow, "per_sample": rays / max(samples, 1.0)},
+        "roofline": None, "cpu_baseline": None}))
+    g.close()
+
+
+def workload_name(a):
+    return (("S1: 7x7 order-5 icospheres (1 003 520 tris) + ground + emissive quad" if a.scene == "s1" else
+             "S2: 500 instances of one order-5 icosphere (10 240 000 instanced tris), glass / GGX")
+            + ", %dx%d, %d spp, max_bounces 8, env+mesh NEE with MIS, %s env" % (a.width, a.height, a.steps, a.env))
+
+
 def main():
     ap = argparse.ArgumentParser()
+    ap.add_argument("--launcher", default="auto", choices=["auto", "ranks", "group"],
+                    help="how --gpus N > 1 runs when no launcher started us: ranks = child processes under torch.distributed.run (auto), group = MsneGroup in this process")
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=64)
     ap.add_argument("--warmup", type=int, default=4)
@@ -98,8 +180,11 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    launched = "WORLD_SIZE" in os.environ or "RANK" in os.environ
+    if a.gpus > 1 and not launched:
+        return run_group(a) if a.launcher == "group" else launch_ranks(a)
     if world != a.gpus:
-        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d (launch N>1 with torch.distributed.run)" % (a.gpus, world))
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d" % (a.gpus, world))
     # MSNE_BENCH_BACKEND=gloo is a debugging aid: several ranks may then share one GPU and the gather goes through host memory
     backend = os.environ.get("MSNE_BENCH_BACKEND", "nccl")
     dev = local_rank if backend == "nccl" else local_rank % max(torch.cuda.device_count(), 1)
@@ -173,12 +258,18 @@ def main():
     sa = ctx.stats()
     ctx.set_profiling(kernel_events=False, traversal_counters=False)
 
-    tt = torch.tensor(times + [float(st["closest_rays"]) / R, float(st["shadow_rays"]) / R, float(st["samples"]) / R], dtype=torch.float64, device="cuda")
+    NDEV = 64
+    tt = torch.tensor(times + [float(st["closest_rays"]) / R, float(st["shadow_rays"]) / R, float(st["samples"]) / R, 1.0] + [float(i == dev) for i in range(NDEV)],
+                      dtype=torch.float64, device="cuda")
     if world > 1:
         tmax = tt.clone(); dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dist.all_reduce(tt, op=dist.ReduceOp.SUM)
         times = [float(x) for x in tmax[:R]]
+        devices_seen = int(tmax[R + 4:].sum())
+    else:
+        devices_seen = 1
     closest, shadow, samples = float(tt[R]), float(tt[R + 1]), float(tt[R + 2])     # per repeat, all ranks
+    ranks_seen = int(round(float(tt[R + 3])))                                         # ranks that took part in the reduction (counted, not assumed)
     rays = closest + shadow
     dt = statistics.median(times)
 
@@ -253,10 +344,9 @@ def main():
             "value": rays / dt / 1e6, "unit": "Mrays/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3,
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": ("S1: 7x7 order-5 icospheres (1 003 520 tris) + ground + emissive quad" if a.scene == "s1" else
-                                    "S2: 500 instances of one order-5 icosphere (10 240 000 instanced tris), glass / GGX")
-                                   + ", %dx%d, %d spp, max_bounces 8, env+mesh NEE with MIS, %s env" % (a.width, a.height, a.steps, a.env),
-                       "sharding": "16x16 image tiles, tile t -> rank t mod %d, one RCCL gather of the packed film" % world},
+            "config": {"workload": workload_name(a),
+                       "sharding": "16x16 image tiles, tile t -> rank t mod %d, one gather of the packed film (one process per GPU)" % world},
+            "launcher": "ranks", "transport": "none" if world == 1 else ("rccl" if backend == "nccl" else backend), "ranks_seen": ranks_seen, "devices_seen": devices_seen,
             "repeats": R, "repeat_values": rates, "spread": (max(rates) - min(rates)) / statistics.median(rates),
             "msamples_per_s": samples / dt / 1e6,
             "rays": {"closest": closest, "shadow": shadow, "per_sample": rays / max(samples, 1.0)},

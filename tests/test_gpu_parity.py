@@ -1251,3 +1251,31 @@ def test_bench_gather_path_with_two_ranks(tmp_path):
     assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
     l1 = json.loads([x for x in r1.stdout.splitlines() if x.startswith("{")][-1]); l2 = json.loads([x for x in r2.stdout.splitlines() if x.startswith("{")][-1])
     assert l2["n_gpus"] == 2 and l1["rays"] == l2["rays"] and len(l2["repeat_values"]) == 2       # the same rays, counted over both ranks
+
+
+def test_bench_starts_its_own_ranks(tmp_path):
+    """`python bench.py --gpus 2` with NO launcher environment: bench.py starts the two ranks itself as child processes (they share this box's one GPU, so the
+    films travel through gloo and the line says so), and `--launcher group` runs the library's MsneGroup in one process (device copies on a shared GPU).
+    Both assemble the film a single rank renders, bit for bit, and count the same rays."""
+    import json, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "MSNE_BENCH_BACKEND")}
+    args = ["--steps", "3", "--warmup", "1", "--repeats", "2", "--width", "328", "--height", "200", "--no-cpu-baseline"]
+    films, lines = {}, {}
+    for name, extra in (("one", ["--gpus", "1"]), ("ranks", ["--gpus", "2"]), ("group", ["--gpus", "2", "--launcher", "group"]), ("ranks3", ["--gpus", "3"])):
+        f = str(tmp_path / (name + ".npy"))
+        r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--dump-film", f] + extra + args, capture_output=True, text=True, timeout=900, env=env)
+        assert r.returncode == 0, (name, r.stderr[-3000:])
+        films[name] = np.load(f)
+        lines[name] = json.loads([x for x in r.stdout.splitlines() if x.startswith("{")][-1])
+    for name in ("ranks", "group", "ranks3"):
+        assert np.array_equal(films[name].view(np.uint32), films["one"].view(np.uint32)), name
+        assert lines[name]["rays"] == lines["one"]["rays"], name
+    import torch
+    shared = torch.cuda.device_count() < 2
+    assert lines["one"]["transport"] == "none" and lines["one"]["n_gpus"] == 1
+    assert lines["ranks"]["n_gpus"] == 2 and lines["ranks"]["ranks_seen"] == 2 and lines["ranks"]["transport"] == ("gloo" if shared else "rccl")
+    assert lines["ranks3"]["n_gpus"] == 3 and lines["ranks3"]["ranks_seen"] == 3
+    assert lines["group"]["n_gpus"] == 2 and lines["group"]["ranks_seen"] == 2 and lines["group"]["transport"] == ("copy" if shared else "rccl")
+    assert lines["ranks"]["devices_seen"] == (1 if shared else 2)
+
