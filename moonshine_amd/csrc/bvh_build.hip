@@ -159,6 +159,7 @@ __global__ __launch_bounds__(256) void k_radix_hist(const uint32_t* keys, uint32
     __syncthreads();
     ghist[threadIdx.x * ntiles + blockIdx.x] = h[threadIdx.x];
 }
+// exclusive scan of `total` counters in place by ONE workgroup (small inputs: PLOC block sums, group sizes)
 __global__ __launch_bounds__(1024) void k_radix_scan(uint32_t* ghist, uint32_t total) {
     __shared__ uint32_t s_wave[17];
     const uint32_t per = (total + 1023u) / 1024u;
@@ -169,11 +170,41 @@ __global__ __launch_bounds__(1024) void k_radix_scan(uint32_t* ghist, uint32_t t
     uint32_t run = block_scan_1024(s, s_wave, all);
     for (uint32_t i = a; i < b; i++) { uint32_t v = ghist[i]; ghist[i] = run; run += v; }
 }
+// the sort's histogram (digit-major: ghist[digit * ntiles + tile]) scanned by one workgroup PER DIGIT: exclusive prefix over the digit's tiles in place, the digit's
+// total to digit_total[digit]; k_radix_scatter adds the totals of the smaller digits itself (a single workgroup over all 256 x ntiles counters took 190 us per pass
+// for a million keys — more than histogram and scatter together)
+__global__ __launch_bounds__(256) void k_radix_scan_digit(uint32_t* ghist, uint32_t ntiles, uint32_t* digit_total) {
+    __shared__ uint32_t s_w[4];
+    uint32_t* h = ghist + (size_t)blockIdx.x * ntiles;
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    uint32_t carry = 0;
+    for (uint32_t base = 0; base < ntiles; base += 256u) {
+        const uint32_t i = base + threadIdx.x;
+        const uint32_t v = i < ntiles ? h[i] : 0u;
+        uint32_t inc = v;
+        for (int o = 1; o < 64; o <<= 1) { const uint32_t t = __shfl_up(inc, o); if (lane >= (uint32_t)o) inc += t; }
+        __syncthreads();
+        if (lane == 63u) s_w[wave] = inc;
+        __syncthreads();
+        uint32_t before = 0, all = 0;
+        for (uint32_t w = 0; w < 4u; w++) { if (w < wave) before += s_w[w]; all += s_w[w]; }
+        if (i < ntiles) h[i] = carry + before + inc - v;
+        carry += all;
+    }
+    if (threadIdx.x == 0) digit_total[blockIdx.x] = carry;
+}
 // one wave per tile, elements scattered in order → stable
 __global__ __launch_bounds__(64) void k_radix_scatter(const uint32_t* keys, const uint32_t* vals, uint32_t n, int shift,
-                                                       const uint32_t* ghist, uint32_t ntiles, uint32_t* okeys, uint32_t* ovals) {
+                                                       const uint32_t* ghist, const uint32_t* digit_total, uint32_t ntiles, uint32_t* okeys, uint32_t* ovals) {
     __shared__ uint32_t base[256];
-    for (int j = threadIdx.x; j < 256; j += 64) base[j] = ghist[j * ntiles + blockIdx.x];
+    {   // first output position of every digit in this tile: keys with smaller digits anywhere + keys with this digit in the tiles before
+        uint32_t tot[4], run = 0;
+        for (int q = 0; q < 4; q++) { tot[q] = digit_total[threadIdx.x * 4 + q]; run += tot[q]; }
+        uint32_t inc = run;
+        for (int o = 1; o < 64; o <<= 1) { const uint32_t t = __shfl_up(inc, o); if (threadIdx.x >= (uint32_t)o) inc += t; }
+        uint32_t ex = inc - run;
+        for (int q = 0; q < 4; q++) { const int j = threadIdx.x * 4 + q; base[j] = ex + ghist[(size_t)j * ntiles + blockIdx.x]; ex += tot[q]; }
+    }
     __syncthreads();
     const uint32_t lane = threadIdx.x;
     const unsigned long long lt = lane == 0 ? 0ull : (~0ull >> (64 - lane));
@@ -496,6 +527,10 @@ __global__ void k_top_gather(const uint32_t* cref, const Box* cbox, uint32_t c, 
     out[i] = o;
 }
 
+}  // namespace msne
+#include "bvh_sweep.h"
+namespace msne {
+
 struct BuildScratch {
     uint32_t cap = 0;
     Box *boxes = nullptr, *sorted = nullptr, *ibox = nullptr;
@@ -507,7 +542,10 @@ struct BuildScratch {
     uint32_t *cra = nullptr, *crb = nullptr, *nn = nullptr, *pflags = nullptr, *bsum = nullptr; PlocState* totals = nullptr;
     uint2* bbase = nullptr;
     uint32_t *seg = nullptr, *csa = nullptr, *csb = nullptr;                   // batched builds: segment of every primitive / cluster (ping-pong)
+    void* arena = nullptr; size_t arena_bytes = 0;                             // the top-down stages' working set (bvh_sweep.h), kept between builds
     void release() {
+        if (arena) (void)hipFree(arena);
+        arena = nullptr; arena_bytes = 0;
         void* p[] = { boxes, sorted, ibox, keys, keys2, idx, idx2, ghist, bounds, left, right, count, cost, split, wa, wb, next_count,
                       cba, cbb, cra, crb, nn, pflags, bsum, totals, bbase, seg, csa, csb };
         for (void* q : p) if (q) (void)hipFree(q);
@@ -520,7 +558,7 @@ struct BuildScratch {
         const uint32_t ntiles = (n + RS_TILE - 1) / RS_TILE;
         HIPCHK(hipMalloc(&boxes, N * sizeof(Box))); HIPCHK(hipMalloc(&sorted, N * sizeof(Box))); HIPCHK(hipMalloc(&ibox, N * sizeof(Box)));
         HIPCHK(hipMalloc(&keys, N * 4)); HIPCHK(hipMalloc(&keys2, N * 4)); HIPCHK(hipMalloc(&idx, N * 4)); HIPCHK(hipMalloc(&idx2, N * 4));
-        HIPCHK(hipMalloc(&ghist, (size_t)ntiles * 256 * 4)); HIPCHK(hipMalloc(&bounds, 6 * 4));
+        HIPCHK(hipMalloc(&ghist, ((size_t)ntiles + 1) * 256 * 4)); HIPCHK(hipMalloc(&bounds, 6 * 4));
         HIPCHK(hipMalloc(&left, N * 4)); HIPCHK(hipMalloc(&right, N * 4)); HIPCHK(hipMalloc(&count, N * 4)); HIPCHK(hipMalloc(&cost, N * 28)); HIPCHK(hipMalloc(&split, N * 8));
         HIPCHK(hipMalloc(&wa, N * sizeof(CollapseWork))); HIPCHK(hipMalloc(&wb, N * sizeof(CollapseWork)));
         HIPCHK(hipMalloc(&next_count, 4));
@@ -549,6 +587,207 @@ static uint32_t top_clusters(uint32_t n, uint32_t nseg) {
     if (m < 2 || nseg > m / 2) return 0;
     (void)n;
     return m;
+}
+
+// ---- the top-down stages, sequentially on the host: the restatement the GPU stages are compared with ($MSNE_TOPDOWN=host; tests only) ----
+static bool sweep_on_host(BuildScratch& S, hipStream_t s, uint32_t n, uint32_t nseg, uint32_t c, uint32_t node_base, const uint32_t* ra, const Box* ba, const uint32_t* sa,
+                          BinTree t, bool rebuild_wanted, uint32_t* root_refs, Box* root_boxes) {
+    const bool segmented = nseg > 1;
+    TopCluster* dtop = nullptr;
+    HIPCHK(hipMalloc(&dtop, (size_t)c * sizeof(TopCluster)));
+    struct FreeTop { TopCluster* p; ~FreeTop() { (void)hipFree(p); } } free_top{ dtop };
+    hipLaunchKernelGGL(k_top_gather, dim3((c + 255) / 256), dim3(256), 0, s, ra, ba, c, t, dtop);
+    std::vector<TopCluster> cl(c); std::vector<uint32_t> cseg_h(segmented ? c : 0u);
+    HIPCHK(hipMemcpyAsync(cl.data(), dtop, (size_t)c * sizeof(TopCluster), hipMemcpyDeviceToHost, s));
+    if (segmented) HIPCHK(hipMemcpyAsync(cseg_h.data(), sa, (size_t)c * 4, hipMemcpyDeviceToHost, s));
+    const uint32_t total = node_base + (c - nseg);   // binary nodes when all is done
+    if (total > n) { fprintf(stderr, "moonshine_amd: binary node count out of range\n"); return false; }
+    HostTree T;
+    T.alloc(total);
+    const bool rebuild_bottom = rebuild_wanted && node_base;
+    RawArray<Box> prim_box;
+    if (rebuild_bottom) {
+        prim_box.alloc(n);
+        HIPCHK(hipMemcpyAsync(T.left.data(), t.left, (size_t)node_base * 4, hipMemcpyDeviceToHost, s));
+        HIPCHK(hipMemcpyAsync(T.right.data(), t.right, (size_t)node_base * 4, hipMemcpyDeviceToHost, s));
+        HIPCHK(hipMemcpyAsync(prim_box.data(), S.sorted, (size_t)n * sizeof(Box), hipMemcpyDeviceToHost, s));
+    }
+    HIPCHK(hipStreamSynchronize(s));
+    if (rebuild_bottom) {
+        // every PLOC cluster is rebuilt top-down over its own primitives (in primitive order), in the node ids it had
+        std::atomic<bool> failed{ false };
+        msne_host::parallel_for(c, [&](uint32_t i) { try {
+            TopCluster& k = cl[i];
+            if (k.ref & REF_LEAF) return;
+            std::vector<uint32_t> ids, prims, stack{ k.ref }; std::vector<TopCluster> el;
+            ids.reserve(k.count); prims.reserve(k.count); el.reserve(k.count);
+            while (!stack.empty()) {
+                const uint32_t r = stack.back(); stack.pop_back();
+                if (r & REF_LEAF) prims.push_back(r & ~REF_LEAF);
+                else { ids.push_back(r); stack.push_back(T.right[r]); stack.push_back(T.left[r]); }
+            }
+            std::sort(ids.begin(), ids.end()); std::sort(prims.begin(), prims.end());
+            for (uint32_t pr : prims) { TopCluster e; e.ref = REF_LEAF | pr; e.box = prim_box[pr]; for (int q = 0; q < 7; q++) e.cost[q] = 0.0f; e.count = 1u; el.push_back(e); }
+            TopDown td(T, ids.data());
+            const TopDown::Sub r = td.run(el.data(), (uint32_t)el.size());
+            k.ref = r.ref; k.box = r.box; for (int q = 0; q < 7; q++) k.cost[q] = r.cost[q];
+        } catch (const std::exception&) { failed = true; } });
+        if (failed) { fprintf(stderr, "moonshine_amd: out of host memory in the BVH builder\n"); return false; }
+    }
+    std::vector<uint32_t> top_ids(c - nseg);
+    for (uint32_t i = 0; i < c - nseg; i++) top_ids[i] = node_base + i;
+    TopDown top(T, top_ids.data());
+    for (uint32_t a = 0, j = 0; a < c; j++) {   // the clusters of a segment are contiguous
+        uint32_t b = a + 1;
+        while (segmented && b < c && cseg_h[b] == cseg_h[a]) b++;
+        if (!segmented) b = c;
+        if (j >= nseg || (segmented && cseg_h[a] != j)) { fprintf(stderr, "moonshine_amd: builder lost a segment\n"); return false; }
+        const TopDown::Sub r = top.run(cl.data() + a, b - a);
+        root_refs[j] = r.ref; root_boxes[j] = r.box;
+        a = b;
+    }
+    const uint32_t first = rebuild_bottom ? 0u : node_base, made = total - first;   // the range of ids the host wrote
+    if (made) {
+        HIPCHK(hipMemcpyAsync(t.left + first, T.left.data() + first, (size_t)made * 4, hipMemcpyHostToDevice, s));
+        HIPCHK(hipMemcpyAsync(t.right + first, T.right.data() + first, (size_t)made * 4, hipMemcpyHostToDevice, s));
+        HIPCHK(hipMemcpyAsync(t.box + first, T.box.data() + first, (size_t)made * sizeof(Box), hipMemcpyHostToDevice, s));
+        HIPCHK(hipMemcpyAsync(t.cost + 7 * (size_t)first, T.cost.data() + 7 * (size_t)first, (size_t)made * 28, hipMemcpyHostToDevice, s));
+        HIPCHK(hipMemcpyAsync(t.split + 8 * (size_t)first, T.split.data() + 8 * (size_t)first, (size_t)made * 8, hipMemcpyHostToDevice, s));
+        HIPCHK(hipStreamSynchronize(s));   // (pageable host vectors about to go out of scope)
+    }
+    return true;
+}
+
+// ---- the top-down stages on the GPU (kernels: bvh_sweep.h) ----
+// stable LSD radix sort of (key, value) pairs on the low `bits` bits, 8 per pass; the sorted pairs end in (ka, va) — the arrays are swapped as the passes go
+static void sweep_radix(hipStream_t s, uint32_t*& ka, uint32_t*& kb, uint32_t*& va, uint32_t*& vb, uint32_t n, int bits, uint32_t* ghist) {
+    const uint32_t ntiles = (n + RS_TILE - 1) / RS_TILE;
+    for (int shift = 0; shift < bits; shift += 8) {
+        hipLaunchKernelGGL(k_radix_hist, dim3(ntiles), dim3(256), 0, s, ka, n, shift, ghist, ntiles);
+        hipLaunchKernelGGL(k_radix_scan_digit, dim3(256), dim3(256), 0, s, ghist, ntiles, ghist + (size_t)ntiles * 256u);
+        hipLaunchKernelGGL(k_radix_scatter, dim3(ntiles), dim3(64), 0, s, ka, va, n, shift, ghist, ghist + (size_t)ntiles * 256u, ntiles, kb, vb);
+        std::swap(ka, kb); std::swap(va, vb);
+    }
+}
+static int bits_for(uint32_t values) { int b = 0; while ((1ull << b) < values) b++; return b; }
+
+static bool sweep_on_gpu(BuildScratch& S, hipStream_t s, uint32_t n, uint32_t nseg, uint32_t c, uint32_t node_base, const uint32_t* ra, const Box* ba, const uint32_t* sa,
+                         BinTree t, bool rebuild_wanted, uint32_t* root_refs, Box* root_boxes) {
+    static const bool timing = getenv("MSNE_BUILD_TIMING") != nullptr;
+    auto t_prev = std::chrono::steady_clock::now();
+    double t_ms[4] = { 0, 0, 0, 0 };   // ownership + element sort, levels, bottom-up, roots
+    auto lap = [&](int k) { if (!timing) return; (void)hipStreamSynchronize(s); const auto now = std::chrono::steady_clock::now(); t_ms[k] += std::chrono::duration<double, std::milli>(now - t_prev).count(); t_prev = now; };
+    const bool segmented = nseg > 1;
+    const bool rebuild_bottom = rebuild_wanted && node_base;
+    const uint32_t P0 = rebuild_bottom ? n : 0u, ngc = rebuild_bottom ? c : 0u, N = P0 + c, G = ngc + nseg;
+    if ((uint64_t)n + c >= 0x7fffff00ull) { fprintf(stderr, "moonshine_amd: too many primitives for the top-down stages\n"); return false; }
+    const uint32_t ntile = (N + SW_TILE - 1) / SW_TILE;
+    const uint32_t nsort = std::max(N, std::max(P0, node_base));
+    // one arena, carved
+    size_t off = 0;
+    auto carve = [&](size_t bytes) { const size_t at = off; off += (bytes + 255) & ~(size_t)255; return at; };
+    const size_t o_ebox = carve((size_t)N * sizeof(Box)), o_ecnt = carve((size_t)N * 4), o_eref = carve((size_t)N * 4), o_egrp = carve((size_t)N * 4);
+    size_t o_ord[2][3], o_segA[2], o_segB[2], o_segR[2], o_best[2], o_act[2], o_vf[3], o_vb[3], o_cf[3], o_list[2];
+    for (int h = 0; h < 2; h++) { for (int k = 0; k < 3; k++) o_ord[h][k] = carve((size_t)N * 4); o_segA[h] = carve((size_t)N * 4); o_segB[h] = carve((size_t)N * 4); o_segR[h] = carve((size_t)N * 4); o_best[h] = carve((size_t)N * 8); o_act[h] = carve(ntile); }
+    for (int k = 0; k < 3; k++) { o_vf[k] = carve((size_t)ntile * sizeof(SwAgg)); o_vb[k] = carve((size_t)ntile * sizeof(SwAgg)); o_cf[k] = carve((size_t)ntile * 4); }
+    const size_t o_right = carve(N);
+    o_list[0] = carve((size_t)std::max(P0, 1u) * 4); o_list[1] = carve((size_t)c * 4);
+    const size_t o_counts = carve(2 * 4), o_lfirst = carve((size_t)2 * (SW_MAX_LEVELS + 1) * 4), o_cid = carve((size_t)std::max(node_base, 1u) * 4);
+    const size_t o_ka = carve((size_t)nsort * 4), o_kb = carve((size_t)nsort * 4), o_va = carve((size_t)nsort * 4), o_vb2 = carve((size_t)nsort * 4);
+    const size_t o_ghist = carve(((size_t)((nsort + RS_TILE - 1) / RS_TILE) + 1) * 256 * 4);
+    const size_t o_lc = carve((size_t)std::max(P0, 1u) * 4), o_pl = carve((size_t)std::max(P0, 1u) * 4), o_nc = carve((size_t)std::max(node_base, 1u) * 4), o_pn = carve((size_t)std::max(node_base, 1u) * 4), o_no = carve((size_t)std::max(node_base, 1u) * 4);
+    const size_t o_psort = carve((size_t)std::max(P0, 1u) * 4), o_pgrp = carve((size_t)std::max(P0, 1u) * 4);
+    const size_t o_gsize = carve(((size_t)G + 1) * 4), o_rref = carve((size_t)nseg * 4), o_rbox = carve((size_t)nseg * sizeof(Box));
+    if (off > S.arena_bytes) {
+        if (S.arena) (void)hipFree(S.arena);
+        S.arena = nullptr; S.arena_bytes = 0;
+        HIPCHK(hipMalloc(&S.arena, off));
+        S.arena_bytes = off;
+    }
+    char* A = (char*)S.arena;
+    auto U32 = [&](size_t o) { return (uint32_t*)(A + o); };
+    SwState St{};
+    St.N = N; St.P0 = P0; St.ngc = ngc; St.node_base = node_base; St.ntile = ntile;
+    Box* ebox = (Box*)(A + o_ebox); uint32_t *ecnt = U32(o_ecnt), *eref = U32(o_eref), *egrp = U32(o_egrp);
+    St.ebox = ebox; St.ecnt = ecnt; St.eref = eref; St.egrp = egrp; St.cid = U32(o_cid);
+    for (int h = 0; h < 2; h++) { for (int k = 0; k < 3; k++) St.ord[h][k] = U32(o_ord[h][k]); St.segA[h] = U32(o_segA[h]); St.segB[h] = U32(o_segB[h]); St.segR[h] = U32(o_segR[h]); St.best[h] = (unsigned long long*)(A + o_best[h]); St.tile_act[h] = (uint8_t*)(A + o_act[h]); }
+    for (int k = 0; k < 3; k++) { St.vf[k] = (SwAgg*)(A + o_vf[k]); St.vb[k] = (SwAgg*)(A + o_vb[k]); St.cf[k] = U32(o_cf[k]); }
+    St.right_side = (uint8_t*)(A + o_right); St.list[0] = U32(o_list[0]); St.list[1] = U32(o_list[1]); St.list_count = U32(o_counts); St.level_first = U32(o_lfirst);
+    uint32_t *ka = U32(o_ka), *kb = U32(o_kb), *va = U32(o_va), *vb = U32(o_vb2), *ghist = U32(o_ghist), *gsize = U32(o_gsize);
+    auto grid = [](uint32_t m) { return dim3((m + 255) / 256); };
+
+    // 1. which cluster owns which primitive / PLOC node; primitives and node ids grouped by cluster (stable: ascending inside)
+    uint32_t *prim_sorted = U32(o_psort), *prim_group = U32(o_pgrp);
+    if (rebuild_bottom) {
+        uint32_t *leaf_cluster = U32(o_lc), *parent_leaf = U32(o_pl), *node_cluster = U32(o_nc), *parent_node = U32(o_pn), *node_owner = U32(o_no);
+        HIPCHK(hipMemsetAsync(leaf_cluster, 0xFF, (size_t)n * 4, s));
+        HIPCHK(hipMemsetAsync(node_cluster, 0xFF, (size_t)node_base * 4, s));
+        hipLaunchKernelGGL(k_sw_roots, grid(c), dim3(256), 0, s, ra, c, leaf_cluster, node_cluster);
+        hipLaunchKernelGGL(k_sw_parents, grid(node_base), dim3(256), 0, s, t, node_base, parent_leaf, parent_node);
+        hipLaunchKernelGGL(k_sw_owner, grid(n + node_base), dim3(256), 0, s, n, node_base, parent_leaf, parent_node, leaf_cluster, node_cluster, node_owner);
+        const int cb = bits_for(c);
+        HIPCHK(hipMemcpyAsync(ka, leaf_cluster, (size_t)n * 4, hipMemcpyDeviceToDevice, s));
+        hipLaunchKernelGGL(k_sw_iota, grid(n), dim3(256), 0, s, n, va);
+        sweep_radix(s, ka, kb, va, vb, n, cb, ghist);
+        HIPCHK(hipMemcpyAsync(prim_group, ka, (size_t)n * 4, hipMemcpyDeviceToDevice, s));
+        HIPCHK(hipMemcpyAsync(prim_sorted, va, (size_t)n * 4, hipMemcpyDeviceToDevice, s));
+        HIPCHK(hipMemcpyAsync(ka, node_owner, (size_t)node_base * 4, hipMemcpyDeviceToDevice, s));
+        hipLaunchKernelGGL(k_sw_iota, grid(node_base), dim3(256), 0, s, node_base, va);
+        sweep_radix(s, ka, kb, va, vb, node_base, cb, ghist);
+        HIPCHK(hipMemcpyAsync(U32(o_cid), va, (size_t)node_base * 4, hipMemcpyDeviceToDevice, s));
+    }
+    // 2. elements, groups, the three orders
+    hipLaunchKernelGGL(k_sw_elements, grid(N), dim3(256), 0, s, N, P0, ngc, prim_sorted, prim_group, S.sorted, ra, ba, segmented ? sa : nullptr, t, ebox, ecnt, eref, egrp);
+    HIPCHK(hipMemsetAsync(gsize, 0, ((size_t)G + 1) * 4, s));
+    hipLaunchKernelGGL(k_sw_group_sizes, grid(c), dim3(256), 0, s, ra, segmented ? sa : nullptr, c, ngc, t, gsize);
+    hipLaunchKernelGGL(k_radix_scan, dim3(1), dim3(1024), 0, s, gsize, G + 1u);       // in place: first position of every group, gsize[G] = N
+    const int gb = G > 1 ? bits_for(G) : 0;
+    for (int axis = 0; axis < 3; axis++) {
+        hipLaunchKernelGGL(k_sw_keys, grid(N), dim3(256), 0, s, N, ebox, axis, ka, va);
+        sweep_radix(s, ka, kb, va, vb, N, 32, ghist);
+        if (gb) { hipLaunchKernelGGL(k_gather_u32, grid(N), dim3(256), 0, s, egrp, va, N, ka); sweep_radix(s, ka, kb, va, vb, N, gb, ghist); }   // stable: back into groups, sorted inside
+        HIPCHK(hipMemcpyAsync(St.ord[0][axis], va, (size_t)N * 4, hipMemcpyDeviceToDevice, s));
+    }
+    HIPCHK(hipMemsetAsync(St.list_count, 0, 8, s));
+    hipLaunchKernelGGL(k_sw_init, dim3(ntile), dim3(SW_TILE), 0, s, St, gsize);
+    lap(0);
+    // 3. one tree level per pass, every build at once
+    const uint32_t want[2] = { rebuild_bottom ? n - c : 0u, c - nseg };
+    std::vector<uint32_t> lfirst((size_t)2 * (SW_MAX_LEVELS + 1));
+    uint32_t made[2] = { 0, 0 }, level = 0;
+    int cur = 0;
+    for (;;) {
+        for (uint32_t g = 0; g < 4u && level < SW_MAX_LEVELS; g++, level++) {
+            hipLaunchKernelGGL(k_sw_agg, dim3(ntile, 3), dim3(SW_TILE), 0, s, St, cur, level);
+            if (level < MAX_SWEEP_DEPTH) hipLaunchKernelGGL(k_sw_cost, dim3(ntile, 3), dim3(SW_TILE), 0, s, St, cur);
+            hipLaunchKernelGGL(k_sw_split, dim3(ntile), dim3(SW_TILE), 0, s, St, cur, t);
+            hipLaunchKernelGGL(k_sw_pagg, dim3(ntile, 3), dim3(SW_TILE), 0, s, St, cur);
+            hipLaunchKernelGGL(k_sw_part, dim3(ntile, 3), dim3(SW_TILE), 0, s, St, cur, t);
+            cur ^= 1;
+        }
+        HIPCHK(hipMemcpyAsync(made, St.list_count, 8, hipMemcpyDeviceToHost, s));
+        HIPCHK(hipStreamSynchronize(s));
+        if (made[0] == want[0] && made[1] == want[1]) break;
+        if (made[0] > want[0] || made[1] > want[1] || level >= SW_MAX_LEVELS) { fprintf(stderr, "moonshine_amd: the top-down stages lost count of their nodes (%u / %u, %u / %u after %u levels)\n", made[0], want[0], made[1], want[1], level); return false; }
+    }
+    HIPCHK(hipMemcpyAsync(lfirst.data(), St.level_first, lfirst.size() * 4, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    lap(1);
+    // 4. boxes and collapse tables, deepest level first; the cluster trees, then the top trees over them
+    for (uint32_t kind = 0; kind < 2; kind++)
+        for (uint32_t L = level; L-- > 0;) {
+            const uint32_t from = lfirst[(size_t)kind * (SW_MAX_LEVELS + 1) + L], to = L + 1 < level ? lfirst[(size_t)kind * (SW_MAX_LEVELS + 1) + L + 1] : made[kind];
+            if (to > from) hipLaunchKernelGGL(k_sw_up, grid(to - from), dim3(256), 0, s, St.list[kind] + from, to - from, t, S.sorted);
+        }
+    lap(2);
+    hipLaunchKernelGGL(k_sw_tree_roots, grid(nseg), dim3(256), 0, s, St, gsize, nseg, t, U32(o_rref), (Box*)(A + o_rbox));
+    HIPCHK(hipMemcpyAsync(root_refs, A + o_rref, (size_t)nseg * 4, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipMemcpyAsync(root_boxes, A + o_rbox, (size_t)nseg * sizeof(Box), hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    lap(3);
+    if (timing && n >= 4096u) fprintf(stderr, "moonshine_amd builder: %u primitives in %u trees, %u clusters swept top-down on the GPU over %u levels: ownership + sorts %.2f ms, levels %.2f ms, tables %.2f ms, roots %.2f ms\n",
+                                      n, nseg, c, level, t_ms[0], t_ms[1], t_ms[2], t_ms[3]);
+    return true;
 }
 
 // Builds `nseg` wide BVHs over the n boxes in S.boxes — segment j = boxes [seg_first[j], seg_first[j + 1]), none empty; nseg == 1: one tree over
@@ -584,8 +823,8 @@ static bool build_from_boxes(BuildScratch& S, hipStream_t s, uint32_t n, uint32_
     uint32_t *ka = S.keys, *kb = S.keys2, *va = S.idx, *vb = S.idx2;
     auto radix_pass = [&](int shift) {
         hipLaunchKernelGGL(k_radix_hist, dim3(ntiles), dim3(256), 0, s, ka, n, shift, S.ghist, ntiles);
-        hipLaunchKernelGGL(k_radix_scan, dim3(1), dim3(1024), 0, s, S.ghist, ntiles * 256u);
-        hipLaunchKernelGGL(k_radix_scatter, dim3(ntiles), dim3(64), 0, s, ka, va, n, shift, S.ghist, ntiles, kb, vb);
+        hipLaunchKernelGGL(k_radix_scan_digit, dim3(256), dim3(256), 0, s, S.ghist, ntiles, S.ghist + (size_t)ntiles * 256u);
+        hipLaunchKernelGGL(k_radix_scatter, dim3(ntiles), dim3(64), 0, s, ka, va, n, shift, S.ghist, S.ghist + (size_t)ntiles * 256u, ntiles, kb, vb);
         std::swap(ka, kb); std::swap(va, vb);
     };
     for (int pass = 0; pass < 4; pass++) radix_pass(pass * 8);                       // low word
@@ -637,80 +876,12 @@ static bool build_from_boxes(BuildScratch& S, hipStream_t s, uint32_t n, uint32_
             c = now.c; node_base = now.node_base;
         }
         phase(1);
-        if (c > nseg) {   // the rest top-down on the host
-            static const bool timing = getenv("MSNE_BUILD_TIMING") != nullptr;
-            auto t_prev = std::chrono::steady_clock::now();
-            double t_ms[4] = { 0, 0, 0, 0 };   // fetch, cluster rebuilds, top tree, upload
-            auto lap = [&](int k) { const auto now = std::chrono::steady_clock::now(); t_ms[k] += std::chrono::duration<double, std::milli>(now - t_prev).count(); t_prev = now; };
-            TopCluster* dtop = nullptr;
-            HIPCHK(hipMalloc(&dtop, (size_t)c * sizeof(TopCluster)));
-            struct FreeTop { TopCluster* p; ~FreeTop() { (void)hipFree(p); } } free_top{ dtop };
-            hipLaunchKernelGGL(k_top_gather, dim3((c + 255) / 256), dim3(256), 0, s, ra, ba, c, t, dtop);
-            std::vector<TopCluster> cl(c); std::vector<uint32_t> cseg_h(segmented ? c : 0u);
-            HIPCHK(hipMemcpyAsync(cl.data(), dtop, (size_t)c * sizeof(TopCluster), hipMemcpyDeviceToHost, s));
-            if (segmented) HIPCHK(hipMemcpyAsync(cseg_h.data(), sa, (size_t)c * 4, hipMemcpyDeviceToHost, s));
-            const uint32_t total = node_base + (c - nseg);   // binary nodes when all is done
-            if (total > n) { fprintf(stderr, "moonshine_amd: binary node count out of range\n"); return false; }
-            HostTree T;
-            T.alloc(total);
-            // (the cluster rebuilds keep 100 B of host memory per primitive for their duration: beyond 48 M primitives only the top tree is made here)
+        if (c > nseg) {   // the rest top-down: a surface-area sweep over every cluster's primitives and over the clusters themselves (bvh_sweep.h)
             static const bool rebuild_wanted = [] { const char* e = getenv("MSNE_SAH_BOTTOM"); return e ? atoi(e) != 0 : true; }();
-            const bool rebuild_bottom = rebuild_wanted && n <= (48u << 20);
-            RawArray<Box> prim_box;
-            if (rebuild_bottom && node_base) {
-                prim_box.alloc(n);
-                HIPCHK(hipMemcpyAsync(T.left.data(), t.left, (size_t)node_base * 4, hipMemcpyDeviceToHost, s));
-                HIPCHK(hipMemcpyAsync(T.right.data(), t.right, (size_t)node_base * 4, hipMemcpyDeviceToHost, s));
-                HIPCHK(hipMemcpyAsync(prim_box.data(), S.sorted, (size_t)n * sizeof(Box), hipMemcpyDeviceToHost, s));
-            }
-            HIPCHK(hipStreamSynchronize(s));
-            lap(0);
-            if (rebuild_bottom && node_base) {
-                // every PLOC cluster is rebuilt top-down over its own primitives, in the node ids it had
-                std::atomic<bool> failed{ false };
-                msne_host::parallel_for(c, [&](uint32_t i) { try {
-                    TopCluster& k = cl[i];
-                    if (k.ref & REF_LEAF) return;
-                    std::vector<uint32_t> ids, stack{ k.ref }; std::vector<TopCluster> el;
-                    ids.reserve(k.count); el.reserve(k.count);
-                    while (!stack.empty()) {
-                        const uint32_t r = stack.back(); stack.pop_back();
-                        if (r & REF_LEAF) { TopCluster e; e.ref = r; e.box = prim_box[r & ~REF_LEAF]; for (int q = 0; q < 7; q++) e.cost[q] = 0.0f; e.count = 1u; el.push_back(e); }
-                        else { ids.push_back(r); stack.push_back(T.right[r]); stack.push_back(T.left[r]); }
-                    }
-                    std::sort(ids.begin(), ids.end());
-                    TopDown td(T, ids.data());
-                    const TopDown::Sub r = td.run(el.data(), (uint32_t)el.size());
-                    k.ref = r.ref; k.box = r.box; for (int q = 0; q < 7; q++) k.cost[q] = r.cost[q];
-                } catch (const std::exception&) { failed = true; } });
-                if (failed) { fprintf(stderr, "moonshine_amd: out of host memory in the BVH builder\n"); return false; }
-            }
-            lap(1);
-            std::vector<uint32_t> top_ids(c - nseg);
-            for (uint32_t i = 0; i < c - nseg; i++) top_ids[i] = node_base + i;
-            TopDown top(T, top_ids.data());
-            for (uint32_t a = 0, j = 0; a < c; j++) {   // the clusters of a segment are contiguous
-                uint32_t b = a + 1;
-                while (segmented && b < c && cseg_h[b] == cseg_h[a]) b++;
-                if (!segmented) b = c;
-                if (j >= nseg || (segmented && cseg_h[a] != j)) { fprintf(stderr, "moonshine_amd: builder lost a segment\n"); return false; }
-                const TopDown::Sub r = top.run(cl.data() + a, b - a);
-                root_refs[j] = r.ref; root_boxes[j] = r.box;
-                a = b;
-            }
-            lap(2);
-            const uint32_t first = (rebuild_bottom && node_base) ? 0u : node_base, made = total - first;   // the range of ids the host wrote
-            if (made) {
-                HIPCHK(hipMemcpyAsync(t.left + first, T.left.data() + first, (size_t)made * 4, hipMemcpyHostToDevice, s));
-                HIPCHK(hipMemcpyAsync(t.right + first, T.right.data() + first, (size_t)made * 4, hipMemcpyHostToDevice, s));
-                HIPCHK(hipMemcpyAsync(t.box + first, T.box.data() + first, (size_t)made * sizeof(Box), hipMemcpyHostToDevice, s));
-                HIPCHK(hipMemcpyAsync(t.cost + 7 * (size_t)first, T.cost.data() + 7 * (size_t)first, (size_t)made * 28, hipMemcpyHostToDevice, s));
-                HIPCHK(hipMemcpyAsync(t.split + 8 * (size_t)first, T.split.data() + 8 * (size_t)first, (size_t)made * 8, hipMemcpyHostToDevice, s));
-                HIPCHK(hipStreamSynchronize(s));   // (pageable host vectors about to go out of scope)
-            }
-            lap(3);
-            if (timing && n >= 4096u) fprintf(stderr, "moonshine_amd builder: %u primitives in %u trees, %u clusters to the host: fetch %.2f ms, cluster rebuilds %.2f ms, top tree %.2f ms, upload %.2f ms\n",
-                                              n, nseg, c, t_ms[0], t_ms[1], t_ms[2], t_ms[3]);
+            const char* where = getenv("MSNE_TOPDOWN");                        // "host": the sequential restatement (tests); read at every build
+            const bool on_host = where && strcmp(where, "host") == 0;
+            if (on_host) { if (!sweep_on_host(S, s, n, nseg, c, node_base, ra, ba, sa, t, rebuild_wanted, root_refs.data(), root_boxes)) return false; }
+            else if (!sweep_on_gpu(S, s, n, nseg, c, node_base, ra, ba, sa, t, rebuild_wanted, root_refs.data(), root_boxes)) return false;
         } else {
             HIPCHK(hipMemcpyAsync(root_refs.data(), ra, (size_t)nseg * 4, hipMemcpyDeviceToHost, s));
             HIPCHK(hipMemcpyAsync(root_boxes, ba, (size_t)nseg * sizeof(Box), hipMemcpyDeviceToHost, s));
@@ -743,7 +914,7 @@ static bool build_from_boxes(BuildScratch& S, hipStream_t s, uint32_t n, uint32_
         std::swap(cur, nxt);
     }
     phase(3);
-    if (phase_timing && n >= 4096u) fprintf(stderr, "moonshine_amd builder: %u primitives: sort %.2f ms, PLOC %.2f ms, host stages %.2f ms, collapse %.2f ms\n", n, ph_ms[0], ph_ms[1], ph_ms[2], ph_ms[3]);
+    if (phase_timing && n >= 4096u) fprintf(stderr, "moonshine_amd builder: %u primitives: sort %.2f ms, PLOC %.2f ms, top-down stages %.2f ms, collapse %.2f ms\n", n, ph_ms[0], ph_ms[1], ph_ms[2], ph_ms[3]);
     return true;
 } catch (const std::exception& e) {   // (host vectors of the top-down stages)
     fprintf(stderr, "moonshine_amd: BVH build failed on the host: %s\n", e.what());

@@ -967,6 +967,98 @@ def test_builder_stages(tmp_path, top):
     assert out.returncode == 0 and "SPILL_OK" in out.stdout, out.stdout[-1500:] + out.stderr[-3000:]
 
 
+SWEEP_WORKER = r"""
+import hashlib, os, sys
+sys.path.insert(0, sys.argv[1])
+import numpy as np
+from moonshine_amd import api, scenes
+
+def tree_hashes(c):
+    # every wide node as a hash of what the traversal sees of it — grid, masks, child planes, its leaf items' records and, in slot order, its children's hashes — i.e.
+    # of its whole subtree whatever the node numbering (k_collapse hands node indices out with atomics).  Children are allocated after their parents: descending order.
+    nodes, tris, root, items = c.read_bvh()
+    h = [None] * len(nodes)
+    pc = lambda x: bin(int(x)).count("1")
+    tlas = np.zeros(len(nodes), bool)               # nodes of the TLAS (their leaves index the instance list): reachable from the root when there is an instance list
+    if len(items) and root < len(nodes):
+        stack = [root]
+        while stack:
+            i = stack.pop(); tlas[i] = True
+            cb = int(nodes[i][16:20].view(np.uint32)[0])
+            stack += [cb + k for k in range(pc(nodes[i][15]))]
+    for i in range(len(nodes) - 1, -1, -1):
+        nd = nodes[i]
+        cb, ib = int(nd[16:20].view(np.uint32)[0]), int(nd[20:24].view(np.uint32)[0])
+        m = hashlib.sha1(nd[0:16].tobytes() + nd[24:25].tobytes() + nd[32:80].tobytes())
+        for k in range(pc(nd[15])):
+            m.update(h[cb + k])
+        for k in range(pc(nd[24])):
+            m.update(items[ib + k].tobytes() if tlas[i] else tris[ib + k].tobytes())
+        h[i] = m.digest()
+    return sorted(h), len(nodes)
+
+def many_meshes(c, extent):
+    rs = np.random.default_rng(4)
+    mat = c.create_material(scenes.LAMBERT, c.solid_texture(0.5, 0.5), c.solid_texture(0, 0, 0), color=c.solid_texture(0.7, 0.7, 0.7))
+    for k in range(40):
+        P, I = scenes.icosphere(k % 4 + 1); P = (P * rs.uniform(0.3, 0.6, (1, 3))).astype(np.float32)
+        if k % 9 == 4: P[5] = np.nan                                                                                  # NaN vertices: empty boxes in the sweep
+        T = np.zeros((3, 4), np.float32); T[:, :3] = np.eye(3) if k % 3 == 0 else scenes._rot((rs.normal(), rs.normal(), rs.normal() + 1e-3), rs.uniform(0, 6.28)) * rs.uniform(0.6, 1.2)
+        T[:, 3] = (1.5 * (k % 5), 1.5 * ((k // 5) % 5), 1.5 * (k // 25))
+        c.create_instance([(c.create_mesh(P, I), mat, False)], transform=T)
+    c.set_background(np.ones((1, 1, 4), np.float32), 1, 1)
+    return c.create_sensor(*extent), c.create_lens(c.make_lens((3, 3, 12), (0, 0, -1), (0, 1, 0), 0.8))
+
+def pile(c, extent):
+    tri = np.array([[-1, -1, 0], [1, -1, 0], [0, 1, 0]], np.float32)
+    mat = c.create_material(scenes.LAMBERT, c.solid_texture(0.5, 0.5), c.solid_texture(0, 0, 0), color=c.solid_texture(0.7, 0.7, 0.7))
+    c.create_instance([(c.create_mesh(tri, np.tile(np.array([[0, 1, 2]], np.uint32), (6000, 1))), mat, False)])
+    k = np.arange(3000); size = (0.97 ** k).astype(np.float32)[:, None, None]
+    pos = np.cumsum(np.concatenate([[0.0], (0.97 ** k[:-1]) * 1.2])).astype(np.float32)
+    chain = (tri[None] * size * 0.5 + np.stack([pos + 3.0, np.zeros(3000, np.float32), np.zeros(3000, np.float32)], 1)[:, None, :]).reshape(-1, 3).astype(np.float32)
+    c.create_instance([(c.create_mesh(chain, np.arange(9000, dtype=np.uint32).reshape(-1, 3)), mat, False)])
+    c.set_background(np.ones((1, 1, 4), np.float32), 1, 1)
+    return c.create_sensor(*extent), c.create_lens(c.make_lens((0, 0, 5), (0, 0, -1), (0, 1, 0), 0.5))
+
+cases = [("s1", scenes.s1, dict(extent=(48, 27), grid=2, order=int(sys.argv[2]))), ("s2", scenes.s2, dict(extent=(48, 27), dims=(4, 4, 3), order=3)),
+         ("meshes", many_meshes, dict(extent=(48, 27))), ("pile", pile, dict(extent=(16, 16)))]
+for name, builder, kw in cases:
+    got = {}
+    for where in ("host", "gpu"):
+        os.environ["MSNE_TOPDOWN"] = where
+        c = api.Context()
+        s, l = builder(c, **kw)
+        c.set_pipeline(samples_per_run=1, max_bounces=4, env_samples_per_bounce=1, mesh_samples_per_bounce=1)
+        c.render(s, l, launches=2)
+        got[where] = (tree_hashes(c), c.sensor_data(s).copy())
+    (hh, nh), (hg, ng) = got["host"][0], got["gpu"][0]
+    assert nh == ng, "%s: %d nodes from the host stages, %d from the GPU's" % (name, nh, ng)
+    assert hh == hg, "%s: %d of %d subtrees differ" % (name, sum(a != b for a, b in zip(hh, hg)), nh)
+    assert np.array_equal(got["host"][1].view(np.uint32), got["gpu"][1].view(np.uint32)), name + ": films differ"
+    print(name, nh, "nodes equal")
+print("SWEEP_OK")
+"""
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("top,order", [("", 5), ("48", 3), ("300", 4)])
+def test_gpu_sweep_builds_the_hosts_nodes(tmp_path, top, order):
+    """the top-down surface-area stages of the BVH builder run on the GPU (csrc/bvh_sweep.h: every cluster and every top tree advance one level per pass); the
+    sequential statement of the same rules (csrc/bvh_topdown.h, $MSNE_TOPDOWN=host) must give the SAME trees: every wide node is compared by a hash of its whole
+    subtree (grid, masks, child planes, leaf records, children in slot order) through MsneReadBvh — an 82 000-triangle S1 with the default 4096 clusters, and S1 / the
+    instanced S2 / 40 distinct meshes in one batch (some with NaN vertices) / 6000 coincident triangles + a chain of shrinking ones with $MSNE_SAH_TOP = 48 and 300
+    (PLOC, cluster rebuilds and top trees in every mesh and in the TLAS)"""
+    import subprocess, sys, os
+    script = tmp_path / "sweep_worker.py"
+    script.write_text(SWEEP_WORKER)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ)
+    if top:
+        env["MSNE_SAH_TOP"] = top
+    out = subprocess.run([sys.executable, str(script), root, str(order)], capture_output=True, text=True, timeout=1500, env=env)
+    assert out.returncode == 0 and "SWEEP_OK" in out.stdout, out.stdout[-1500:] + out.stderr[-3000:]
+
+
 @pytest.mark.gpu
 def test_builder_on_piles_of_identical_boxes(orc, gpu_api):
     """what a surface-area sweep cannot split: 6000 copies of one triangle (every candidate split costs the same: the builder must halve, not peel one off per level),
