@@ -579,14 +579,17 @@ void bvh_scratch_destroy(BuildScratch* s) { if (s) { s->release(); delete s; } }
 void bvh_scratch_release(BuildScratch* s) { if (s) s->release(); }
 size_t bvh_scratch_capacity(const BuildScratch* s) { return s ? s->cap : 0; }
 
-// How many clusters PLOC leaves for the top-down stage (0: none, PLOC merges down to the roots).  $MSNE_SAH_TOP overrides.
+// How many clusters PLOC leaves for the top-down stages (0: none, PLOC merges down to the roots; >= n: no PLOC at all, ONE sweep over every primitive).  $MSNE_SAH_TOP overrides.
+// The sweep over everything makes the best trees (S1 5870 against 5770 Mrays/s with 4096 clusters and 5627 with PLOC alone, S2 3423 / 3391 / 3335, a 16 M-triangle
+// scene 3848 / 3808: profiles/r04_sah_top_sweep.txt) and on the GPU it is cheap enough to be the rule: 10 ms for a million triangles (7 with clusters), 148 ms for
+// 16 M (94) — the reference asks for prefer_fast_trace builds everywhere (Accel.zig:112,259,445,645).  Beyond 32 M primitives in one build PLOC goes first again
+// (the sweep keeps ~100 B per position).
 static uint32_t top_clusters(uint32_t n, uint32_t nseg) {
-    static const int forced = [] { const char* e = getenv("MSNE_SAH_TOP"); return e ? atoi(e) : -1; }();
-    // 4096 for one tree; a batch of trees gets ~4 clusters each, up to 32768 — beyond 16384 trees in one batch PLOC builds them whole
-    const uint32_t m = forced >= 0 ? (uint32_t)forced : std::min<uint32_t>(std::max<uint32_t>(4096u, 4u * nseg), 32768u);
-    if (m < 2 || nseg > m / 2) return 0;
-    (void)n;
-    return m;
+    static const long long forced = [] { const char* e = getenv("MSNE_SAH_TOP"); return e ? atoll(e) : -1ll; }();
+    if (forced >= 0) { const uint32_t m = (uint32_t)std::min<long long>(forced, 0x7fffffffll); return (m < 2 || nseg > m / 2) ? 0u : m; }
+    if (n <= (32u << 20)) return n;
+    const uint32_t m = std::min<uint32_t>(std::max<uint32_t>(4096u, 4u * nseg), 32768u);   // ~4 clusters per tree of a batch; beyond 16384 trees PLOC builds them whole
+    return nseg > m / 2 ? 0u : m;
 }
 
 // ---- the top-down stages, sequentially on the host: the restatement the GPU stages are compared with ($MSNE_TOPDOWN=host; tests only) ----
@@ -687,13 +690,15 @@ static bool sweep_on_gpu(BuildScratch& S, hipStream_t s, uint32_t n, uint32_t ns
     size_t off = 0;
     auto carve = [&](size_t bytes) { const size_t at = off; off += (bytes + 255) & ~(size_t)255; return at; };
     const size_t o_ebox = carve((size_t)N * sizeof(Box)), o_ecnt = carve((size_t)N * 4), o_eref = carve((size_t)N * 4), o_egrp = carve((size_t)N * 4);
-    size_t o_ord[2][3], o_segA[2], o_segB[2], o_segR[2], o_best[2], o_act[2], o_vf[3], o_vb[3], o_cf[3], o_list[2];
+    size_t o_ord[2][3], o_segA[2], o_segB[2], o_segR[2], o_best[2], o_act[2], o_vf[3], o_vb[3], o_cf[3], o_vf2[3], o_vb2[3], o_cf2[3], o_list[2];
+    const uint32_t nsuper = (ntile + SW_SUPER - 1) / SW_SUPER;
     for (int h = 0; h < 2; h++) { for (int k = 0; k < 3; k++) o_ord[h][k] = carve((size_t)N * 4); o_segA[h] = carve((size_t)N * 4); o_segB[h] = carve((size_t)N * 4); o_segR[h] = carve((size_t)N * 4); o_best[h] = carve((size_t)N * 8); o_act[h] = carve(ntile); }
-    for (int k = 0; k < 3; k++) { o_vf[k] = carve((size_t)ntile * sizeof(SwAgg)); o_vb[k] = carve((size_t)ntile * sizeof(SwAgg)); o_cf[k] = carve((size_t)ntile * 4); }
+    for (int k = 0; k < 3; k++) { o_vf[k] = carve((size_t)ntile * sizeof(SwAgg)); o_vb[k] = carve((size_t)ntile * sizeof(SwAgg)); o_cf[k] = carve((size_t)ntile * 4);
+                                  o_vf2[k] = carve((size_t)nsuper * sizeof(SwAgg)); o_vb2[k] = carve((size_t)nsuper * sizeof(SwAgg)); o_cf2[k] = carve((size_t)nsuper * 4); }
     const size_t o_right = carve(N);
     o_list[0] = carve((size_t)std::max(P0, 1u) * 4); o_list[1] = carve((size_t)c * 4);
     const size_t o_counts = carve(2 * 4), o_lfirst = carve((size_t)2 * (SW_MAX_LEVELS + 1) * 4), o_cid = carve((size_t)std::max(node_base, 1u) * 4);
-    const size_t o_ka = carve((size_t)nsort * 4), o_kb = carve((size_t)nsort * 4), o_va = carve((size_t)nsort * 4), o_vb2 = carve((size_t)nsort * 4);
+    const size_t o_ka = carve((size_t)nsort * 4), o_kb = carve((size_t)nsort * 4), o_va = carve((size_t)nsort * 4), o_vbs = carve((size_t)nsort * 4);
     const size_t o_ghist = carve(((size_t)((nsort + RS_TILE - 1) / RS_TILE) + 1) * 256 * 4);
     const size_t o_lc = carve((size_t)std::max(P0, 1u) * 4), o_pl = carve((size_t)std::max(P0, 1u) * 4), o_nc = carve((size_t)std::max(node_base, 1u) * 4), o_pn = carve((size_t)std::max(node_base, 1u) * 4), o_no = carve((size_t)std::max(node_base, 1u) * 4);
     const size_t o_psort = carve((size_t)std::max(P0, 1u) * 4), o_pgrp = carve((size_t)std::max(P0, 1u) * 4);
@@ -711,9 +716,9 @@ static bool sweep_on_gpu(BuildScratch& S, hipStream_t s, uint32_t n, uint32_t ns
     Box* ebox = (Box*)(A + o_ebox); uint32_t *ecnt = U32(o_ecnt), *eref = U32(o_eref), *egrp = U32(o_egrp);
     St.ebox = ebox; St.ecnt = ecnt; St.eref = eref; St.egrp = egrp; St.cid = U32(o_cid);
     for (int h = 0; h < 2; h++) { for (int k = 0; k < 3; k++) St.ord[h][k] = U32(o_ord[h][k]); St.segA[h] = U32(o_segA[h]); St.segB[h] = U32(o_segB[h]); St.segR[h] = U32(o_segR[h]); St.best[h] = (unsigned long long*)(A + o_best[h]); St.tile_act[h] = (uint8_t*)(A + o_act[h]); }
-    for (int k = 0; k < 3; k++) { St.vf[k] = (SwAgg*)(A + o_vf[k]); St.vb[k] = (SwAgg*)(A + o_vb[k]); St.cf[k] = U32(o_cf[k]); }
+    for (int k = 0; k < 3; k++) { St.vf[k] = (SwAgg*)(A + o_vf[k]); St.vb[k] = (SwAgg*)(A + o_vb[k]); St.cf[k] = U32(o_cf[k]); St.vf2[k] = (SwAgg*)(A + o_vf2[k]); St.vb2[k] = (SwAgg*)(A + o_vb2[k]); St.cf2[k] = U32(o_cf2[k]); }
     St.right_side = (uint8_t*)(A + o_right); St.list[0] = U32(o_list[0]); St.list[1] = U32(o_list[1]); St.list_count = U32(o_counts); St.level_first = U32(o_lfirst);
-    uint32_t *ka = U32(o_ka), *kb = U32(o_kb), *va = U32(o_va), *vb = U32(o_vb2), *ghist = U32(o_ghist), *gsize = U32(o_gsize);
+    uint32_t *ka = U32(o_ka), *kb = U32(o_kb), *va = U32(o_va), *vb = U32(o_vbs), *ghist = U32(o_ghist), *gsize = U32(o_gsize);
     auto grid = [](uint32_t m) { return dim3((m + 255) / 256); };
 
     // 1. which cluster owns which primitive / PLOC node; primitives and node ids grouped by cluster (stable: ascending inside)
@@ -738,9 +743,11 @@ static bool sweep_on_gpu(BuildScratch& S, hipStream_t s, uint32_t n, uint32_t ns
     }
     // 2. elements, groups, the three orders
     hipLaunchKernelGGL(k_sw_elements, grid(N), dim3(256), 0, s, N, P0, ngc, prim_sorted, prim_group, S.sorted, ra, ba, segmented ? sa : nullptr, t, ebox, ecnt, eref, egrp);
-    HIPCHK(hipMemsetAsync(gsize, 0, ((size_t)G + 1) * 4, s));
-    hipLaunchKernelGGL(k_sw_group_sizes, grid(c), dim3(256), 0, s, ra, segmented ? sa : nullptr, c, ngc, t, gsize);
-    hipLaunchKernelGGL(k_radix_scan, dim3(1), dim3(1024), 0, s, gsize, G + 1u);       // in place: first position of every group, gsize[G] = N
+    if (ngc) {
+        hipLaunchKernelGGL(k_sw_cluster_sizes, grid(c + 1u), dim3(256), 0, s, ra, c, t, gsize);
+        hipLaunchKernelGGL(k_radix_scan, dim3(1), dim3(1024), 0, s, gsize, ngc + 1u);   // in place: first position of every cluster's primitives, gsize[ngc] = P0
+    }
+    hipLaunchKernelGGL(k_sw_tree_first, grid(c + 1u), dim3(256), 0, s, segmented ? sa : nullptr, c, ngc, nseg, P0, gsize);   // gsize[G] = N
     const int gb = G > 1 ? bits_for(G) : 0;
     for (int axis = 0; axis < 3; axis++) {
         hipLaunchKernelGGL(k_sw_keys, grid(N), dim3(256), 0, s, N, ebox, axis, ka, va);
@@ -759,9 +766,13 @@ static bool sweep_on_gpu(BuildScratch& S, hipStream_t s, uint32_t n, uint32_t ns
     for (;;) {
         for (uint32_t g = 0; g < 4u && level < SW_MAX_LEVELS; g++, level++) {
             hipLaunchKernelGGL(k_sw_agg, dim3(ntile, 3), dim3(SW_TILE), 0, s, St, cur, level);
-            if (level < MAX_SWEEP_DEPTH) hipLaunchKernelGGL(k_sw_cost, dim3(ntile, 3), dim3(SW_TILE), 0, s, St, cur);
+            if (level < MAX_SWEEP_DEPTH) {
+                if (nsuper > 1) hipLaunchKernelGGL(k_sw_agg2, dim3(nsuper, 3), dim3(64), 0, s, St, cur);
+                hipLaunchKernelGGL(k_sw_cost, dim3(ntile, 3), dim3(SW_TILE), 0, s, St, cur);
+            }
             hipLaunchKernelGGL(k_sw_split, dim3(ntile), dim3(SW_TILE), 0, s, St, cur, t);
             hipLaunchKernelGGL(k_sw_pagg, dim3(ntile, 3), dim3(SW_TILE), 0, s, St, cur);
+            if (nsuper > 1) hipLaunchKernelGGL(k_sw_pagg2, dim3(nsuper, 3), dim3(64), 0, s, St, cur);
             hipLaunchKernelGGL(k_sw_part, dim3(ntile, 3), dim3(SW_TILE), 0, s, St, cur, t);
             cur ^= 1;
         }

@@ -18,6 +18,7 @@ namespace msne {
 constexpr int SW_TILE = 256;                 // positions per workgroup
 constexpr uint32_t SW_MAX_LEVELS = 192;      // MAX_SWEEP_DEPTH lopsided levels + log2 of the largest segment halved after them
 constexpr uint32_t SW_NONE = 0xFFFFFFFFu;
+constexpr uint32_t SW_SUPER = 64;           // tiles per super-tile
 
 struct alignas(16) SwAgg { float lo[3]; float hi[3]; uint32_t cnt; uint32_t pad; };   // union of boxes + sum of primitive counts
 __device__ __forceinline__ SwAgg sw_identity() { SwAgg v; for (int k = 0; k < 3; k++) { v.lo[k] = 3.0e38f; v.hi[k] = -3.0e38f; } v.cnt = 0u; v.pad = 0u; return v; }
@@ -53,6 +54,7 @@ struct SwState {
     uint32_t* segA[2]; uint32_t* segB[2]; uint32_t* segR[2]; unsigned long long* best[2];   // segment start per position; end / right turns / best split per segment start
     uint8_t* tile_act[2]; uint8_t* right_side;
     SwAgg* vf[3]; SwAgg* vb[3]; uint32_t* cf[3]; // per tile and axis: aggregates of the segment that leaves the tile at its end / enters it at its start; left-goers of the former
+    SwAgg* vf2[3]; SwAgg* vb2[3]; uint32_t* cf2[3]; // the same summed over SW_SUPER consecutive tiles (a segment of a million positions spans 4000 tiles: nobody walks them one by one)
     uint32_t* list[2]; uint32_t* list_count;     // node ids by kind (0 cluster trees, 1 top trees) in level order; [2] counters
     uint32_t* level_first;                       // [2][SW_MAX_LEVELS + 1]
 };
@@ -92,6 +94,45 @@ __global__ __launch_bounds__(SW_TILE) void k_sw_agg(SwState S, int cur, uint32_t
     if (need_b) { const SwAgg r = sw_block_reduce((p < t1 && p < b_first) ? v : sw_identity(), s_red); if (threadIdx.x == 0) S.vb[axis][t] = r; }
 }
 
+// Sum of the per-tile aggregates fine[lo .. hi) by the whole workgroup: whole super-tiles inside the range come from `coarse`.  Returns this thread's share (reduce it).
+__device__ __forceinline__ SwAgg sw_walk(const SwAgg* fine, const SwAgg* coarse, uint32_t lo, uint32_t hi) {
+    SwAgg c = sw_identity();
+    const uint32_t s0 = (lo + SW_SUPER - 1u) / SW_SUPER, s1 = hi / SW_SUPER;
+    if (s0 < s1) {
+        const uint32_t n0 = s0 * SW_SUPER - lo, n1 = s1 - s0, n2 = hi - s1 * SW_SUPER;
+        for (uint32_t i = threadIdx.x; i < n0 + n1 + n2; i += SW_TILE)
+            sw_add(c, i < n0 ? fine[lo + i] : (i < n0 + n1 ? coarse[s0 + (i - n0)] : fine[s1 * SW_SUPER + (i - n0 - n1)]));
+    } else for (uint32_t i = lo + threadIdx.x; i < hi; i += SW_TILE) sw_add(c, fine[i]);
+    return c;
+}
+__device__ __forceinline__ uint32_t sw_walk_count(const uint32_t* fine, const uint32_t* coarse, uint32_t lo, uint32_t hi) {
+    uint32_t c = 0;
+    const uint32_t s0 = (lo + SW_SUPER - 1u) / SW_SUPER, s1 = hi / SW_SUPER;
+    if (s0 < s1) {
+        const uint32_t n0 = s0 * SW_SUPER - lo, n1 = s1 - s0, n2 = hi - s1 * SW_SUPER;
+        for (uint32_t i = threadIdx.x; i < n0 + n1 + n2; i += SW_TILE)
+            c += i < n0 ? fine[lo + i] : (i < n0 + n1 ? coarse[s0 + (i - n0)] : fine[s1 * SW_SUPER + (i - n0 - n1)]);
+    } else for (uint32_t i = lo + threadIdx.x; i < hi; i += SW_TILE) c += fine[i];
+    return c;
+}
+// per super-tile and axis: the tiles' aggregates summed (only ever read for super-tiles that lie wholly inside one segment, where every tile's entry is this level's)
+__global__ __launch_bounds__(64) void k_sw_agg2(SwState S, int cur) {
+    const uint32_t axis = blockIdx.y, j = blockIdx.x * SW_SUPER + threadIdx.x;
+    const bool valid = j < S.ntile;
+    if (__ballot(valid && S.tile_act[cur][j]) == 0ull) return;
+    SwAgg f = valid ? S.vf[axis][j] : sw_identity(), b = valid ? S.vb[axis][j] : sw_identity();
+    for (int o = 32; o >= 1; o >>= 1) { const SwAgg tf = sw_shfl(f, (int)(threadIdx.x ^ (uint32_t)o)), tb = sw_shfl(b, (int)(threadIdx.x ^ (uint32_t)o)); sw_add(f, tf); sw_add(b, tb); }
+    if (threadIdx.x == 0) { S.vf2[axis][blockIdx.x] = f; S.vb2[axis][blockIdx.x] = b; }
+}
+__global__ __launch_bounds__(64) void k_sw_pagg2(SwState S, int cur) {
+    const uint32_t axis = blockIdx.y, j = blockIdx.x * SW_SUPER + threadIdx.x;
+    const bool valid = j < S.ntile;
+    if (__ballot(valid && S.tile_act[cur][j]) == 0ull) return;
+    uint32_t c = valid ? S.cf[axis][j] : 0u;
+    for (int o = 32; o >= 1; o >>= 1) c += (uint32_t)__shfl_xor((int)c, o);
+    if (threadIdx.x == 0) S.cf2[axis][blockIdx.x] = c;
+}
+
 // every split of every segment along one axis: cost from the inclusive prefix up to p and the exclusive suffix after p (split between p and p + 1)
 __global__ __launch_bounds__(SW_TILE) void k_sw_cost(SwState S, int cur) {
     __shared__ SwAgg s_red[SW_TILE / 64], s_wf[SW_TILE / 64], s_wb[SW_TILE / 64], s_first[SW_TILE / 64 + 1];
@@ -110,18 +151,8 @@ __global__ __launch_bounds__(SW_TILE) void k_sw_cost(SwState S, int cur) {
     // carries from the tiles before / after (the segment open at the tile's start / end); every thread of the tile computes the same two sums
     const uint32_t a_first = S.segA[cur][t0], a_last = S.segA[cur][t1 - 1u], b_last = S.segB[cur][a_last];
     SwAgg carry_f = sw_identity(), carry_b = sw_identity();
-    if (a_first < t0) {
-        SwAgg c = sw_identity();
-        const uint32_t tf = a_first / SW_TILE;
-        for (uint32_t j = t - 1u - threadIdx.x; j + 1u > tf && j < t; j -= SW_TILE) { sw_add(c, S.vf[axis][j]); if (j < SW_TILE) break; }
-        carry_f = sw_block_reduce(c, s_red);
-    }
-    if (b_last > t1) {
-        SwAgg c = sw_identity();
-        const uint32_t tl = (b_last - 1u) / SW_TILE;
-        for (uint32_t j = t + 1u + threadIdx.x; j <= tl; j += SW_TILE) sw_add(c, S.vb[axis][j]);
-        carry_b = sw_block_reduce(c, s_red);
-    }
+    if (a_first < t0) carry_f = sw_block_reduce(sw_walk(S.vf[axis], S.vf2[axis], a_first / SW_TILE, t), s_red);
+    if (b_last > t1) carry_b = sw_block_reduce(sw_walk(S.vb[axis], S.vb2[axis], t + 1u, (b_last - 1u) / SW_TILE + 1u), s_red);
     // forward inclusive segmented scan inside the wave (heads: segment starts), then across the tile's waves
     SwAgg P = v; bool hf = valid ? (p == a) : true;
     for (int d = 1; d < 64; d <<= 1) {
@@ -242,9 +273,7 @@ __global__ __launch_bounds__(SW_TILE) void k_sw_part(SwState S, int cur, BinTree
     const uint32_t a_first = S.segA[cur][t0];
     uint32_t carry = 0;
     if (a_first < t0 && S.segB[cur][a_first] - a_first >= 2u) {
-        uint32_t c = 0;
-        const uint32_t tf = a_first / SW_TILE;
-        for (uint32_t j = t - 1u - threadIdx.x; j + 1u > tf && j < t; j -= SW_TILE) { c += S.cf[axis][j]; if (j < SW_TILE) break; }
+        uint32_t c = sw_walk_count(S.cf[axis], S.cf2[axis], a_first / SW_TILE, t);
         for (int o = 32; o >= 1; o >>= 1) c += (uint32_t)__shfl_xor((int)c, o);
         if (lane == 0u) s_red[wave] = c;
         __syncthreads();
@@ -318,12 +347,17 @@ __global__ void k_sw_owner(uint32_t n, uint32_t node_base, const uint32_t* paren
 }
 __global__ void k_sw_iota(uint32_t n, uint32_t* v) { const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; if (i < n) v[i] = i; }
 
-// group sizes: clusters (their primitive counts) then trees (their cluster counts); scanned in place into first positions afterwards
-__global__ void k_sw_group_sizes(const uint32_t* cref, const uint32_t* cseg, uint32_t c, uint32_t ngc, BinTree tr, uint32_t* gsize) {
+// first position of every group: the clusters' primitive counts are scanned in place (k_sw_cluster_sizes, then an exclusive scan over ngc + 1 entries), the trees'
+// first clusters are found where the segment number changes (k_sw_tree_first, after the scan)
+__global__ void k_sw_cluster_sizes(const uint32_t* cref, uint32_t c, BinTree tr, uint32_t* gsize) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= c) return;
-    if (ngc) { const uint32_t r = cref[i]; gsize[i] = (r & REF_LEAF) ? 1u : tr.count[r]; }
-    atomicAdd(&gsize[ngc + (cseg ? cseg[i] : 0u)], 1u);
+    if (i < c) { const uint32_t r = cref[i]; gsize[i] = (r & REF_LEAF) ? 1u : tr.count[r]; }
+    if (i == c) gsize[c] = 0u;
+}
+__global__ void k_sw_tree_first(const uint32_t* cseg, uint32_t c, uint32_t ngc, uint32_t nseg, uint32_t P0, uint32_t* grp_first) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < c && (i == 0u || (cseg && cseg[i - 1u] != cseg[i]))) grp_first[ngc + (cseg ? cseg[i] : 0u)] = P0 + i;
+    if (i == c) grp_first[ngc + nseg] = P0 + c;
 }
 // elements in base order: primitives grouped by cluster (prim_sorted / prim_group: the by-cluster sort's output), then the clusters
 __global__ void k_sw_elements(uint32_t N, uint32_t P0, uint32_t ngc, const uint32_t* prim_sorted, const uint32_t* prim_group, const Box* prim_boxes,
