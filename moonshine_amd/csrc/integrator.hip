@@ -117,7 +117,12 @@ __device__ __forceinline__ f3 estimate_direct_mis(const Frame& frame, const LSam
 #ifndef SHADE_WPS
 #define SHADE_WPS 3          // resident waves per SIMD k_shade is register-allocated for (168 registers; 4 = 128 registers and 35 spilled, measured below)
 #endif
-__global__ __launch_bounds__(SHADE_BLOCK, SHADE_WPS) void k_shade(SceneView sc, PipelineOpts opts, PathState cur, HitBuf hits, PathState nxt, ShadowQueue shq,
+// SPEC: which paths an instantiation shades — 0: all of them (the shipped kernel); 1: finished paths and misses (no surface code at all); 2: hits on glass and
+// mirrors (no light samples, no PBR); 3: Lambert hits; 4: StandardPBR hits.  The specialised ones skip every other path of the queue: launched one after the
+// other they shade a bounce between them, bit-identically ($MSNE_SHADE_SPEC=1; measured in profiles/r04_shade_specialised.txt).
+constexpr uint32_t shade_spec_wps(int spec) { return spec == 1 ? 8u : (uint32_t)SHADE_WPS; }
+template <int SPEC>
+__global__ __launch_bounds__(SHADE_BLOCK, shade_spec_wps(SPEC)) void k_shade(SceneView sc, PipelineOpts opts, PathState cur, HitBuf hits, PathState nxt, ShadowQueue shq,
                                                          const float4* c_prev /* light-sample contributions of the previous bounce */,
                                                          float4* lbuf, BounceCounters* cnt /* [0]: this bounce, [1]: the next */, uint32_t first_pass /* the queue is k_raygen's */) {
     const uint32_t n = cnt[0].n_paths;
@@ -169,6 +174,10 @@ __global__ __launch_bounds__(SHADE_BLOCK, SHADE_WPS) void k_shade(SceneView sc, 
                         }
                     }
                 }
+                if (SPEC == 1 && cat > 1u) cat = CAT_NONE;
+                if (SPEC == 2 && cat != 2u + MAT_GLASS && cat != 2u + MAT_MIRROR) cat = CAT_NONE;
+                if (SPEC == 3 && cat != 2u + MAT_LAMBERT) cat = CAT_NONE;
+                if (SPEC == 4 && cat != 2u + MAT_PBR) cat = CAT_NONE;
             }
             uint32_t rank = 0;
 #pragma unroll
@@ -225,13 +234,16 @@ __global__ __launch_bounds__(SHADE_BLOCK, SHADE_WPS) void k_shade(SceneView sc, 
                 }
                 done = true;
             }
-            if (!done) {
+            if (SPEC != 1 && !done) {
                 const uint32_t htri = hrec.y;
                 const uint4 pg = s_geo[src];
                 GeometryRec geometry; geometry.mesh = pg.x; geometry.material = pg.y; geometry.sampled = pg.z;
                 MaterialRec mrec;
                 { const uint4 m0 = s_mat[0][src], m1 = s_mat[1][src];
-                  mrec.normal = m0.x; mrec.emissive = m0.y; mrec.type = m0.z; mrec.color = m0.w; mrec.metalness = m1.x; mrec.roughness = m1.y; mrec.ior = u2f(m1.z); mrec.pad = m1.w; }
+                  mrec.normal = m0.x; mrec.emissive = m0.y; mrec.type = m0.z; mrec.color = m0.w; mrec.metalness = m1.x; mrec.roughness = m1.y; mrec.ior = u2f(m1.z); mrec.pad = m1.w;
+                  if (SPEC == 2) mrec.type = m0.z & 2u;          // (the category filter let only these types through: the compiler drops the other BSDFs)
+                  if (SPEC == 3) mrec.type = MAT_LAMBERT;
+                  if (SPEC == 4) mrec.type = MAT_PBR; }
                 // the material's texture descriptors, all at once and before the attribute fetch below hides their latency (unused slots read the normal map's again)
                 const TexDesc t_normal = sc.textures[mrec.normal], t_emissive = sc.textures[mrec.emissive];
                 const bool has_color = mrec.type == MAT_PBR || mrec.type == MAT_LAMBERT;
@@ -266,7 +278,7 @@ __global__ __launch_bounds__(SHADE_BLOCK, SHADE_WPS) void k_shade(SceneView sc, 
                     if (rng_float(rng) > pSurvive) done = true;
                     else throughput = divs(throughput, pSurvive);
                 }
-                if (!done) { alive = true; delta = material_is_delta(material); nee = !delta && n_nee != 0u; }
+                if (!done) { alive = true; delta = SPEC == 2 ? true : (SPEC >= 3 ? false : material_is_delta(material)); nee = !delta && n_nee != 0u; }
             }
             if (done) lbuf[slot] = make_float4(L.x, L.y, L.z, 0.0f);
         }
@@ -292,9 +304,9 @@ __global__ __launch_bounds__(SHADE_BLOCK, SHADE_WPS) void k_shade(SceneView sc, 
         const uint32_t j = (uint32_t)base + (uint32_t)__popcll(ma & lt);
         const uint32_t q = (uint32_t)(base >> 32) + (uint32_t)__popcll(mn & lt);   // sample k of this path: entry q + k * stride
         // ---- phase C: light samples (integrator.hlsl:137-151) and the next direction (:153-165) ----
-        if (alive) {
+        if (SPEC != 1 && alive) {
             uint32_t valid = 0;
-            if (!delta) {   // the random numbers of every sample are drawn whether or not it gets a queue entry
+            if (SPEC != 2 && !delta) {   // the random numbers of every sample are drawn whether or not it gets a queue entry
                 for (uint32_t k = 0; k < env_n; k++) {   // integrator.hlsl:141-144
                     f2 rand; rand.x = rng_float(rng); rand.y = rng_float(rng);
                     const LSample ls = env_sample_unoccluded(sc.env, rand);
@@ -504,7 +516,12 @@ void launch_raygen(hipStream_t s, int grid, const ShardView& sh, const CameraCon
     hipLaunchKernelGGL(k_raygen, dim3(grid), dim3(SHADE_BLOCK), 0, s, sh, cam, o, sample_base, s_count, st, cnt);
 }
 void launch_shade(hipStream_t s, int grid, const SceneView& sc, const PipelineOpts& o, const PathState& cur, const HitBuf& hits, const PathState& nxt, const ShadowQueue& q, const float4* c_prev, float4* lbuf, BounceCounters* cnt, bool first_pass) {
-    hipLaunchKernelGGL(k_shade, dim3(grid), dim3(SHADE_BLOCK), 0, s, sc, o, cur, hits, nxt, q, c_prev, lbuf, cnt, first_pass ? 1u : 0u);
+    static const bool specialised = [] { const char* e = getenv("MSNE_SHADE_SPEC"); return e && atoi(e) != 0; }();
+    if (!specialised) { hipLaunchKernelGGL(k_shade<0>, dim3(grid), dim3(SHADE_BLOCK), 0, s, sc, o, cur, hits, nxt, q, c_prev, lbuf, cnt, first_pass ? 1u : 0u); return; }
+    hipLaunchKernelGGL(k_shade<1>, dim3(grid), dim3(SHADE_BLOCK), 0, s, sc, o, cur, hits, nxt, q, c_prev, lbuf, cnt, first_pass ? 1u : 0u);
+    hipLaunchKernelGGL(k_shade<2>, dim3(grid), dim3(SHADE_BLOCK), 0, s, sc, o, cur, hits, nxt, q, c_prev, lbuf, cnt, first_pass ? 1u : 0u);
+    hipLaunchKernelGGL(k_shade<3>, dim3(grid), dim3(SHADE_BLOCK), 0, s, sc, o, cur, hits, nxt, q, c_prev, lbuf, cnt, first_pass ? 1u : 0u);
+    hipLaunchKernelGGL(k_shade<4>, dim3(grid), dim3(SHADE_BLOCK), 0, s, sc, o, cur, hits, nxt, q, c_prev, lbuf, cnt, first_pass ? 1u : 0u);
 }
 void launch_light_tris(hipStream_t s, const SceneView& sc, uint32_t indexed_attributes, uint32_t n_instances, LightTri* out) {
     hipLaunchKernelGGL(k_light_tris, dim3((sc.alias_count + 1 + 255) / 256), dim3(256), 0, s, sc, indexed_attributes, n_instances, out);
