@@ -279,6 +279,10 @@ void MsneGetAccelStats(HdMoonshine*, uint64_t out[2]);
 /* bytes of texture data the context keeps in HBM: every texture in the format it was created with (MaterialManager.zig:351-390), each rounded up to 16 B */
 uint64_t MsneGetTexelPoolBytes(HdMoonshine*);
 int MsneGetTraversalCounters(HdMoonshine*, uint64_t out[20]); /* [0..3] closest {nodes,tris}, shadow {nodes,tris}; [4..19] wave-cycle profiles */
+/* lane use of the traversal loop with the counters on, summed over wave iterations: out[0..11] closest-hit kernel, out[12..23] any-hit kernel —
+   {iterations, lanes with a ray, lanes in the node / triangle / space body, lanes waiting for the space body, lanes with a ray that ran no body,
+   iterations that ran the node / triangle / space body, lanes waiting for their triangle queue, unused} */
+int MsneGetTraversalLaneUse(HdMoonshine*, uint64_t out[24]);
 /* queue lengths of the last batch, per bounce b: out[4b..4b+3] = {path-queue entries, of which entries without a ray, shadow-queue entries, shadow rays traced}; returns the number of bounces written */
 int MsneGetBounceCounters(HdMoonshine*, uint32_t* out, uint32_t max_bounces);
 /* rays: 7 floats each (origin, direction, tmax); out_ids: 4 per ray {hit, instance, geometry, primitive}; out_tuv: 3 per ray */

@@ -135,6 +135,7 @@ SYMBOLS = [
     ("MsneGetTexelPoolBytes", C.c_uint64, [_vp]),
     ("MsneGetAccelStats", None, [_vp, C.POINTER(C.c_uint64)]),
     ("MsneGetTraversalCounters", C.c_int, [_vp, C.POINTER(C.c_uint64)]),
+    ("MsneGetTraversalLaneUse", C.c_int, [_vp, C.POINTER(C.c_uint64)]),
     ("MsneTraceRays", C.c_int, [_vp, _vp, _u32, C.c_int, _vp, _vp]),
     ("MsnePick", C.c_int, [_vp, _u32, _u32, F32x2, _vp]),
     ("MsneGetEnvSize", _u32, [_vp]),
@@ -411,6 +412,12 @@ class Context:
                 "shadow_node_visits": int(out[2]), "shadow_tri_tests": int(out[3]),
                 "closest_profile": {n: int(out[4 + i]) for i, n in enumerate(names)},
                 "shadow_profile": {n: int(out[12 + i]) for i, n in enumerate(names)}}
+
+    def traversal_lane_use(self):
+        out = (C.c_uint64 * 24)()
+        self.L.MsneGetTraversalLaneUse(self.h, out)
+        names = ("iterations", "with_ray", "node_body", "tri_body", "space_body", "wait_space", "no_body", "iter_node", "iter_tri", "iter_space", "wait_tri_queue", "unused")
+        return {"closest": {n: int(out[i]) for i, n in enumerate(names)}, "shadow": {n: int(out[12 + i]) for i, n in enumerate(names)}}
 
     def pick(self, sensor, lens, x, y):
         """ObjectPicker.getClickedObject: (instance, geometry, primitive, (u, v)) under normalized sensor coordinates, or None."""

@@ -1115,6 +1115,23 @@ __global__ void k_tlas_refit(Node8* nodes, uint32_t node_begin, uint32_t item_be
     }
 }
 
+// the traversal's record of every TLAS leaf (msne_device.h TlasLeaf), from the instance records: after a TLAS build and after every in-place update
+__global__ void k_tlas_leaves(const uint32_t* items, const InstanceRec* instances, uint32_t n, TlasLeaf* out) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t ii = items[i];
+    const InstanceRec r = instances[ii];
+    TlasLeaf l;
+    for (int a = 0; a < 3; a++) for (int b = 0; b < 4; b++) l.w2i[4 * a + b] = r.world_to_instance.m[a][b];
+    l.root = (r.flags & INST_FLAG_VISIBLE) ? r.blas_root : MAX_UINT;
+    l.inst = (r.flags & INST_FLAG_WORLD) ? WORLD_INSTANCE : ii;
+    l.flags = r.flags; l.pad = 0u;
+    out[i] = l;
+}
+void bvh_tlas_leaves(hipStream_t s, const uint32_t* items, const InstanceRec* instances, uint32_t n, TlasLeaf* out) {
+    if (n) hipLaunchKernelGGL(k_tlas_leaves, dim3((n + 255) / 256), dim3(256), 0, s, items, instances, n, out);
+}
+
 void bvh_tlas_links(hipStream_t s, const Node8* nodes, uint32_t node_begin, uint32_t node_end, uint32_t item_begin, uint2* node_parent, uint2* item_parent, uint32_t root) {
     if (node_end > node_begin) hipLaunchKernelGGL(k_tlas_links, dim3((node_end - node_begin + 255) / 256), dim3(256), 0, s, nodes, node_begin, node_end, item_begin, node_parent, item_parent, root);
 }

@@ -46,6 +46,7 @@ struct TlasInst { float T[12]; float blas_box[6]; uint32_t mesh_begin, mesh_end,
 struct TlasMesh { const float* positions; uint32_t count, pad; };
 bool bvh_build_tlas(BuildScratch*, hipStream_t, const TlasInst*, const uint32_t*, uint32_t, const TlasMesh*, uint32_t, Node8*, uint32_t*, uint32_t, uint32_t*, uint32_t*, uint32_t*, uint32_t*);
 void bvh_tlas_links(hipStream_t, const Node8*, uint32_t node_begin, uint32_t node_end, uint32_t item_begin, uint2* node_parent, uint2* item_parent, uint32_t root);
+void bvh_tlas_leaves(hipStream_t, const uint32_t* items, const InstanceRec* instances, uint32_t n, TlasLeaf* out);
 bool bvh_refit_tlas(hipStream_t, const TlasInst*, const TlasMesh*, uint32_t, const uint32_t* edit_items, uint32_t n_edits, Node8*, uint32_t node_begin, uint32_t item_begin, const uint2*, const uint2*);
 }  // namespace msne
 
@@ -121,7 +122,7 @@ struct HdMoonshine {
     DevBuf<InstanceRec> d_instances;
     DevBuf<AliasEntry> d_alias;
     DevBuf<LightTri> d_light_tris; bool lights_dirty = true; uint32_t lights_indexed = 0;   // gathered light triangles (rebuilt with the alias table / attribute mode)
-    DevBuf<Node8> d_nodes; DevBuf<TriRec> d_tris; DevBuf<TriAttr> d_tri_attrs; DevBuf<uint32_t> d_tlas_items, d_item_src;
+    DevBuf<Node8> d_nodes; DevBuf<TriRec> d_tris; DevBuf<TriAttr> d_tri_attrs; DevBuf<uint32_t> d_tlas_items, d_item_src; DevBuf<TlasLeaf> d_tlas_leaves;
     bool blas_indexed = true;                             // the attribute mode the TriAttr records of the cached BLASes were gathered with
     DevBuf<uint32_t> d_build_counters;    // [0] node count, [1] tri count, [2] tlas item count
     uint32_t blas_nodes_end = 0, blas_tris_end = 0;
@@ -129,7 +130,7 @@ struct HdMoonshine {
     std::vector<uint32_t> world_blas_key;                 // key of the ONE world BLAS kept in blas_cache (empty: none)
     uint32_t dead_tris = 0;                               // triangles of evicted world BLASes still lying in the pools (reclaimed by a pool reset)
     BuildScratch* build_scratch = nullptr;                // this context's BVH build buffers: nothing is shared between contexts
-    uint32_t tlas_root = MAX_UINT, root_in_blas = 0;
+    uint32_t tlas_root = MAX_UINT, root_in_blas = 0, n_tlas_items = 0;
     // in-place TLAS update (Accel.zig:567-601): transform edits since the last build, and what a refit needs of that build
     std::vector<uint32_t> transform_edits;
     std::vector<char> built_in_world; std::vector<uint32_t> item_of_instance;   // per instance, as of the last rebuild (MAX_UINT: not in the TLAS)
@@ -411,7 +412,7 @@ bool HdMoonshine::rebuild_accel() {
         CHECK_HIP(this, hipStreamSynchronize(stream));
         std::swap(nn.p, d_nodes.p); std::swap(nn.n, d_nodes.n);
     }
-    if (!d_item_src.ensure(std::max(d_tris.n, N + 2)) || !d_tlas_items.ensure(N + 2)) { fail("out of device memory (items)"); return false; }
+    if (!d_item_src.ensure(std::max(d_tris.n, N + 2)) || !d_tlas_items.ensure(N + 2) || !d_tlas_leaves.ensure(N + 2)) { fail("out of device memory (items)"); return false; }
     // counters: node count resumes after the BLAS region (the previous TLAS is discarded)
     { uint32_t c[4] = { blas_nodes_end, blas_tris_end, 0u, 0u }; CHECK_HIP(this, hipMemcpyAsync(d_build_counters.p, c, 16, hipMemcpyHostToDevice, stream)); CHECK_HIP(this, hipStreamSynchronize(stream)); }
     lap("pools");
@@ -509,6 +510,8 @@ bool HdMoonshine::rebuild_accel() {
         for (size_t it = 0; it < h_items.size(); it++) if (h_items[it] <= N) item_of_instance[h_items[it]] = (uint32_t)it;
         if (!d_tlas_node_parent.ensure(tlas_node_end - tlas_node_begin + 1) || !d_tlas_item_parent.ensure(ids.size() + 1)) { fail("out of device memory (TLAS links)"); return false; }
         bvh_tlas_links(stream, d_nodes.p, tlas_node_begin, tlas_node_end, tlas_item_begin, d_tlas_node_parent.p, d_tlas_item_parent.p, tlas_root);
+        bvh_tlas_leaves(stream, d_tlas_items.p, d_instances.p, (uint32_t)ids.size(), d_tlas_leaves.p);
+        n_tlas_items = (uint32_t)ids.size();
     }
     if (timing) (void)hipStreamSynchronize(stream);
     lap("TLAS");
@@ -570,6 +573,7 @@ bool HdMoonshine::refit_tlas() {
     }
     if (!bvh_refit_tlas(stream, tinst.data(), tmesh.data(), (uint32_t)tmesh.size(), items.data(), (uint32_t)items.size(), d_nodes.p, tlas_node_begin, tlas_item_begin,
                         d_tlas_node_parent.p, d_tlas_item_parent.p)) return false;
+    bvh_tlas_leaves(stream, d_tlas_items.p, d_instances.p, n_tlas_items, d_tlas_leaves.p);   // (the edited instances' matrices; all of them rewritten: microseconds)
     transform_edits.clear(); n_tlas_updates++;
     return true;
 }
@@ -594,7 +598,7 @@ bool HdMoonshine::ensure_scene() {
 
 SceneView HdMoonshine::scene_view() const {
     SceneView v{};
-    v.nodes = d_nodes.p; v.tris = d_tris.p; v.tri_attrs = d_tri_attrs.p; v.tlas_items = d_tlas_items.p; v.instances = d_instances.p; v.geometries = d_geometries.p;
+    v.nodes = d_nodes.p; v.tris = d_tris.p; v.tri_attrs = d_tri_attrs.p; v.tlas_items = d_tlas_items.p; v.tlas_leaves = d_tlas_leaves.p; v.instances = d_instances.p; v.geometries = d_geometries.p;
     v.meshes = d_meshes.p; v.materials = d_materials.p; v.textures = d_texdesc.p; v.texels = d_texels.p; v.srgb_lut = d_srgb.p; v.alias = d_alias.p;
     if (!h_alias.empty()) { v.alias_count = h_alias[0].alias; v.alias_sum = h_alias[0].select; }
     v.light_tris = d_light_tris.p;
@@ -654,8 +658,8 @@ bool HdMoonshine::ensure_wavefront(size_t npaths, size_t slots, int npipes) {
     }
     if (slots > lbuf_cap) { if (!d_lbuf.alloc(slots)) { fail("out of device memory (sample buffer)"); lbuf_cap = 0; return false; } lbuf_cap = slots; }
     if (!d_overflow.p) {
-        if (!d_overflow.alloc(1) || !d_trace_stats.alloc(20)) { fail("out of device memory"); return false; }
-        if (hipMemsetAsync(d_overflow.p, 0, 4, stream) != hipSuccess || hipMemsetAsync(d_trace_stats.p, 0, 160, stream) != hipSuccess) return false;
+        if (!d_overflow.alloc(1) || !d_trace_stats.alloc(44)) { fail("out of device memory"); return false; }
+        if (hipMemsetAsync(d_overflow.p, 0, 4, stream) != hipSuccess || hipMemsetAsync(d_trace_stats.p, 0, 352, stream) != hipSuccess) return false;
     }
     return hipStreamSynchronize(stream) == hipSuccess;
 }
@@ -1092,7 +1096,7 @@ void MsneResetStats(HdMoonshine* c) {
     if (!c->bind()) return;
     c->stats = MsneStats{};
     for (auto& pp : c->pipes) if (pp.totals.p) (void)hipMemset(pp.totals.p, 0, sizeof(Totals));
-    if (c->d_trace_stats.p) (void)hipMemset(c->d_trace_stats.p, 0, 160);
+    if (c->d_trace_stats.p) (void)hipMemset(c->d_trace_stats.p, 0, 352);
 }
 
 // ---- diagnostics used by the parity tests (no reference equivalent) ----
@@ -1116,6 +1120,15 @@ int MsneGetTraversalCounters(HdMoonshine* c, uint64_t out[20]) {   // [0..3] clo
     unsigned long long h[20];
     if (hipMemcpy(h, c->d_trace_stats.p, 160, hipMemcpyDeviceToHost) != hipSuccess) return -1;
     for (int i = 0; i < 20; i++) out[i] = h[i];
+    return 0;
+}
+int MsneGetTraversalLaneUse(HdMoonshine* c, uint64_t out[24]) {   // [0..11] closest, [12..23] shadow: the lane-use counters of trace_wave_loop (STATS instantiation)
+    LOCK(c);
+    for (int i = 0; i < 24; i++) out[i] = 0;
+    if (!c->bind() || !c->d_trace_stats.p) return 0;
+    unsigned long long h[24];
+    if (hipMemcpy(h, c->d_trace_stats.p + 20, 192, hipMemcpyDeviceToHost) != hipSuccess) return -1;
+    for (int i = 0; i < 24; i++) out[i] = h[i];
     return 0;
 }
 // rays: 7 floats each (origin, direction, tmax); out_ids 4 per ray {hit, instance, geometry, primitive}; out_tuv 3 per ray

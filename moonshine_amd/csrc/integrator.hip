@@ -120,7 +120,7 @@ __device__ __forceinline__ f3 estimate_direct_mis(const Frame& frame, const LSam
 // SPEC: which paths an instantiation shades — 0: all of them (the shipped kernel); 1: finished paths and misses (no surface code at all); 2: hits on glass and
 // mirrors (no light samples, no PBR); 3: Lambert hits; 4: StandardPBR hits.  The specialised ones skip every other path of the queue: launched one after the
 // other they shade a bounce between them, bit-identically ($MSNE_SHADE_SPEC=1; measured in profiles/r04_shade_specialised.txt).
-constexpr uint32_t shade_spec_wps(int spec) { return spec == 1 ? 8u : (uint32_t)SHADE_WPS; }
+constexpr uint32_t shade_spec_wps(int spec) { return spec == 1 ? 4u : (uint32_t)SHADE_WPS; }   // (the workgroup's 35 KB of LDS allow four waves per SIMD at most)
 template <int SPEC>
 __global__ __launch_bounds__(SHADE_BLOCK, shade_spec_wps(SPEC)) void k_shade(SceneView sc, PipelineOpts opts, PathState cur, HitBuf hits, PathState nxt, ShadowQueue shq,
                                                          const float4* c_prev /* light-sample contributions of the previous bounce */,

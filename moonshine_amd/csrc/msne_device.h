@@ -114,11 +114,17 @@ struct EnvView {
     float top;                // the single texel of the last level (the map's integral)
 };
 
+// One record per TLAS leaf: everything a ray needs to enter the instance behind it (Accel.zig:394-432's instance record cut to the traversal's part) in ONE 64-B
+// fetch instead of tlas_items -> InstanceRec.  root = MAX_UINT: nothing to enter (hidden, empty BLAS); inst = WORLD_INSTANCE for the merged world BLAS.
+struct alignas(16) TlasLeaf { float w2i[12]; uint32_t root, inst, flags, pad; };
+static_assert(sizeof(TlasLeaf) == 64, "TlasLeaf must be 64 bytes");
+
 struct SceneView {
     const Node8* nodes;
     const TriRec* tris;
     const TriAttr* tri_attrs;         // parallel to tris (same slot); nullptr when no mesh of the scene has normals or texcoords
     const uint32_t* tlas_items;       // instance index per TLAS leaf item
+    const TlasLeaf* tlas_leaves;      // parallel to tlas_items: what entering that instance takes
     const InstanceRec* instances;
     const GeometryRec* geometries;
     const MeshRec* meshes;

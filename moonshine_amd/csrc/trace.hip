@@ -33,7 +33,7 @@ constexpr int TRACE_BLOCK = 256;
 #define TRACE_WPS 6          // resident waves per SIMD the trace kernels are register-allocated for (= blocks of 256 per CU)
 #endif
 #ifndef TRACE_WPS_TLAS
-#define TRACE_WPS_TLAS 5     // two-level scenes: one wave per SIMD less buys 96 registers — room for the world-space half of the ray a lane keeps while inside an instance
+#define TRACE_WPS_TLAS 6     // two-level scenes: the world-space half of the ray a lane keeps while inside an instance costs 13 spilled registers at 80 — and 6 waves per SIMD are still 3 % faster than 5 at 96 registers without spills (S2 3597 / 3481 Mrays/s, profiles/r04_s2_variants.txt; round 3 measured the opposite before the leaf records took the InstanceRec hop out of the space body)
 #endif
 #ifndef TRACE_SPACE_MIN_LANES
 #define TRACE_SPACE_MIN_LANES 16   // lanes that must wait for a change of space (instance entry / exit) before the wave runs that body
@@ -313,10 +313,10 @@ __device__ __forceinline__ void order_table_init(uint8_t* lut) {
 // `store(i, lane)` receives the finished lane.
 // INSTANCED = the scene has a TLAS level.  Without one (sc.root_in_blas: the world BLAS is the root) no lane ever changes space,
 // and that instantiation carries none of the space-body bookkeeping (measured on S1: the shared code cost 7 %).
-template <bool ANY_HIT, bool STATS, bool INSTANCED, class Load, class Store>
+template <bool ANY_HIT, bool STATS, bool INSTANCED, class Load, class LoadDir, class Store>
 __device__ __forceinline__ void trace_wave_loop(const SceneView& sc, uint32_t n, uint32_t* head, uint32_t* lds_stack, const uint8_t* lut, uint32_t* spill, uint32_t* overflow,
-                                                uint32_t refill /* idle lanes of 64 that trigger a refill from the ray queue */, Load load, Store store, unsigned long long& nv, unsigned long long& nt, unsigned long long* prof,
-                                                uint32_t* rays_traced = nullptr /* += queue entries that held a ray */) {
+                                                uint32_t refill /* idle lanes of 64 that trigger a refill from the ray queue */, Load load, LoadDir load_dir /* (i) -> the ray's direction again */, Store store, unsigned long long& nv, unsigned long long& nt, unsigned long long* prof,
+                                                uint32_t* rays_traced = nullptr /* += queue entries that held a ray */, unsigned long long* lanes_out = nullptr /* STATS: lane use, 12 counters */) {
     const uint32_t lane = threadIdx.x & 63u;
     const unsigned long long lt = lane == 0 ? 0ull : (~0ull >> (64 - lane));
     const uint32_t gtid = blockIdx.x * TRACE_BLOCK + threadIdx.x;
@@ -326,6 +326,10 @@ __device__ __forceinline__ void trace_wave_loop(const SceneView& sc, uint32_t n,
     bool active = false; uint32_t my = 0, n_rays = 0;
     // STATS builds: wave-cycle profile of the loop sections (s_memtime), accumulated per wave
     unsigned long long cyc[8] = { 0, 0, 0, 0, 0, 0, 0, 0 }, tprev = 0;
+    // lane use per iteration (MsneGetTraversalLaneUse): [0] iterations that reach the bodies, [1] lanes with a ray, [2] / [3] / [4] lanes in the node / triangle / space
+    // body, [5] lanes whose group is an instance while the space body does not run, [6] lanes with a ray that run no body at all, [7] / [8] / [9] iterations that
+    // run the node / triangle / space body, [10] lanes that hold a node group but wait for their triangle queue to drain
+    unsigned long long use[12] = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 };
     auto lap = [&](int k) { if (STATS) { const unsigned long long t = __builtin_readcyclecounter(); cyc[k] += t - tprev; tprev = t; } };
     if (STATS) tprev = __builtin_readcyclecounter();
     for (;;) {
@@ -453,20 +457,15 @@ __device__ __forceinline__ void trace_wave_loop(const SceneView& sc, uint32_t n,
         const bool do_s = INSTANCED && ms != 0ull && ((uint32_t)__popcll(ms) >= SPACE_MIN_LANES || (!do_n && !do_t));
         if (STATS && do_s) cyc[2] += __popcll(ms);   // lanes that change space (slot 2 of the profile: the vote itself is timed with the node section)
         if (INSTANCED && do_s && want_s) {   // entering an instance (leaving needs no body: the world-space half of the lane's ray was put aside)
-            uint32_t root = MAX_UINT, new_inst = 0u;
             const uint32_t item = group_take(L, S, lut);   // TLAS leaf (one instance of the group; the rest of the group goes back on the stack)
-            const uint32_t ii = sc.tlas_items[item];
-            const InstanceRec* ir = sc.instances + ii;
-            const uint32_t flags = ir->flags;
-            root = ir->blas_root;
-            if (!(flags & INST_FLAG_VISIBLE)) root = MAX_UINT;
-            new_inst = (flags & INST_FLAG_WORLD) ? WORLD_INSTANCE : ii;
+            // the leaf's own 64-B record (matrix, BLAS root, instance) and the ray's direction: five independent loads, one round trip
+            const float4* mp = reinterpret_cast<const float4*>(sc.tlas_leaves + item);
+            const float4 r0 = mp[0], r1 = mp[1], r2 = mp[2];
+            const uint4 lw = reinterpret_cast<const uint4*>(mp)[3];
+            const uint32_t root = lw.x, new_inst = lw.y, flags = lw.z;
             if (root != MAX_UINT) {
                 const bool ident = (flags & INST_FLAG_IDENTITY) != 0u;
-                const float4* mp = reinterpret_cast<const float4*>(&ir->world_to_instance);
-                const float4 r0 = mp[0], r1 = mp[1], r2 = mp[2];
-                f3 o, d; float tmax;
-                (void)load(my, o, d, tmax);   // the world-space direction is not kept in registers
+                f3 o = L.o, d = load_dir(my);   // at TLAS level the lane's origin IS the world-space one; the world-space direction is not kept in registers
                 L.wo = L.o; L.wid = L.id; L.woct = L.octbase;
                 L.ret_sp = L.sp;   // (the rest of the instance group is already on the stack: group_take above)
                 if (!ident) {   // t is preserved: d is not renormalised.  (Identity: M·(o,1) = o and M·d = d exactly — only the shear constants are recomputed)
@@ -490,6 +489,14 @@ __device__ __forceinline__ void trace_wave_loop(const SceneView& sc, uint32_t n,
         }
         lap(3);
         if (STATS && do_n2) cyc[6] += __popcll(__ballot(want_n2));   // node-lane steps
+        if (STATS) {
+            const bool ran_s = INSTANCED && do_s && want_s, ran_n = do_n2 && want_n2, ran_t = do_t && want_t;
+            use[0] += 1; use[1] += __popcll(__ballot(active));
+            use[2] += __popcll(__ballot(ran_n)); use[3] += __popcll(__ballot(ran_t)); use[4] += __popcll(__ballot(ran_s));
+            use[5] += __popcll(__ballot(want_s && !do_s)); use[6] += __popcll(__ballot(active && !ran_s && !ran_n && !ran_t));
+            use[7] += do_n2 ? 1 : 0; use[8] += do_t ? 1 : 0; use[9] += (INSTANCED && do_s) ? 1 : 0;
+            use[10] += __popcll(__ballot(has_g && !want_s && !want_n));
+        }
         if (STATS && !INSTANCED && do_t) cyc[2] += 1;   // (scenes without a TLAS level: slot 2 counts the iterations that ran the triangle body)
         if (do_t && want_t) {
             if (step_tri<ANY_HIT, STATS, INSTANCED>(L, sc, nt)) { L.sp = 0; L.sb = 0; L.g1 = 0; L.ta1 = 0; L.tb1 = 0; store(my, L); active = false; }
@@ -497,7 +504,7 @@ __device__ __forceinline__ void trace_wave_loop(const SceneView& sc, uint32_t n,
         lap(4);
         if (STATS) cyc[5] += __popcll(__ballot(active));   // active lanes at the end of the iteration
     }
-    if (STATS && (threadIdx.x & 63u) == 0) for (int k = 0; k < 8; k++) atomicAdd(&prof[k], cyc[k]);
+    if (STATS && (threadIdx.x & 63u) == 0) { for (int k = 0; k < 8; k++) atomicAdd(&prof[k], cyc[k]); if (lanes_out) for (int k = 0; k < 12; k++) atomicAdd(&lanes_out[k], use[k]); }
     if (rays_traced) {   // one atomic per wave
         for (int o = 32; o >= 1; o >>= 1) n_rays += __shfl_xor(n_rays, o);
         if ((threadIdx.x & 63u) == 0 && n_rays) atomicAdd(rays_traced, n_rays);
@@ -523,9 +530,10 @@ __global__ __launch_bounds__(TRACE_BLOCK, INSTANCED ? TRACE_WPS_TLAS : TRACE_WPS
             o = F3(ro.x, ro.y, ro.z); d = F3(rd.x, rd.y, rd.z); tmax = INFINITY_F;
             return true;
         },
+        [&](uint32_t i) -> f3 { const float4 rd = st.rd[i]; return F3(rd.x, rd.y, rd.z); },
         [&](uint32_t i, const Lane& L) {
             hits.rec[i] = make_uint4(L.best.inst, L.best.tri, f2u(L.best.u), f2u(L.best.v));
-        }, nv, nt, stat_out + 4);
+        }, nv, nt, stat_out + 4, nullptr, stat_out + 20);
     if (STATS) { atomicAdd(&stat_out[0], nv); atomicAdd(&stat_out[1], nt); }
 }
 
@@ -542,10 +550,11 @@ __global__ __launch_bounds__(TRACE_BLOCK, INSTANCED ? TRACE_WPS_TLAS : TRACE_WPS
             o = F3(qo.x, qo.y, qo.z); d = F3(qd.x, qd.y, qd.z); tmax = qo.w;
             return true;
         },
+        [&](uint32_t i) -> f3 { const float4 qd = q.d[i]; return F3(qd.x, qd.y, qd.z); },
         [&](uint32_t i, const Lane& L) {
             // ShadowIntersection::hit → lightSample.pdf = 0 (light.hlsl:75-77,154-156): the sample's contribution vanishes
             if (L.best.inst != MAX_UINT) q.c[i] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-        }, nv, nt, stat_out + 12, &cnt->n_shadow_traced);
+        }, nv, nt, stat_out + 12, &cnt->n_shadow_traced, stat_out + 32);
     if (STATS) { atomicAdd(&stat_out[2], nv); atomicAdd(&stat_out[3], nt); }
 }
 
@@ -562,6 +571,7 @@ __global__ __launch_bounds__(TRACE_BLOCK, TRACE_WPS_TLAS) void k_trace_probe(Sce
             o = F3(r[0], r[1], r[2]); d = F3(r[3], r[4], r[5]); tmax = r[6];
             return true;
         },
+        [&](uint32_t i) -> f3 { const float* r = rays + 7 * (size_t)i; return F3(r[3], r[4], r[5]); },
         [&](uint32_t i, const Lane& L) {
             const bool hit = L.best.inst != MAX_UINT;
             if (ANY_HIT) {   // the pieces of a shared any-hit ray report separately: only occlusion is written (the buffers start zeroed)
