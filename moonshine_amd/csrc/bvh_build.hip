@@ -1052,7 +1052,7 @@ __device__ __forceinline__ bool quantise_child(const float origin[3], const uint
     for (int k = 0; k < 3; k++) {
         const float inv_s = u2f((uint32_t)(254 - e[k]) << 23);
         const float lo = floorf((b.lo[k] - origin[k]) * inv_s - 1e-3f), hi = ceilf((b.hi[k] - origin[k]) * inv_s + 1e-3f);
-        if (!(lo >= 0.0f) || !(hi <= 255.0f)) return false;
+        if (!(lo >= 0.0f) || !(hi <= 255.0f) || !(hi >= 0.0f) || !(lo <= 255.0f)) return false;   // (NaN or an empty box: does not fit any grid)
         ql[k] = (uint8_t)lo; qh[k] = (uint8_t)hi;
     }
     return true;
@@ -1067,51 +1067,98 @@ __device__ __forceinline__ Box dequantise_child(const Node8& nd, uint32_t s) {
     return b;
 }
 
-// ONE thread walks every edit from its leaf to the root (edits may share ancestors; a refit is a few dozen loads and stores per level)
-__global__ void k_tlas_refit(Node8* nodes, uint32_t node_begin, uint32_t item_begin, const uint2* node_parent, const uint2* item_parent,
-                             const uint32_t* edit_items, const Box* edit_boxes, uint32_t n_edits) {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
-    for (uint32_t ed = 0; ed < n_edits; ed++) {
-        Box nb = edit_boxes[ed];
-        uint2 at = item_parent[edit_items[ed] - item_begin];
-        while (at.x != MAX_UINT) {
-            Node8 nd = nodes[at.x];
-            const uint32_t used = (uint32_t)nd.imask | (uint32_t)nd.lmask;
-            float origin[3] = { nd.ox, nd.oy, nd.oz }; uint8_t e[3] = { nd.ex, nd.ey, nd.ez };
-            uint8_t ql[3], qh[3];
-            if (quantise_child(origin, e, nb, ql, qh)) { for (int k = 0; k < 3; k++) { nd.qlo[k][at.y] = ql[k]; nd.qhi[k][at.y] = qh[k]; } }
-            else {   // the child left the node's grid: a new grid over the union of all children (the others from their quantised boxes: conservative)
-                Box cb[8]; Box u;
-                for (int k = 0; k < 3; k++) { u.lo[k] = 3.0e38f; u.hi[k] = -3.0e38f; }
-                for (uint32_t s = 0; s < 8; s++) if ((used >> s) & 1u) {
-                    cb[s] = s == at.y ? nb : dequantise_child(nd, s);
-                    for (int k = 0; k < 3; k++) { u.lo[k] = fminf(u.lo[k], cb[s].lo[k]); u.hi[k] = fmaxf(u.hi[k], cb[s].hi[k]); }
-                }
-                nd.ox = u.lo[0]; nd.oy = u.lo[1]; nd.oz = u.lo[2];
-                for (int k = 0; k < 3; k++) {   // smallest power of two s with ext/s <= 254, as k_collapse chooses it
-                    const float ext = u.hi[k] - u.lo[k];
-                    int ex = 1;
-                    if (ext > 0.0f) { const float q = ext / 254.0f; ex = (int)((f2u(q) >> 23) & 0xff) + 1; }
-                    if (ex < 1) ex = 1;
-                    if (ex > 254) ex = 254;
-                    e[k] = (uint8_t)ex; origin[k] = u.lo[k];
-                }
-                nd.ex = e[0]; nd.ey = e[1]; nd.ez = e[2];
-                for (uint32_t s = 0; s < 8; s++) if ((used >> s) & 1u) {
-                    uint8_t a[3], b[3];
-                    if (!quantise_child(origin, e, cb[s], a, b)) for (int k = 0; k < 3; k++) { a[k] = 0; b[k] = 255; }   // (cannot happen: the grid spans the union)
-                    for (int k = 0; k < 3; k++) { nd.qlo[k][s] = a[k]; nd.qhi[k][s] = b[k]; }
-                }
-            }
-            nodes[at.x] = nd;
-            // what the parent has to bound: the union of this node's children as the traversal sees them
-            for (int k = 0; k < 3; k++) { nb.lo[k] = 3.0e38f; nb.hi[k] = -3.0e38f; }
-            for (uint32_t s = 0; s < 8; s++) if ((used >> s) & 1u) {
-                const Box c = dequantise_child(nd, s);
-                for (int k = 0; k < 3; k++) { nb.lo[k] = fminf(nb.lo[k], c.lo[k]); nb.hi[k] = fmaxf(nb.hi[k], c.hi[k]); }
-            }
-            at = node_parent[at.x - node_begin];
+// ---- the refit, one thread per edit ----
+// Pass 1 (k_tlas_refit_mark): every edit stores its leaf's new box and walks towards the root, marking nodes dirty; a node that was already dirty ends the walk (its
+// ancestors are marked), a node that becomes dirty counts as one pending child of its parent.  Pass 2 (k_tlas_refit_apply): a dirty node is re-fitted ONCE, when none of
+// its dirty children is pending any more — by whoever gets there first (the edits under it, or the thread that finished its last dirty child) — from its children as
+// they are now: edited leaves with their new boxes, re-fitted child nodes with their new bounds, everything else as quantised.  The planes of a changed child are
+// re-quantised on the node's grid; only when one does not fit is the grid re-made over the union of all children.
+struct RefitState {
+    uint32_t* dirty; uint32_t* pending; uint32_t* claimed;   // per TLAS node (index - node_begin), zeroed before every refit
+    Box* node_bounds;                                          // per TLAS node: what a re-fitted node's parent has to bound
+    uint32_t* item_edited; Box* item_box;                      // per TLAS leaf item (index - item_begin): the item was edited / its new box
+};
+
+__global__ void k_tlas_refit_mark(RefitState R, uint32_t node_begin, uint32_t item_begin, const uint2* node_parent, const uint2* item_parent,
+                                  const uint32_t* edit_items, const Box* edit_boxes, uint32_t n_edits) {
+    const uint32_t ed = blockIdx.x * blockDim.x + threadIdx.x;
+    if (ed >= n_edits) return;
+    const uint32_t item = edit_items[ed] - item_begin;
+    R.item_box[item] = edit_boxes[ed]; R.item_edited[item] = 1u;
+    uint32_t n = item_parent[item].x;
+    while (n != MAX_UINT) {
+        if (atomicExch(&R.dirty[n - node_begin], 1u) != 0u) break;          // someone else marked it and everything above
+        const uint32_t up = node_parent[n - node_begin].x;
+        if (up != MAX_UINT) atomicAdd(&R.pending[up - node_begin], 1u);
+        n = up;
+    }
+}
+
+__device__ __forceinline__ void refit_node(Node8* nodes, uint32_t n, const RefitState& R, uint32_t node_begin, uint32_t item_begin) {
+    Node8 nd = nodes[n];
+    const uint32_t used = (uint32_t)nd.imask | (uint32_t)nd.lmask;
+    float origin[3] = { nd.ox, nd.oy, nd.oz }; uint8_t e[3] = { nd.ex, nd.ey, nd.ez };
+    Box cb[8]; uint32_t changed = 0; bool fits = true;
+    uint32_t ci = 0, li = 0;
+    for (uint32_t s = 0; s < 8; s++) {
+        if ((nd.imask >> s) & 1u) {
+            const uint32_t c = nd.child_base + ci++;
+            if (R.dirty[c - node_begin]) { cb[s] = R.node_bounds[c - node_begin]; changed |= 1u << s; } else cb[s] = dequantise_child(nd, s);
+        } else if ((nd.lmask >> s) & 1u) {
+            const uint32_t it = nd.item_base + li++ - item_begin;
+            if (R.item_edited[it]) { cb[s] = R.item_box[it]; changed |= 1u << s; } else cb[s] = dequantise_child(nd, s);
         }
+    }
+    for (uint32_t s = 0; s < 8; s++) if ((changed >> s) & 1u) {
+        uint8_t ql[3], qh[3];
+        if (quantise_child(origin, e, cb[s], ql, qh)) { for (int k = 0; k < 3; k++) { nd.qlo[k][s] = ql[k]; nd.qhi[k][s] = qh[k]; } }
+        else fits = false;
+    }
+    if (!fits) {   // a child left the node's grid: a new grid over the union of all children (the unchanged ones from their quantised boxes: conservative)
+        Box u;
+        for (int k = 0; k < 3; k++) { u.lo[k] = 3.0e38f; u.hi[k] = -3.0e38f; }
+        for (uint32_t s = 0; s < 8; s++) if ((used >> s) & 1u) for (int k = 0; k < 3; k++) { u.lo[k] = fminf(u.lo[k], cb[s].lo[k]); u.hi[k] = fmaxf(u.hi[k], cb[s].hi[k]); }
+        nd.ox = u.lo[0]; nd.oy = u.lo[1]; nd.oz = u.lo[2];
+        for (int k = 0; k < 3; k++) {   // smallest power of two s with ext/s <= 254, as k_collapse chooses it
+            const float ext = u.hi[k] - u.lo[k];
+            int ex = 1;
+            if (ext > 0.0f) { const float q = ext / 254.0f; ex = (int)((f2u(q) >> 23) & 0xff) + 1; }
+            if (ex < 1) ex = 1;
+            if (ex > 254) ex = 254;
+            e[k] = (uint8_t)ex; origin[k] = u.lo[k];
+        }
+        nd.ex = e[0]; nd.ey = e[1]; nd.ez = e[2];
+        for (uint32_t s = 0; s < 8; s++) if ((used >> s) & 1u) {
+            uint8_t a[3], b[3];
+            if (!quantise_child(origin, e, cb[s], a, b)) for (int k = 0; k < 3; k++) { a[k] = 0; b[k] = 255; }   // (an instance without a finite vertex: everything)
+            for (int k = 0; k < 3; k++) { nd.qlo[k][s] = a[k]; nd.qhi[k][s] = b[k]; }
+        }
+    }
+    nodes[n] = nd;
+    Box nb;   // what the parent has to bound: the union of this node's children as the traversal sees them
+    for (int k = 0; k < 3; k++) { nb.lo[k] = 3.0e38f; nb.hi[k] = -3.0e38f; }
+    for (uint32_t s = 0; s < 8; s++) if ((used >> s) & 1u) {
+        const Box c = dequantise_child(nd, s);
+        for (int k = 0; k < 3; k++) { nb.lo[k] = fminf(nb.lo[k], c.lo[k]); nb.hi[k] = fmaxf(nb.hi[k], c.hi[k]); }
+    }
+    R.node_bounds[n - node_begin] = nb;
+}
+
+__global__ void k_tlas_refit_apply(Node8* nodes, RefitState R, uint32_t node_begin, uint32_t item_begin, const uint2* node_parent, const uint2* item_parent,
+                                   const uint32_t* edit_items, uint32_t n_edits) {
+    const uint32_t ed = blockIdx.x * blockDim.x + threadIdx.x;
+    if (ed >= n_edits) return;
+    uint32_t n = item_parent[edit_items[ed] - item_begin].x;
+    while (n != MAX_UINT) {
+        if (atomicAdd(&R.pending[n - node_begin], 0u) != 0u) break;           // a dirty child is still out: whoever finishes the last one comes back here
+        if (atomicExch(&R.claimed[n - node_begin], 1u) != 0u) break;          // another edit under this node got here first
+        __threadfence();
+        refit_node(nodes, n, R, node_begin, item_begin);
+        __threadfence();
+        const uint32_t up = node_parent[n - node_begin].x;
+        if (up == MAX_UINT) break;
+        if (atomicSub(&R.pending[up - node_begin], 1u) != 1u) break;          // not the last dirty child of the parent
+        n = up;
     }
 }
 
@@ -1136,22 +1183,29 @@ void bvh_tlas_links(hipStream_t s, const Node8* nodes, uint32_t node_begin, uint
     if (node_end > node_begin) hipLaunchKernelGGL(k_tlas_links, dim3((node_end - node_begin + 255) / 256), dim3(256), 0, s, nodes, node_begin, node_end, item_begin, node_parent, item_parent, root);
 }
 
-// insts / meshes describe the n_edits edited instances (their NEW transforms), edit_items their TLAS leaf items
+// insts / meshes describe the n_edits edited instances (their NEW transforms), edit_items their TLAS leaf items; n_nodes / n_items: the TLAS's nodes and leaf items
 bool bvh_refit_tlas(hipStream_t s, const TlasInst* insts, const TlasMesh* meshes, uint32_t nmeshes, const uint32_t* edit_items, uint32_t n_edits,
-                    Node8* nodes, uint32_t node_begin, uint32_t item_begin, const uint2* node_parent, const uint2* item_parent) {
+                    Node8* nodes, uint32_t node_begin, uint32_t n_nodes, uint32_t item_begin, uint32_t n_items, const uint2* node_parent, const uint2* item_parent) {
     if (n_edits == 0) return true;
-    TlasInst* dinst = nullptr; TlasMesh* dmesh = nullptr; uint32_t* ditems = nullptr; Box* dboxes = nullptr;
+    TlasInst* dinst = nullptr; TlasMesh* dmesh = nullptr; uint32_t* ditems = nullptr; Box* dboxes = nullptr; char* state = nullptr;
+    struct Free { TlasInst*& a; TlasMesh*& b; uint32_t*& c; Box*& d; char*& e; ~Free() { (void)hipFree(a); (void)hipFree(b); (void)hipFree(c); (void)hipFree(d); (void)hipFree(e); } } fr{ dinst, dmesh, ditems, dboxes, state };
     HIPCHK(hipMalloc(&dinst, (size_t)n_edits * sizeof(TlasInst)));
     HIPCHK(hipMalloc(&dboxes, (size_t)n_edits * sizeof(Box)));
     HIPCHK(hipMalloc(&dmesh, (size_t)std::max(nmeshes, 1u) * sizeof(TlasMesh)));
     HIPCHK(hipMalloc(&ditems, (size_t)n_edits * 4));
+    const size_t zeroed = ((size_t)3 * n_nodes + n_items) * 4, total = zeroed + ((size_t)n_nodes + n_items) * sizeof(Box);
+    HIPCHK(hipMalloc(&state, total));
+    HIPCHK(hipMemsetAsync(state, 0, zeroed, s));
+    RefitState R;
+    R.dirty = (uint32_t*)state; R.pending = R.dirty + n_nodes; R.claimed = R.pending + n_nodes; R.item_edited = R.claimed + n_nodes;
+    R.node_bounds = (Box*)(state + zeroed); R.item_box = R.node_bounds + n_nodes;
     HIPCHK(hipMemcpyAsync(dinst, insts, (size_t)n_edits * sizeof(TlasInst), hipMemcpyHostToDevice, s));
     if (nmeshes) HIPCHK(hipMemcpyAsync(dmesh, meshes, (size_t)nmeshes * sizeof(TlasMesh), hipMemcpyHostToDevice, s));
     HIPCHK(hipMemcpyAsync(ditems, edit_items, (size_t)n_edits * 4, hipMemcpyHostToDevice, s));
     hipLaunchKernelGGL(k_instance_boxes, dim3(n_edits), dim3(256), 0, s, dinst, dmesh, n_edits, dboxes);
-    hipLaunchKernelGGL(k_tlas_refit, dim3(1), dim3(64), 0, s, nodes, node_begin, item_begin, node_parent, item_parent, ditems, dboxes, n_edits);
+    hipLaunchKernelGGL(k_tlas_refit_mark, dim3((n_edits + 63) / 64), dim3(64), 0, s, R, node_begin, item_begin, node_parent, item_parent, ditems, dboxes, n_edits);
+    hipLaunchKernelGGL(k_tlas_refit_apply, dim3((n_edits + 63) / 64), dim3(64), 0, s, nodes, R, node_begin, item_begin, node_parent, item_parent, ditems, n_edits);
     HIPCHK(hipStreamSynchronize(s));
-    (void)hipFree(dinst); (void)hipFree(dmesh); (void)hipFree(ditems); (void)hipFree(dboxes);
     return true;
 }
 

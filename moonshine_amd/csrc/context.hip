@@ -47,7 +47,7 @@ struct TlasMesh { const float* positions; uint32_t count, pad; };
 bool bvh_build_tlas(BuildScratch*, hipStream_t, const TlasInst*, const uint32_t*, uint32_t, const TlasMesh*, uint32_t, Node8*, uint32_t*, uint32_t, uint32_t*, uint32_t*, uint32_t*, uint32_t*);
 void bvh_tlas_links(hipStream_t, const Node8*, uint32_t node_begin, uint32_t node_end, uint32_t item_begin, uint2* node_parent, uint2* item_parent, uint32_t root);
 void bvh_tlas_leaves(hipStream_t, const uint32_t* items, const InstanceRec* instances, uint32_t n, TlasLeaf* out);
-bool bvh_refit_tlas(hipStream_t, const TlasInst*, const TlasMesh*, uint32_t, const uint32_t* edit_items, uint32_t n_edits, Node8*, uint32_t node_begin, uint32_t item_begin, const uint2*, const uint2*);
+bool bvh_refit_tlas(hipStream_t, const TlasInst*, const TlasMesh*, uint32_t, const uint32_t* edit_items, uint32_t n_edits, Node8*, uint32_t node_begin, uint32_t n_nodes, uint32_t item_begin, uint32_t n_items, const uint2*, const uint2*);
 }  // namespace msne
 
 using namespace msne;
@@ -136,7 +136,7 @@ struct HdMoonshine {
     std::vector<char> built_in_world; std::vector<uint32_t> item_of_instance;   // per instance, as of the last rebuild (MAX_UINT: not in the TLAS)
     DevBuf<uint2> d_tlas_node_parent, d_tlas_item_parent; uint32_t tlas_node_begin = 0, tlas_node_end = 0, tlas_item_begin = 0;
     std::vector<InstanceRec> h_irec;
-    uint64_t n_rebuilds = 0, n_tlas_updates = 0;
+    uint64_t n_rebuilds = 0, n_tlas_updates = 0; uint32_t refits_since_rebuild = 0;
     bool refit_tlas();
     std::vector<AliasEntry> h_alias;
     // environment
@@ -543,7 +543,7 @@ bool HdMoonshine::rebuild_accel() {
     if (bvh_scratch_capacity(build_scratch) > (1u << 20)) bvh_scratch_release(build_scratch);
     lap("scratch release");
     if (timing) fprintf(stderr, "moonshine_amd rebuild (%zu instances):%s\n", N, t_report.c_str());
-    accel_dirty = false; transform_edits.clear(); n_rebuilds++;
+    accel_dirty = false; transform_edits.clear(); n_rebuilds++; refits_since_rebuild = 0;
     return true;
 }
 
@@ -563,7 +563,7 @@ bool HdMoonshine::refit_tlas() {
         InstanceRec& r = h_irec[h];
         r.transform = instances[h].transform; r.world_to_instance = m34_inverse_affine(instances[h].transform);
         r.flags = INST_FLAG_VISIBLE;   // (a refit never sees an identity transform or a hidden instance: those are rebuilds)
-        CHECK_HIP(this, hipMemcpyAsync(d_instances.p + h, &r, sizeof(InstanceRec), hipMemcpyHostToDevice, stream));
+        if (transform_edits.size() <= 64) CHECK_HIP(this, hipMemcpyAsync(d_instances.p + h, &r, sizeof(InstanceRec), hipMemcpyHostToDevice, stream));
         TlasInst t{};
         memcpy(t.T, &instances[h].transform, 48); memcpy(t.blas_box, bi->second.box, 24);
         t.mesh_begin = (uint32_t)tmesh.size();
@@ -571,10 +571,11 @@ bool HdMoonshine::refit_tlas() {
         t.mesh_end = (uint32_t)tmesh.size(); t.exact = t.mesh_end > t.mesh_begin ? 1u : 0u;
         tinst.push_back(t); items.push_back(item_of_instance[h]);
     }
-    if (!bvh_refit_tlas(stream, tinst.data(), tmesh.data(), (uint32_t)tmesh.size(), items.data(), (uint32_t)items.size(), d_nodes.p, tlas_node_begin, tlas_item_begin,
+    if (transform_edits.size() > 64) CHECK_HIP(this, hipMemcpyAsync(d_instances.p, h_irec.data(), h_irec.size() * sizeof(InstanceRec), hipMemcpyHostToDevice, stream));   // many edits: the whole table in one copy
+    if (!bvh_refit_tlas(stream, tinst.data(), tmesh.data(), (uint32_t)tmesh.size(), items.data(), (uint32_t)items.size(), d_nodes.p, tlas_node_begin, tlas_node_end - tlas_node_begin, tlas_item_begin, n_tlas_items,
                         d_tlas_node_parent.p, d_tlas_item_parent.p)) return false;
     bvh_tlas_leaves(stream, d_tlas_items.p, d_instances.p, n_tlas_items, d_tlas_leaves.p);   // (the edited instances' matrices; all of them rewritten: microseconds)
-    transform_edits.clear(); n_tlas_updates++;
+    transform_edits.clear(); n_tlas_updates++; refits_since_rebuild++;
     return true;
 }
 
@@ -582,7 +583,11 @@ bool HdMoonshine::ensure_scene() {
     if (textures_dirty && !upload_textures()) return false;
     if ((materials_dirty || !material_updates.empty()) && !upload_materials()) return false;
     if (blas_indexed != (opts.indexed_attributes != 0)) accel_dirty = true;
-    if (!accel_dirty && !transform_edits.empty() && (transform_edits.size() > 256 || !refit_tlas())) accel_dirty = true;   // many edits, or anything unexpected: rebuild
+    // Transform edits re-fit the TLAS in place (every edit its own thread: bvh_refit_tlas) while they are a minority of the instances; when a quarter of the scene moves
+    // at once the tree's shape is stale anyway and the rebuild is cheap (17 ms for 100 000 instances).  A re-fitted tree keeps its shape and its re-made grids round
+    // outward, so its boxes only ever grow: after 64 re-fits in a row it is rebuilt (the reference's UPDATE-mode builds degrade the same way, Accel.zig:567-601).
+    if (!accel_dirty && !transform_edits.empty() &&
+        (transform_edits.size() > std::max<size_t>(256, instances.size() / 4) || refits_since_rebuild >= 64 || !refit_tlas())) accel_dirty = true;
     if (accel_dirty && !rebuild_accel()) return false;
     if (lights_dirty || lights_indexed != opts.indexed_attributes) {
         const uint32_t count = h_alias.empty() ? 0u : h_alias[0].alias;

@@ -20,8 +20,15 @@ for name, kw in (("S2 500 x 10242 verts", dict(extent=(320, 180), dims=(10, 10, 
     T = np.zeros((3, 4), dtype=np.float32); T[:, :3] = np.eye(3) * 0.9; T[:, 3] = [0.1, 0.2, 3.3]
     c.set_instance_transform(3, T)
     upd = timed(lambda: c.render(s, l))
+    rs = np.random.default_rng(1); n_inst = kw["dims"][0] * kw["dims"][1] * kw["dims"][2]
+    many = rs.choice(n_inst, n_inst // 10, replace=False)
+    for h in many:
+        T2 = T.copy(); T2[:, 3] = rs.normal(size=3) * 5.0 + (0, 0, 5)
+        c.set_instance_transform(int(h), T2)
+    upd_many = timed(lambda: c.render(s, l))
+    many_stats = c.accel_stats()
     c.set_instance_visibility(5, False)
     reb = timed(lambda: c.render(s, l))
-    print("%-22s first render (BLAS + TLAS build) %6.1f ms | plain render %5.1f ms | after one transform edit %5.1f ms (%s) | after a visibility edit (TLAS rebuild) %5.1f ms"
-          % (name, first, plain, upd, c.accel_stats(), reb))
+    print("%-22s first render (BLAS + TLAS build) %6.1f ms | plain render %5.1f ms | after one transform edit %5.1f ms (%s) | after %d transform edits at once %5.1f ms (%s) | after a visibility edit (TLAS rebuild) %5.1f ms"
+          % (name, first, plain, upd, c.accel_stats(), len(many), upd_many, many_stats, reb))
     c.close()
