@@ -30,7 +30,7 @@ import torch  # noqa: E402  (before the HIP library: one HIP runtime per process
 import torch.distributed as dist  # noqa: E402
 
 from moonshine_amd import api, scenes  # noqa: E402
-from moonshine_amd.hostinfo import usable_cores  # noqa: E402
+from moonshine_amd.hostinfo import usable_cores, source_hash  # noqa: E402
 
 HBM_PEAK = 8.0e12  # B/s, /opt/skills/guides/MI355X_MICROARCH.md "HBM3E peak BW"
 KERNELS = ("k_trace_closest", "k_trace_shadow", "k_shade")
@@ -196,8 +196,13 @@ def main():
             dist.init_process_group(backend)
 
     ctx = api.Context(device=dev, shard_index=rank, shard_count=world)
+    t_scene = time.perf_counter()
     sensor, lens = build_scene(ctx, a)
     ctx.set_pipeline(samples_per_run=1, max_bounces=8, env_samples_per_bounce=1, mesh_samples_per_bounce=1)
+    t_build = time.perf_counter()
+    ctx.render(sensor, lens, launches=0, readback=False)      # scene -> first launch: texture / material upload, BLAS + TLAS build, light tables (outside the timed region)
+    torch.cuda.synchronize()
+    build_ms = {"scene_calls_ms": (t_build - t_scene) * 1e3, "build_ms": (time.perf_counter() - t_build) * 1e3}
     ctx.set_profiling(kernel_events=False, traversal_counters=False)   # no events inside the timed region: per-kernel times come from the attribution pass below
     ctx.reserve(sensor, max(a.steps, a.warmup))   # wavefront state for the whole batch, allocated outside the timed region
     ptr, n4 = ctx.packed_film(sensor)
@@ -319,16 +324,24 @@ def main():
             # the §8(d) HBM figure exceeds the peak: most algorithmic bytes are re-reads that L2 / Infinity Cache serve, HBM is not what bounds this kernel.
             # What does: vector-instruction ISSUE.  achieved = issue cycles the kernel's instructions need per second (calibrated per class on this part),
             # peak = 1024 SIMDs x 2.4 GHz.
-            peak = cal["peak_simd_cycles_per_s"]
+            # peak at the clock the kernel ran at when its counters were taken (GRBM_GUI_ACTIVE / duration in the counters file), not the nominal 2.4 GHz
+            clock = (ck.get("memory_pipeline") or {}).get("clock_ghz") or 2.4
+            peak = 1024.0 * clock * 1e9
             ach = vc * (kun[dom] / nl) / (avg_ms * 1e-3)
+            lanes = ck["lanes_per_valu_instruction"]
             roof = {"bound": "valu", "kernel": dom, "achieved": ach / 1e9, "peak": peak / 1e9, "unit": "G SIMD-cycles/s", "frac": ach / peak,
                     "frac_low": valu_cycles(dom, low=True) * (kun[dom] / nl) / (avg_ms * 1e-3) / peak, "issue_cycles_per_unit_low": valu_cycles(dom, low=True),
                     "issue_cycles_per_unit": vc, "wave_instructions_per_unit": ck["valu_wave_instructions_per_unit"],
-                    "lanes_per_instruction": ck["lanes_per_valu_instruction"], "class_per_unit": ck["valu_class_per_unit"],
+                    "lanes_per_instruction": lanes, "lane_utilisation": lanes / 64.0, "useful_issue_frac": ach / peak * lanes / 64.0,
+                    "useful_issue_frac_low": valu_cycles(dom, low=True) * (kun[dom] / nl) / (avg_ms * 1e-3) / peak * lanes / 64.0,
+                    "peak_clock_ghz": clock, "class_per_unit": ck["valu_class_per_unit"],
                     "from": {"instruction_counts": "profiles/" + cnt_file, "cycles_per_class": "profiles/r03_valu_calibration.json"},
                     "hbm_algorithmic_frac": hbm["frac"], "hbm_algorithmic": hbm}
         else:
             roof = dict(hbm, bound="hbm", kernel=dom)
+        if cnt:
+            roof["counters_source_hash"] = cnt.get("source_hash"); roof["counters_steps"] = cnt.get("steps")
+            roof["counters_stale"] = cnt.get("source_hash") != source_hash()       # per-ray instruction counts were taken on other kernel sources than the ones running now
         roof.update({"units_per_launch": kun[dom] / nl, "avg_launch_ms": avg_ms, "launches": nl, "traffic": None,
                      "timing": "HIP events around every launch of the kernel in an extra pass of the same K steps with the kernels in stream order (exclusive durations)"})
         if ck:
@@ -350,11 +363,11 @@ def main():
             "repeats": R, "repeat_values": rates, "spread": (max(rates) - min(rates)) / statistics.median(rates),
             "msamples_per_s": samples / dt / 1e6,
             "rays": {"closest": closest, "shadow": shadow, "per_sample": rays / max(samples, 1.0)},
-            "roofline": roof,
+            "roofline": roof, "build": build_ms,
             "whole_path_roofline_frac": (rays / dt * fx["B_ray"] + samples / dt * (fx["B_shade"] + 32)) / HBM_PEAK / world,
             "kernel_ms_stream_order": {k: kms[k] for k in KERNELS}, "render_ms_stream_order": sa["render_ms"], "render_ms_per_repeat": st["render_ms"] / R,
             "kernel_hbm_algorithmic_frac": {k: unit_bytes[k] * kun[k] / max(kms[k] * 1e-3, 1e-12) / HBM_PEAK for k in KERNELS},
-            "kernel_valu_frac": ({k: valu_cycles(k) * kun[k] / max(kms[k] * 1e-3, 1e-12) / cal["peak_simd_cycles_per_s"] for k in KERNELS}
+            "kernel_valu_frac": ({k: valu_cycles(k) * kun[k] / max(kms[k] * 1e-3, 1e-12) / (1024.0e9 * ((cnt["kernels"][k].get("memory_pipeline") or {}).get("clock_ghz") or 2.4)) for k in KERNELS}
                                  if (cnt and cal and all("valu_class_per_unit" in cnt["kernels"].get(k, {}) for k in KERNELS)) else None),
             # for tools/profile_counters.py: what the counters of a rocprofv3 run of this command have to be divided by
             "profile_totals": {"closest_rays": warm["closest_rays"] + st["closest_rays"] + sa["closest_rays"], "shadow_rays": warm["shadow_rays"] + st["shadow_rays"] + sa["shadow_rays"],

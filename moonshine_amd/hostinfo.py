@@ -18,3 +18,17 @@ def usable_cores():
         except Exception:
             pass
     return n
+
+
+def source_hash():
+    """sha1 over the kernel sources (csrc/*.hip, csrc/*.h) and the build flags: what per-ray instruction counters depend on.  tools/profile_counters.py records it
+    in profiles/*_counters_*.json, bench.py compares it with the tree it runs from."""
+    import hashlib
+    here = os.path.dirname(os.path.abspath(__file__))
+    h = hashlib.sha1()
+    d = os.path.join(here, "csrc")
+    for f in sorted(os.listdir(d)):
+        if f.endswith((".hip", ".h")):
+            h.update(f.encode()); h.update(open(os.path.join(d, f), "rb").read())
+    h.update(open(os.path.join(here, "build.py"), "rb").read())
+    return h.hexdigest()[:16]

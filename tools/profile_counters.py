@@ -72,7 +72,9 @@ for r in csv.DictReader(open(stats)):
 lines += ["", "# the command's own line (HIP-event kernel times inside the timed region; under the profiler)", json.dumps(line)]
 open(os.path.join(ROOT, "profiles", "%s_kernel_stats_%s.txt" % (tag, scene)), "w").write("\n".join(lines) + "\n")
 
-out = {"command": open(G + "_cmd.txt").read().strip(), "unit": {"k_trace_closest": "closest-hit ray", "k_trace_shadow": "shadow ray", "k_shade": "path shaded (= closest-hit ray)"},
+sys.path.insert(0, ROOT)
+from moonshine_amd.hostinfo import source_hash      # noqa: E402  (ties the counters to the kernel sources they were taken on: bench.py flags them as stale otherwise)
+out = {"command": open(G + "_cmd.txt").read().strip(), "source_hash": source_hash(), "steps": line.get("steps"), "unit": {"k_trace_closest": "closest-hit ray", "k_trace_shadow": "shadow ray", "k_shade": "path shaded (= closest-hit ray)"},
        "fetch_correction": "FETCH_SIZE x2 (gfx950 tallies 128-B requests at 64 B; MI355X_MICROARCH.md HBM section), KB -> B x1024", "clock_ghz_assumed": 2.4, "kernels": {}}
 per = {}
 for sub in ("fetch", "write", "sq", "valu", "mem", "mem2"):
