@@ -11,6 +11,8 @@ except Exception:  # pragma: no cover
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
+if os.path.dirname(os.path.abspath(__file__)) not in sys.path:      # tests/assets.py, tests/io_common.py, the second sources
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 
 
 def pytest_configure(config):

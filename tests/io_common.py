@@ -1,4 +1,4 @@
-"""Shared helpers for the scene-I/O tests: asset generation (moonshine_amd.assets) and the importer→oracle shim."""
+"""Shared helpers for the scene-I/O tests: asset generation (tests/assets.py) and the importer→oracle shim."""
 import ctypes as C
 import math
 import os
@@ -6,7 +6,8 @@ import subprocess
 
 import numpy as np
 
-from moonshine_amd import assets, scenes
+import assets
+from moonshine_amd import scenes
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 _SHIM = None

@@ -38,7 +38,8 @@ def test_offline_with_a_tiled_mipmapped_environment(tmp_path):
     (what several HDRI tools produce; tinyexr's loader — exr.zig:109-110 — takes level 0 of those): identical output files, pixel for pixel"""
     glb, sky = str(tmp_path / "gallery.glb"), str(tmp_path / "sky.exr")
     io.write_gallery(glb, sky)
-    from moonshine_amd import api, assets
+    import assets
+    from moonshine_amd import api
     env = api.exr_load(sky)
     scan, tiled = str(tmp_path / "scan.exr"), str(tmp_path / "tiled.exr")
     open(scan, "wb").write(assets.exr_bytes(env, "RGB", "float", "zip"))
@@ -73,6 +74,29 @@ def test_gallery_glb_matches_oracle(tmp_path, orc, gpu_api, u32):
     gc.save_exr(0, out)
     back = gpu_api.exr_load(out)
     assert np.array_equal(bits(back[..., :3]), bits(imgs[0][..., :3]))
+
+
+@pytest.mark.parametrize("scene", ["gallery", "room"])
+def test_glb_import_rules_against_a_second_source_on_the_gpu(tmp_path, gpu_api, scene):
+    """MsneLoadGlb against tests/second_source_glb.py (World.zig:44-349 + Camera.zig:26-51 restated in Python, building the scene through the C ABI's scene calls):
+    two HIP contexts, one per way of getting the scene in, bit-identical films — the import semantics are no longer compared with themselves"""
+    import second_source_glb
+    glb, exr = str(tmp_path / "scene.glb"), str(tmp_path / "sky.exr")
+    if scene == "room":
+        io.write_bathroom_standin(glb, exr, spheres=16, order=3, tex=32, env=(128, 64))
+    else:
+        io.write_gallery(glb, exr, u32=True, interleaved=True)
+    films = []
+    for how in ("MsneLoadGlb", "second source"):
+        c = gpu_api.Context()
+        lens = c.load_glb(glb)[0] if how == "MsneLoadGlb" else second_source_glb.load(c, glb)
+        c.set_background_exr(exr)
+        s = c.create_sensor(320, 200)
+        c.set_pipeline(samples_per_run=1, max_bounces=8, env_samples_per_bounce=1, mesh_samples_per_bounce=1)
+        c.render(s, lens, launches=8)
+        films.append(c.sensor_data(s))
+    assert np.isfinite(films[0]).all() and float(films[0][..., :3].mean()) > 0.01
+    assert np.array_equal(bits(films[0]), bits(films[1])), "%d pixels differ" % (bits(films[0]) != bits(films[1])).any(-1).sum()
 
 
 def test_offline_cli(tmp_path, orc):

@@ -1,6 +1,7 @@
 """CPU tests of the rows either side of the hot path: the EXR codec and the GLB importer.
 The importer is exercised against the oracle through tests/shim (no GPU needed); the same files are loaded by the HIP
 library in tests/test_gpu_io.py."""
+import ctypes as C
 import math
 import os
 import struct
@@ -10,7 +11,8 @@ import sys
 import numpy as np
 import pytest
 
-from moonshine_amd import api, assets, scenes
+import assets
+from moonshine_amd import api, scenes
 from moonshine_amd.hostinfo import usable_cores
 from tests import io_common as io
 
@@ -60,7 +62,7 @@ def test_exr_piz_16_bit_wavelet_variant(tmp_path):
 @pytest.mark.parametrize("channels,ptype", [("RGB", "half"), ("RGBA", "float"), ("G", "half")])
 def test_exr_piz_reader_against_independent_encoder(tmp_path, name, channels, ptype):
     """PIZ (tinyexr reads it, exr.zig:109-110; the default of most HDRI tools): files from the independent numpy encoder in
-    moonshine_amd/assets.py — bitmap/LUT, wavelet (14- and 16-bit variants, odd sizes, partial last block of 32 lines), Huffman
+    tests/assets.py — bitmap/LUT, wavelet (14- and 16-bit variants, odd sizes, partial last block of 32 lines), Huffman
     with and without the run-length escape, and blocks stored raw because they did not shrink"""
     img = _piz_images()[name]
     p = str(tmp_path / "p.exr")
@@ -76,6 +78,26 @@ def test_exr_piz_reader_against_independent_encoder(tmp_path, name, channels, pt
         assert np.array_equal(bits(got), bits(ref)), (name, channels, ptype, rle)
     if name in ("smooth", "flat"):
         assert len(data) < 0.8 * len(assets.exr_bytes(img, channels, ptype, "none"))     # ... and the encoder does compress
+
+
+@pytest.mark.parametrize("name,channels,ptype", [("smooth", "RGB", "half"), ("flat", "RGBA", "float"), ("odd", "RGB", "float"), ("tiny", "G", "half"), ("noisy", "RGB", "half"), ("wide16", "RGB", "float")])
+def test_piz_encoder_against_a_second_decoder(name, channels, ptype):
+    """the numpy PIZ ENCODER of tests/assets.py pins the product's PIZ reader; this pins the encoder itself with a decoder that is neither the product's nor the
+    encoder's author's first reading: tests/piz_reference.py walks the stream the way OpenEXR's reference implementation does (hufUncompress, wav2Decode with
+    wdec14 / wdec16, reverse lookup table) — every stored word must come back, with and without the run-length escape"""
+    import piz_reference
+    imgs = _piz_images()
+    img = imgs["wide"][:34, :256] if name == "wide16" else imgs[name]            # (a slice of the 16-bit-wavelet image: the pure-Python decoder is slow)
+    if name == "wide16":
+        assert len(np.unique(np.frombuffer(np.ascontiguousarray(img[:32, :, :3]).tobytes(), "<u2"))) >= (1 << 14)      # more than 2^14 distinct words in a block: wdec16
+    for rle in (True, False):
+        data = assets.exr_bytes(img, channels, ptype, "piz", piz_rle=rle)
+        got = piz_reference.exr_piz_decode(data)
+        assert sorted(got) == sorted(channels)
+        for c in channels:
+            ref = img[..., "RGBA".index(c)]
+            ref = ref.astype(np.float16) if ptype == "half" else ref
+            assert got[c].dtype == ref.dtype and np.array_equal(got[c].view(np.uint16 if ptype == "half" else np.uint32), ref.view(np.uint16 if ptype == "half" else np.uint32)), (name, c, rle)
 
 
 def test_exr_writer_layout_and_roundtrip(tmp_path):
@@ -119,7 +141,7 @@ def test_exrdiff_tool(tmp_path):
 def test_exr_tiled_reader_against_independent_writer(tmp_path, tiles, levels, channels, ptype, comp, order):
     """single-part TILED files (what several HDRI tools write by default; tinyexr's LoadEXRFromMemory, exr.zig:109-110, reads them): tiles smaller
     and larger than the image, partial edge tiles, every compression, mip-mapped files (only the full-resolution level is read), chunks stored
-    bottom-up — against the numpy writer in moonshine_amd/assets.py, and equal to the scanline file of the same picture"""
+    bottom-up — against the numpy writer in tests/assets.py, and equal to the scanline file of the same picture"""
     rs = np.random.default_rng(11)
     yy, xx = np.mgrid[0:45, 0:71]
     img = np.stack([np.sin(xx / 7.0) + 1.5, (yy / 45.0) ** 2 * 9.0, rs.random((45, 71)) * 3.0, np.full((45, 71), 0.75)], -1).astype(np.float32)
@@ -196,6 +218,35 @@ def test_config0_single_triangle_glb_on_the_cpu_integrator(tmp_path, orc):
     d.set_pipeline(samples_per_run=1, max_bounces=1, env_samples_per_bounce=1, mesh_samples_per_bounce=0)
     d.render(ds, dl)
     assert rel_l2(img, d.sensor_data(ds)) < 1e-6
+
+
+@pytest.mark.parametrize("scene", ["gallery", "gallery_u32_interleaved", "room"])
+def test_glb_import_rules_against_a_second_source(tmp_path, orc, scene):
+    """the importer (moonshine_amd/host/glb.cpp, here feeding the oracle through tests/shim) against tests/second_source_glb.py — a Python statement of
+    World.zig:44-349 and Camera.zig:26-51 that reads the GLB with json / struct / Pillow and builds the scene straight through the scene API: material rules (normal map
+    R,G; sRGB emissive and base colour with alpha 255; transmission -> glass; metallicRoughness R = metalness, G = roughness; (0,1) Lambert / (1,0) mirror / constants),
+    KHR_materials_{ior, transmission, emissive_strength}, the "Emitter" name prefix, one mesh per primitive per node, node hierarchies with matrix and TRS, the (x, z, y)
+    row swap, the first camera.  Same scene -> the oracle's films are bit-identical."""
+    import second_source_glb
+    glb, exr = str(tmp_path / "scene.glb"), str(tmp_path / "sky.exr")
+    if scene == "room":
+        io.write_bathroom_standin(glb, exr, spheres=10, order=2, tex=16, env=(64, 32))
+    else:
+        io.write_gallery(glb, exr, u32=scene != "gallery", interleaved=scene != "gallery")
+    films = []
+    for how in ("importer", "second source"):
+        c = orc.Context(threads=usable_cores())
+        if how == "importer":
+            lens, _ = io.oracle_load(orc, c, glb, exr)
+        else:
+            lens = second_source_glb.load(c, glb)
+            assert io.shim(orc).ShimSetBackgroundExr(C.c_void_p(c.h), exr.encode()) == 0
+        s = c.create_sensor(96, 64)
+        c.set_pipeline(samples_per_run=1, max_bounces=6, env_samples_per_bounce=1, mesh_samples_per_bounce=1)
+        c.render(s, lens, launches=3)
+        films.append(c.sensor_data(s))
+    assert np.isfinite(films[0]).all() and float(films[0][..., :3].mean()) > 0.01
+    assert np.array_equal(bits(films[0]), bits(films[1])), "%d pixels differ" % (bits(films[0]) != bits(films[1])).any(-1).sum()
 
 
 def rel_l2(a, b):

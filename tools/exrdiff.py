@@ -1,15 +1,16 @@
 """Image-level parity between two OpenEXR files: relative per-pixel L2 ‖A − B‖₂ / ‖B‖₂ over RGB —
 the north star's figure (< 1e-4 against the reference renderer) — plus max abs error and the worst pixel.
     python tools/exrdiff.py ours.exr reference.exr [--tol 1e-4]
-Pure Python (moonshine_amd/assets.py:exr_decode): runs on a box that has the reference renderer but not this library."""
+Pure Python (tests/assets.py:exr_decode): runs on a box that has the reference renderer but not this library."""
 import argparse
 import os
 import sys
 
 import numpy as np
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from moonshine_amd.assets import exr_decode  # noqa: E402
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+from assets import exr_decode  # noqa: E402
 
 
 def main():
