@@ -4,10 +4,13 @@ import math
 import os
 import subprocess
 
+import sys
+
 import numpy as np
 
-import assets
-from moonshine_amd import scenes
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))      # (tools/ import this module as tests.io_common)
+import assets  # noqa: E402
+from moonshine_amd import scenes  # noqa: E402
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 _SHIM = None

@@ -1,4 +1,4 @@
-"""Turns the scratch output of tools/profile_round3.sh TAG SCENE (gpurun_out/TAG_SCENE_{trace,fetch,write,sq}) into the files
+"""Turns the scratch output of tools/profile_round.sh TAG SCENE (gpurun_out/TAG_SCENE_{trace,fetch,write,sq}) into the files
 committed under profiles/ and read by bench.py:   python tools/profile_counters.py TAG SCENE
 
   profiles/TAG_kernel_stats_SCENE.txt   rocprofv3 --kernel-trace --stats table of the bench command + its JSON line
@@ -99,7 +99,7 @@ for k in KERNELS:
     e["vmem_rd_instructions_per_unit"] = c["SQ_INSTS_VMEM_RD"] / su[k]
     e["wave_cycles_split"] = {"active": c["SQ_ACTIVE_INST_ANY"] / max(c["SQ_WAVE_CYCLES"], 1.0), "wait_inst": c["SQ_WAIT_INST_ANY"] / max(c["SQ_WAVE_CYCLES"], 1.0),
                               "wait_any": c["SQ_WAIT_ANY"] / max(c["SQ_WAVE_CYCLES"], 1.0)}
-    if "valu" in per:   # instruction classes (tools/profile_round3.sh pass "valu"): what bench.py's VALU roofline prices with profiles/r03_valu_calibration.json
+    if "valu" in per:   # instruction classes (tools/profile_round.sh pass "valu"): what bench.py's VALU roofline prices with profiles/r03_valu_calibration.json
         v, _, _, u = per["valu"]
         e["valu_class_per_unit"] = {c: v[k]["SQ_INSTS_VALU_" + c] / u[k] for c in ("FMA_F32", "MUL_F32", "ADD_F32", "INT32", "CVT", "TRANS_F32")}
         e["salu_instructions_per_unit"] = v[k]["SQ_INSTS_SALU"] / u[k]

@@ -1,4 +1,4 @@
-# usage (on the GPU box): bash tools/profile_round3.sh TAG SCENE [PASSES] [extra bench.py args]
+# usage (on the GPU box): bash tools/profile_round.sh TAG SCENE [PASSES] [extra bench.py args]
 #   PASSES = comma list out of trace,fetch,write,sq,valu,mem,mem2 (default: all).  Kernel trace + PMC passes of
 #   `python3 bench.py --scene SCENE --no-cpu-baseline --repeats 2 ...`, each in its OWN run (gpurun refuses --pmc combined with
 #   sys/hip traces; the counters of one pass have to fit the hardware's per-block limits).  MSNE_SERIAL=1: kernels in stream order, so

@@ -22,8 +22,10 @@ for name, kw in (("S2 500 x 10242 verts", dict(extent=(320, 180), dims=(10, 10, 
     upd = timed(lambda: c.render(s, l))
     rs = np.random.default_rng(1); n_inst = kw["dims"][0] * kw["dims"][1] * kw["dims"][2]
     many = rs.choice(n_inst, n_inst // 10, replace=False)
-    for h in many:
-        T2 = T.copy(); T2[:, 3] = rs.normal(size=3) * 5.0 + (0, 0, 5)
+    dx, dy, dz = kw["dims"]
+    for h in many:     # every moved instance stays near its own grid cell (scenes.s2's layout): the scene keeps its character, only the TLAS changes
+        ix, iy, iz = int(h) % dx, (int(h) // dx) % dy, int(h) // (dx * dy)
+        T2 = T.copy(); T2[:, 3] = np.array([(ix - (dx - 1) / 2) * 2.5, (iy - (dy - 1) / 2) * 2.5, 1.0 + iz * 2.5]) + rs.normal(size=3) * 0.5
         c.set_instance_transform(int(h), T2)
     upd_many = timed(lambda: c.render(s, l))
     many_stats = c.accel_stats()
