@@ -577,17 +577,17 @@ def test_s1_full_frame_matches_oracle(orc, s1_full):
     assert counters == {k: v for k, v in oc.counters().items() if k in ("closest_rays", "shadow_rays", "samples")}
 
 
-@pytest.mark.parametrize("which", ["s1_sky", "s2"])
-def test_other_full_size_configs_match_oracle(orc, gpu_api, which):
-    """BASELINE.json's other full-size workloads, every pixel of one launch at 1920x1080: S1 under the 512x256 sky+sun
-    environment (mip descent) and S2 (10.24 M instanced triangles: TLAS + 500 transformed instances)"""
-    build = (lambda c: scenes.s1(c, extent=(1920, 1080), env="sky")) if which == "s1_sky" else (lambda c: scenes.s2(c, extent=(1920, 1080)))
+@pytest.mark.parametrize("which,launches", [("s1_sky", 3), ("s2", 3), ("s1", 8)])
+def test_other_full_size_configs_match_oracle(orc, gpu_api, which, launches):
+    """BASELINE.json's full-size workloads, every pixel at 1920x1080 over several launches in one batch: S1 under the 512x256 sky+sun environment (mip descent),
+    S2 (10.24 M instanced triangles: TLAS + 500 transformed instances), and S1 itself for eight launches (70 M rays): bit-identical films, identical ray counts"""
+    build = {"s1_sky": lambda c: scenes.s1(c, extent=(1920, 1080), env="sky"), "s2": lambda c: scenes.s2(c, extent=(1920, 1080)), "s1": lambda c: scenes.s1(c, extent=(1920, 1080))}[which]
     gc = gpu_api.Context(); oc = orc.Context(threads=usable_cores())
     sg, lg = build(gc); so, lo = build(oc)
     for c in (gc, oc):
         c.set_pipeline(samples_per_run=1, max_bounces=8, env_samples_per_bounce=1, mesh_samples_per_bounce=1)
-    gc.render(sg, lg, launches=1); oc.render(so, lo, launches=1)
-    assert_film_equal(gc.sensor_data(sg), oc.sensor_data(so), which + " 1920x1080 full frame")
+    gc.render(sg, lg, launches=launches); oc.render(so, lo, launches=launches)
+    assert_film_equal(gc.sensor_data(sg), oc.sensor_data(so), "%s 1920x1080 full frame, %d launches" % (which, launches))
     assert gc.counters() == {k: v for k, v in oc.counters().items() if k in ("closest_rays", "shadow_rays", "samples")}
 
 
@@ -1414,4 +1414,19 @@ def test_bench_starts_its_own_ranks(tmp_path):
     assert lines["ranks3"]["n_gpus"] == 3 and lines["ranks3"]["ranks_seen"] == 3
     assert lines["group"]["n_gpus"] == 2 and lines["group"]["ranks_seen"] == 2 and lines["group"]["transport"] == ("copy" if shared else "rccl")
     assert lines["ranks"]["devices_seen"] == (1 if shared else 2)
+
+
+def test_traversal_lane_use_counters(gpu_api):
+    """MsneGetTraversalLaneUse (the STATS instantiation's per-iteration lane histogram, tools/lane_use.py): consistent with itself and with the visit counters"""
+    c = gpu_api.Context()
+    s, l = scenes.s2(c, extent=(160, 90), dims=(4, 4, 3), order=3)
+    c.set_pipeline(samples_per_run=1, max_bounces=4, env_samples_per_bounce=1, mesh_samples_per_bounce=1)
+    c.set_profiling(True, True)
+    c.render(s, l, launches=2, readback=False)
+    u, t = c.traversal_lane_use(), c.traversal_counters()
+    for k, visits, tests in (("closest", t["closest_node_visits"], t["closest_tri_tests"]), ("shadow", t["shadow_node_visits"], t["shadow_tri_tests"])):
+        x = u[k]
+        assert x["iterations"] > 0 and x["node_body"] == visits and x["tri_body"] == tests                       # a lane in the node / triangle body = one visit / one test
+        assert x["with_ray"] <= 64 * x["iterations"] and x["node_body"] + x["tri_body"] + x["space_body"] >= x["with_ray"] - x["no_body"] - 1
+        assert x["space_body"] > 0 and x["iter_space"] <= x["iterations"] and x["wait_space"] >= 0                # a two-level scene: lanes do change space
 

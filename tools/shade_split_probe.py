@@ -4,7 +4,8 @@ phase A: attributes, textures, emission, termination; phase B: queue reservation
 budget and at 128 registers (4 waves per SIMD).  Compile-time only (hipcc cross-compiles without a GPU):   python tools/shade_split_probe.py"""
 import os, re, subprocess, sys, tempfile
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-s = open(os.path.join(ROOT, "moonshine_amd", "csrc", "integrator.hip")).read()
+# (round 3's kernel: round 4 turned k_shade into a template over path categories — profiles/r04_shade_specialised.txt — and this probe edits the source by pattern)
+s = subprocess.check_output(["git", "-C", ROOT, "show", "ec77618:moonshine_amd/csrc/integrator.hip"], text=True)
 
 
 def rep(old, new):
