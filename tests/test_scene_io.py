@@ -155,6 +155,14 @@ def test_exr_tiled_reader_against_independent_writer(tmp_path, tiles, levels, ch
     if "A" not in channels:
         ref[..., 3] = 1.0
     assert np.array_equal(bits(got), bits(ref)) and np.array_equal(bits(got), bits(api.exr_load(q)))
+    # ... and a second reader (tests/exr_reference.py: the file-layout document read from the other side — it insists on the prescribed order of the offset
+    # table and on clipped edge tiles) gets the same pixels out of both files
+    import exr_reference
+    for blob in (data, open(q, "rb").read()):
+        dec = exr_reference.read(blob)
+        assert sorted(dec) == sorted(channels)
+        for ch in channels:
+            assert np.array_equal(bits(dec[ch].astype(np.float32)), bits(ref[..., "RGBA".index(ch)]))
 
 
 def test_exr_tiled_files_that_must_be_rejected(tmp_path):
