@@ -675,7 +675,7 @@ static void sweep_radix(hipStream_t s, uint32_t*& ka, uint32_t*& kb, uint32_t*& 
 static int bits_for(uint32_t values) { int b = 0; while ((1ull << b) < values) b++; return b; }
 
 static bool sweep_on_gpu(BuildScratch& S, hipStream_t s, uint32_t n, uint32_t nseg, uint32_t c, uint32_t node_base, const uint32_t* ra, const Box* ba, const uint32_t* sa,
-                         BinTree t, bool rebuild_wanted, uint32_t* root_refs, Box* root_boxes) {
+                         BinTree t, bool rebuild_wanted, uint32_t* root_refs, Box* root_boxes, bool* no_memory) {
     static const bool timing = getenv("MSNE_BUILD_TIMING") != nullptr;
     auto t_prev = std::chrono::steady_clock::now();
     double t_ms[4] = { 0, 0, 0, 0 };   // ownership + element sort, levels, bottom-up, roots
@@ -703,10 +703,15 @@ static bool sweep_on_gpu(BuildScratch& S, hipStream_t s, uint32_t n, uint32_t ns
     const size_t o_lc = carve((size_t)std::max(P0, 1u) * 4), o_pl = carve((size_t)std::max(P0, 1u) * 4), o_nc = carve((size_t)std::max(node_base, 1u) * 4), o_pn = carve((size_t)std::max(node_base, 1u) * 4), o_no = carve((size_t)std::max(node_base, 1u) * 4);
     const size_t o_psort = carve((size_t)std::max(P0, 1u) * 4), o_pgrp = carve((size_t)std::max(P0, 1u) * 4);
     const size_t o_gsize = carve(((size_t)G + 1) * 4), o_rref = carve((size_t)nseg * 4), o_rbox = carve((size_t)nseg * sizeof(Box));
+    static const size_t arena_limit = [] { const char* e = getenv("MSNE_SWEEP_ARENA_LIMIT"); return e ? (size_t)atoll(e) : ~(size_t)0; }();   // (tests: pretend the working set does not fit)
     if (off > S.arena_bytes) {
         if (S.arena) (void)hipFree(S.arena);
         S.arena = nullptr; S.arena_bytes = 0;
-        HIPCHK(hipMalloc(&S.arena, off));
+        if (off > arena_limit || hipMalloc(&S.arena, off) != hipSuccess) {   // nothing of the tree has been touched yet: the caller lets PLOC finish the build
+            (void)hipGetLastError(); S.arena = nullptr;
+            if (no_memory) *no_memory = true;
+            return false;
+        }
         S.arena_bytes = off;
     }
     char* A = (char*)S.arena;
@@ -867,7 +872,8 @@ static bool build_from_boxes(BuildScratch& S, hipStream_t s, uint32_t n, uint32_
         HIPCHK(hipMemcpyAsync(S.totals, &st0, sizeof st0, hipMemcpyHostToDevice, s));
         uint32_t c = n, round = 0, node_base = 0;
         // (each round at most halves the clusters: `group` rounds from c leave at least c >> group)
-        const uint32_t stop = std::max(nseg, top_clusters(n, nseg));
+        uint32_t stop = std::max(nseg, top_clusters(n, nseg));
+        auto ploc_down_to = [&](uint32_t stop) -> bool {
         while (c > stop) {
             const uint32_t nb = (c + PLOC_BLOCK - 1) / PLOC_BLOCK;
             uint32_t group = PLOC_GROUP;
@@ -886,14 +892,28 @@ static bool build_from_boxes(BuildScratch& S, hipStream_t s, uint32_t n, uint32_
             if (now.stuck || now.c >= c || now.c < nseg) { fprintf(stderr, "moonshine_amd: PLOC made no progress\n"); return false; }
             c = now.c; node_base = now.node_base;
         }
+        return true; };
+        if (!ploc_down_to(stop)) return false;
         phase(1);
+        bool swept = false;
         if (c > nseg) {   // the rest top-down: a surface-area sweep over every cluster's primitives and over the clusters themselves (bvh_sweep.h)
             static const bool rebuild_wanted = [] { const char* e = getenv("MSNE_SAH_BOTTOM"); return e ? atoi(e) != 0 : true; }();
             const char* where = getenv("MSNE_TOPDOWN");                        // "host": the sequential restatement (tests); read at every build
             const bool on_host = where && strcmp(where, "host") == 0;
             if (on_host) { if (!sweep_on_host(S, s, n, nseg, c, node_base, ra, ba, sa, t, rebuild_wanted, root_refs.data(), root_boxes)) return false; }
-            else if (!sweep_on_gpu(S, s, n, nseg, c, node_base, ra, ba, sa, t, rebuild_wanted, root_refs.data(), root_boxes)) return false;
-        } else {
+            else {
+                bool no_memory = false;
+                if (!sweep_on_gpu(S, s, n, nseg, c, node_base, ra, ba, sa, t, rebuild_wanted, root_refs.data(), root_boxes, &no_memory)) {
+                    if (!no_memory) return false;
+                    // the sweep's working set (~100 B per position) does not fit: PLOC carries on to the roots — a slightly worse tree instead of a failed build
+                    fprintf(stderr, "moonshine_amd: no device memory for the top-down stages of a %u-primitive build; PLOC builds it whole\n", n);
+                    stop = nseg;
+                    if (!ploc_down_to(stop)) return false;
+                } else swept = true;
+            }
+            if (on_host) swept = true;
+        }
+        if (!swept) {   // PLOC went down to one cluster per tree
             HIPCHK(hipMemcpyAsync(root_refs.data(), ra, (size_t)nseg * 4, hipMemcpyDeviceToHost, s));
             HIPCHK(hipMemcpyAsync(root_boxes, ba, (size_t)nseg * sizeof(Box), hipMemcpyDeviceToHost, s));
             HIPCHK(hipStreamSynchronize(s));

@@ -997,6 +997,20 @@ def test_fine_morton_codes(tmp_path):
 
 
 @pytest.mark.gpu
+def test_builder_without_memory_for_the_sweep(tmp_path):
+    """the top-down sweep keeps ~100 B of working set per position; when that does not fit ($MSNE_SWEEP_ARENA_LIMIT pretends so) PLOC carries the build on to the
+    roots instead of failing it: S1 and the instanced S2 render like the oracle, and the library says what it did"""
+    import subprocess, sys, os
+    from moonshine_amd import api
+    script = tmp_path / "arena_worker.py"
+    script.write_text(SPILL_WORKER)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, str(script), root, api.LIB_PATH], capture_output=True, text=True, timeout=900, env=dict(os.environ, MSNE_SWEEP_ARENA_LIMIT="4096"))
+    assert out.returncode == 0 and "SPILL_OK" in out.stdout, out.stdout[-1500:] + out.stderr[-3000:]
+    assert "PLOC builds it whole" in out.stderr
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("top", ["0", "48"])
 def test_builder_stages(tmp_path, top):
     """the BVH builder hands PLOC's last 4096 clusters to a top-down surface-area build on the host and rebuilds every cluster the same way; the test scenes have fewer
