@@ -278,6 +278,10 @@ void MsneSetProfiling(HdMoonshine*, int kernel_events, int traversal_counters);
 void MsneGetAccelStats(HdMoonshine*, uint64_t out[2]);
 /* bytes of texture data the context keeps in HBM: every texture in the format it was created with (MaterialManager.zig:351-390), each rounded up to 16 B */
 uint64_t MsneGetTexelPoolBytes(HdMoonshine*);
+/* How acceleration structures are built from the next (re)build on.  The reference asks the driver for prefer_fast_trace builds everywhere (Accel.zig:112,259,445,645)
+   and so does the default (1): one surface-area sweep over every primitive.  0 = prefer a fast BUILD (agglomerative clustering only, no sweep: about a third of the
+   build time, ~4 % fewer rays per second) — for editing sessions that rebuild the TLAS every frame.  Results do not depend on it. */
+void MsneSetBuildQuality(HdMoonshine*, int prefer_fast_trace);
 int MsneGetTraversalCounters(HdMoonshine*, uint64_t out[20]); /* [0..3] closest {nodes,tris}, shadow {nodes,tris}; [4..19] wave-cycle profiles */
 /* lane use of the traversal loop with the counters on, summed over wave iterations: out[0..11] closest-hit kernel, out[12..23] any-hit kernel —
    {iterations, lanes with a ray, lanes in the node / triangle / space body, lanes waiting for the space body, lanes with a ray that ran no body,

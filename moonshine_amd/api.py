@@ -134,6 +134,7 @@ SYMBOLS = [
     ("MsneSetProfiling", None, [_vp, C.c_int, C.c_int]),
     ("MsneGetTexelPoolBytes", C.c_uint64, [_vp]),
     ("MsneGetAccelStats", None, [_vp, C.POINTER(C.c_uint64)]),
+    ("MsneSetBuildQuality", None, [_vp, C.c_int]),
     ("MsneGetTraversalCounters", C.c_int, [_vp, C.POINTER(C.c_uint64)]),
     ("MsneGetTraversalLaneUse", C.c_int, [_vp, C.POINTER(C.c_uint64)]),
     ("MsneTraceRays", C.c_int, [_vp, _vp, _u32, C.c_int, _vp, _vp]),
@@ -384,6 +385,9 @@ class Context:
 
     def texel_pool_bytes(self):
         return int(self.L.MsneGetTexelPoolBytes(self.h))
+
+    def set_build_quality(self, prefer_fast_trace=True):
+        self.L.MsneSetBuildQuality(self.h, int(prefer_fast_trace))
 
     def set_profiling(self, kernel_events=True, traversal_counters=False):
         self.L.MsneSetProfiling(self.h, int(kernel_events), int(traversal_counters))

@@ -543,13 +543,16 @@ struct BuildScratch {
     uint2* bbase = nullptr;
     uint32_t *seg = nullptr, *csa = nullptr, *csb = nullptr;                   // batched builds: segment of every primitive / cluster (ping-pong)
     void* arena = nullptr; size_t arena_bytes = 0;                             // the top-down stages' working set (bvh_sweep.h), kept between builds
+    bool fast_builds = false;                                                  // MsneSetBuildQuality(ctx, 0): PLOC to the roots, no sweep (an editing session's rebuilds)
     void release() {
         if (arena) (void)hipFree(arena);
         arena = nullptr; arena_bytes = 0;
         void* p[] = { boxes, sorted, ibox, keys, keys2, idx, idx2, ghist, bounds, left, right, count, cost, split, wa, wb, next_count,
                       cba, cbb, cra, crb, nn, pflags, bsum, totals, bbase, seg, csa, csb };
         for (void* q : p) if (q) (void)hipFree(q);
+        const bool keep = fast_builds;
         *this = BuildScratch();
+        fast_builds = keep;
     }
     bool reserve(uint32_t n) {
         if (n <= cap) return true;
@@ -578,13 +581,15 @@ BuildScratch* bvh_scratch_create() { return new (std::nothrow) BuildScratch(); }
 void bvh_scratch_destroy(BuildScratch* s) { if (s) { s->release(); delete s; } }
 void bvh_scratch_release(BuildScratch* s) { if (s) s->release(); }
 size_t bvh_scratch_capacity(const BuildScratch* s) { return s ? s->cap : 0; }
+void bvh_scratch_set_fast(BuildScratch* s, bool fast) { if (s) s->fast_builds = fast; }
 
 // How many clusters PLOC leaves for the top-down stages (0: none, PLOC merges down to the roots; >= n: no PLOC at all, ONE sweep over every primitive).  $MSNE_SAH_TOP overrides.
 // The sweep over everything makes the best trees (S1 5870 against 5770 Mrays/s with 4096 clusters and 5627 with PLOC alone, S2 3423 / 3391 / 3335, a 16 M-triangle
 // scene 3848 / 3808: profiles/r04_sah_top_sweep.txt) and on the GPU it is cheap enough to be the rule: 10 ms for a million triangles (7 with clusters), 148 ms for
 // 16 M (94) — the reference asks for prefer_fast_trace builds everywhere (Accel.zig:112,259,445,645).  Beyond 32 M primitives in one build PLOC goes first again
 // (the sweep keeps ~100 B per position).
-static uint32_t top_clusters(uint32_t n, uint32_t nseg) {
+static uint32_t top_clusters(uint32_t n, uint32_t nseg, bool fast) {
+    if (fast) return 0u;
     static const long long forced = [] { const char* e = getenv("MSNE_SAH_TOP"); return e ? atoll(e) : -1ll; }();
     if (forced >= 0) { const uint32_t m = (uint32_t)std::min<long long>(forced, 0x7fffffffll); return (m < 2 || nseg > m / 2) ? 0u : m; }
     if (n <= (32u << 20)) return n;
@@ -872,7 +877,7 @@ static bool build_from_boxes(BuildScratch& S, hipStream_t s, uint32_t n, uint32_
         HIPCHK(hipMemcpyAsync(S.totals, &st0, sizeof st0, hipMemcpyHostToDevice, s));
         uint32_t c = n, round = 0, node_base = 0;
         // (each round at most halves the clusters: `group` rounds from c leave at least c >> group)
-        uint32_t stop = std::max(nseg, top_clusters(n, nseg));
+        uint32_t stop = std::max(nseg, top_clusters(n, nseg, S.fast_builds));
         auto ploc_down_to = [&](uint32_t stop) -> bool {
         while (c > stop) {
             const uint32_t nb = (c + PLOC_BLOCK - 1) / PLOC_BLOCK;

@@ -38,6 +38,7 @@ void launch_env_quads(hipStream_t, const float*, const uint32_t*, float4*, const
 struct BlasGeo { const float* positions; const uint32_t* indices; uint32_t tri_offset, tri_count, geo, inst; const float* normals; const float* texcoords; uint32_t indexed, attr_count; };
 struct BuildScratch;   // per-context build buffers (bvh_build.hip)
 BuildScratch* bvh_scratch_create();
+void bvh_scratch_set_fast(BuildScratch*, bool);
 void bvh_scratch_destroy(BuildScratch*);
 void bvh_scratch_release(BuildScratch*);
 size_t bvh_scratch_capacity(const BuildScratch*);
@@ -137,6 +138,7 @@ struct HdMoonshine {
     DevBuf<uint2> d_tlas_node_parent, d_tlas_item_parent; uint32_t tlas_node_begin = 0, tlas_node_end = 0, tlas_item_begin = 0;
     std::vector<InstanceRec> h_irec;
     uint64_t n_rebuilds = 0, n_tlas_updates = 0; uint32_t refits_since_rebuild = 0;
+    bool fast_builds = false;                      // MsneSetBuildQuality
     bool refit_tlas();
     std::vector<AliasEntry> h_alias;
     // environment
@@ -388,6 +390,7 @@ bool HdMoonshine::rebuild_accel() {
             for (size_t i = 0; i < N; i++) if (in_world[i]) for (uint32_t m : keys[i]) new_tris += meshes[m]->index_count;
     }
     if (!build_scratch && !(build_scratch = bvh_scratch_create())) { fail("out of host memory"); return false; }
+    bvh_scratch_set_fast(build_scratch, fast_builds);
     if (!d_build_counters.p) { if (!d_build_counters.alloc(4)) { fail("out of device memory"); return false; } CHECK_HIP(this, hipMemsetAsync(d_build_counters.p, 0, 16, stream)); }
     const size_t need_tris = (size_t)blas_tris_end + new_tris;
     const size_t need_nodes = (size_t)blas_nodes_end + new_tris + 2 * N + 64;
@@ -1112,6 +1115,7 @@ void MsneSetProfiling(HdMoonshine* c, int kernel_events, int traversal_counters)
     if (kernel_events == 2) { if (c->serial_saved == -2) c->serial_saved = c->serial_mode; c->serial_mode = 1; }
     else if (c->serial_saved != -2) { c->serial_mode = c->serial_saved; c->serial_saved = -2; }
 }
+void MsneSetBuildQuality(HdMoonshine* c, int prefer_fast_trace) { LOCK(c); c->fast_builds = prefer_fast_trace == 0; }   // takes effect at the next (re)build
 void MsneGetAccelStats(HdMoonshine* c, uint64_t out[2]) { LOCK(c); out[0] = c->n_rebuilds; out[1] = c->n_tlas_updates; }   // acceleration-structure rebuilds, in-place TLAS updates
 uint64_t MsneGetTexelPoolBytes(HdMoonshine* c) {   // bytes of texels resident in HBM (after the next upload: what has been created so far)
     LOCK(c);

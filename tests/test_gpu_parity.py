@@ -1444,3 +1444,24 @@ def test_traversal_lane_use_counters(gpu_api):
         assert x["with_ray"] <= 64 * x["iterations"] and x["node_body"] + x["tri_body"] + x["space_body"] >= x["with_ray"] - x["no_body"] - 1
         assert x["space_body"] > 0 and x["iter_space"] <= x["iterations"] and x["wait_space"] >= 0                # a two-level scene: lanes do change space
 
+
+def test_build_quality_switch(orc, gpu_api):
+    """MsneSetBuildQuality(ctx, 0): the next builds skip the surface-area sweep (agglomerative clustering to the roots) — other trees (fewer or more wide nodes),
+    the same film and the same hit records as the oracle; switching back restores the default trees"""
+    oc = orc.Context(threads=8)
+    so, lo = scenes.s2(oc, extent=(96, 54), dims=(4, 4, 3), order=3)
+    oc.set_pipeline(samples_per_run=1, max_bounces=4, env_samples_per_bounce=1, mesh_samples_per_bounce=1)
+    oc.render(so, lo, launches=2)
+    counts = []
+    for fast_trace in (True, False, True):
+        gc = gpu_api.Context()
+        gc.set_build_quality(prefer_fast_trace=fast_trace)
+        sg, lg = scenes.s2(gc, extent=(96, 54), dims=(4, 4, 3), order=3)
+        gc.set_pipeline(samples_per_run=1, max_bounces=4, env_samples_per_bounce=1, mesh_samples_per_bounce=1)
+        gc.render(sg, lg, launches=2)
+        assert_film_equal(gc.sensor_data(sg), oc.sensor_data(so), "build quality %s" % fast_trace)
+        _check_rays(oc, gc, _random_rays(500, 3, radius=12.0))
+        nodes = gc.read_bvh()[0]
+        counts.append((len(nodes), hash(nodes.tobytes())))
+    assert counts[0][0] == counts[2][0] and counts[0][0] != counts[1][0] or counts[0][1] != counts[1][1]
+
