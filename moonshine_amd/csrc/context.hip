@@ -26,7 +26,7 @@ void launch_trace_probe(hipStream_t, int, const SceneView&, const float*, uint32
 size_t trace_spill_words(int grid);
 int trace_blocks_per_cu();
 void launch_raygen(hipStream_t, int, const ShardView&, const CameraConsts&, const PipelineOpts&, uint32_t, uint32_t, const PathState&, BounceCounters*);
-void launch_shade(hipStream_t, int, const SceneView&, const PipelineOpts&, const PathState&, const HitBuf&, const PathState&, const ShadowQueue&, const float4*, float4*, BounceCounters*, bool);
+void launch_shade(hipStream_t, int, const SceneView&, const PipelineOpts&, const PathState&, const HitBuf&, const PathState&, const ShadowQueue&, const float4*, float4*, BounceCounters*, bool, bool);
 void launch_account(hipStream_t, const BounceCounters*, uint32_t, Totals*);
 void launch_light_tris(hipStream_t, const SceneView&, uint32_t, uint32_t, LightTri*);
 void launch_film(hipStream_t, int, const ShardView&, const PipelineOpts&, const float4*, uint32_t, uint32_t, int, int, uint32_t, float4*, float4*);
@@ -732,6 +732,11 @@ bool HdMoonshine::render(uint32_t sensor, uint32_t lens, uint32_t launches, bool
     }
     const SceneView sv = scene_view();
     const CameraConsts cam = make_camera(lenses[lens], s->extent.width, s->extent.height);
+    // every texture 1x1 (constant material parameters: the glTF factors of World.zig:44-228, every synthetic scene): k_shade without the bilinear sampler
+    static const int force_tex = [] { const char* e = getenv("MSNE_SHADE_TEXTURED"); return e ? atoi(e) : -1; }();
+    bool textured = false;
+    for (const auto& t : textures) if (t.w != 1 || t.h != 1) { textured = true; break; }
+    if (force_tex >= 0) textured = textured || force_tex != 0;
     events_used = 0; spans.clear();
     hipEvent_t ev_begin = nullptr, ev_end = nullptr;
     ev_begin = next_event(); ev_end = next_event();
@@ -769,7 +774,7 @@ bool HdMoonshine::render(uint32_t sensor, uint32_t lens, uint32_t launches, bool
             timed2(0, pp.s0, [&] { launch_trace_closest(pp.s0, trace_grid, trace_stats, sv, cur, hits, cnt + b, pp.spill.p, d_overflow.p, d_trace_stats.p, refill); });
             if (shadow_done) CHECK_HIP(this, hipStreamWaitEvent(pp.s0, shadow_done, 0));   // k_shade(b) consumes the results of k_trace_shadow(b-1)
             const ShadowQueue shq{ shq_f4, shq_f4 + qc, contrib[b & 1] };
-            timed2(2, pp.s0, [&] { launch_shade(pp.s0, shade_k_grid, sv, opts, cur, hits, nxt, shq, contrib[(b + 1) & 1], lbuf, cnt + b, b == 0); });
+            timed2(2, pp.s0, [&] { launch_shade(pp.s0, shade_k_grid, sv, opts, cur, hits, nxt, shq, contrib[(b + 1) & 1], lbuf, cnt + b, b == 0, textured); });
             hipEvent_t shade_done = next_event();
             if (!shade_done) { fail("hipEventCreate failed"); return false; }
             CHECK_HIP(this, hipEventRecord(shade_done, pp.s0));

@@ -10,7 +10,7 @@
 
 namespace msne {
 
-constexpr int SHADE_BLOCK = 256;   // k_shade is held at 168 VGPRs (3 waves/SIMD; 172 unconstrained = 2 waves, 25 % slower); 128 (4 waves) spills 61 registers and is 15 % slower
+constexpr int SHADE_BLOCK = 256;   // one wave per SIMD per workgroup; k_shade runs four workgroups per CU (128 registers, 39 KB of LDS each)
 
 __device__ __forceinline__ uint32_t wave_append(uint32_t* counter, bool pred) {
     const unsigned long long m = __ballot(pred);
@@ -115,14 +115,20 @@ __device__ __forceinline__ f3 estimate_direct_mis(const Frame& frame, const LSam
 }
 
 #ifndef SHADE_WPS
-#define SHADE_WPS 3          // resident waves per SIMD k_shade is register-allocated for (168 registers; 4 = 128 registers and 35 spilled, measured below)
+#define SHADE_WPS 4          // resident waves per SIMD the TEXTURED k_shade is register-allocated for: 128 registers with the descriptors fetched where they are used (19 spilled;
+                             // stand-in with 64^2 / 1024^2 textures: shade 55.9 -> 54.0 / 60.7 -> 59.5 ms per 64-step batch against 3 waves at 166 registers; round 3, with the
+                             // descriptors fetched up front, had measured 4 waves slower)
 #endif
 // SPEC: which paths an instantiation shades — 0: all of them (the shipped kernel); 1: finished paths and misses (no surface code at all); 2: hits on glass and
 // mirrors (no light samples, no PBR); 3: Lambert hits; 4: StandardPBR hits.  The specialised ones skip every other path of the queue: launched one after the
 // other they shade a bounce between them, bit-identically ($MSNE_SHADE_SPEC=1; measured in profiles/r04_shade_specialised.txt).
-constexpr uint32_t shade_spec_wps(int spec) { return spec == 1 ? 4u : (uint32_t)SHADE_WPS; }   // (the workgroup's 35 KB of LDS allow four waves per SIMD at most)
-template <int SPEC>
-__global__ __launch_bounds__(SHADE_BLOCK, shade_spec_wps(SPEC)) void k_shade(SceneView sc, PipelineOpts opts, PathState cur, HitBuf hits, PathState nxt, ShadowQueue shq,
+// TEX: false when every texture of the scene is 1x1 (constant material parameters): no sampler code, fewer registers (shade.h tex_sample_desc)
+#ifndef SHADE_WPS_CONST
+#define SHADE_WPS_CONST 4    // 128 registers, 8 spilled: S1 k_shade 26.7 -> 23.0 ms per 64-step batch (5904 -> 6197 Mrays/s), S2 39.0 -> 33.0 (3579 -> 3707); at 3 waves (141 registers) 26.1 / 38.2
+#endif
+constexpr uint32_t shade_spec_wps(int spec, bool tex) { return spec == 1 ? 4u : (tex ? (uint32_t)SHADE_WPS : (uint32_t)SHADE_WPS_CONST); }   // (the workgroup's 39 KB of LDS allow four waves per SIMD at most)
+template <int SPEC, bool TEX>
+__global__ __launch_bounds__(SHADE_BLOCK, shade_spec_wps(SPEC, TEX)) void k_shade(SceneView sc, PipelineOpts opts, PathState cur, HitBuf hits, PathState nxt, ShadowQueue shq,
                                                          const float4* c_prev /* light-sample contributions of the previous bounce */,
                                                          float4* lbuf, BounceCounters* cnt /* [0]: this bounce, [1]: the next */, uint32_t first_pass /* the queue is k_raygen's */) {
     const uint32_t n = cnt[0].n_paths;
@@ -244,16 +250,27 @@ __global__ __launch_bounds__(SHADE_BLOCK, shade_spec_wps(SPEC)) void k_shade(Sce
                   if (SPEC == 2) mrec.type = m0.z & 2u;          // (the category filter let only these types through: the compiler drops the other BSDFs)
                   if (SPEC == 3) mrec.type = MAT_LAMBERT;
                   if (SPEC == 4) mrec.type = MAT_PBR; }
-                // the material's texture descriptors, all at once and before the attribute fetch below hides their latency (unused slots read the normal map's again)
-                const TexDesc t_normal = sc.textures[mrec.normal], t_emissive = sc.textures[mrec.emissive];
-                const bool has_color = mrec.type == MAT_PBR || mrec.type == MAT_LAMBERT;
-                const TexDesc t_color = sc.textures[has_color ? mrec.color : mrec.normal];
-                const TexDesc t_metal = sc.textures[mrec.type == MAT_PBR ? mrec.metalness : mrec.normal], t_rough = sc.textures[mrec.type == MAT_PBR ? mrec.roughness : mrec.normal];
-                attrs = mesh_attributes_world(sc, opts.indexed_attributes != 0, hinst, 0u, 0u, F2(u2f(hrec.z), u2f(hrec.w)), geometry, htri, true);
-                const Frame textureFrame = get_texture_frame(sc, t_normal, opts.two_component_normal_texture != 0, attrs.texcoord, attrs.frame);
-                const float4 em4 = tex_sample_desc(sc, t_emissive, attrs.texcoord);
-                const f3 emissiveLight = F3(em4.x, em4.y, em4.z);
-                material = material_load_desc(sc, mrec, t_color, t_metal, t_rough, attrs.texcoord);
+                Frame textureFrame; f3 emissiveLight;
+                if (TEX && SHADE_WPS >= 4) {   // at 128 registers five descriptors in flight are 40 registers too many: each is fetched where it is used
+                    attrs = mesh_attributes_world(sc, opts.indexed_attributes != 0, hinst, 0u, 0u, F2(u2f(hrec.z), u2f(hrec.w)), geometry, htri, true);
+                    textureFrame = get_texture_frame<TEX>(sc, sc.textures[mrec.normal], opts.two_component_normal_texture != 0, attrs.texcoord, attrs.frame);
+                    const float4 em4 = tex_sample_desc<TEX>(sc, sc.textures[mrec.emissive], attrs.texcoord);
+                    emissiveLight = F3(em4.x, em4.y, em4.z);
+                    const bool has_color = mrec.type == MAT_PBR || mrec.type == MAT_LAMBERT;
+                    material = material_load_desc<TEX>(sc, mrec, sc.textures[has_color ? mrec.color : mrec.normal], sc.textures[mrec.type == MAT_PBR ? mrec.metalness : mrec.normal], sc.textures[mrec.type == MAT_PBR ? mrec.roughness : mrec.normal], attrs.texcoord);
+                } else {
+                    // the material's texture descriptors, all at once and before the attribute fetch below hides their latency (unused slots read the normal map's again);
+                    // constant-texture scenes only ever use the descriptors' inline texels
+                    const TexDesc t_normal = sc.textures[mrec.normal], t_emissive = sc.textures[mrec.emissive];
+                    const bool has_color = mrec.type == MAT_PBR || mrec.type == MAT_LAMBERT;
+                    const TexDesc t_color = sc.textures[has_color ? mrec.color : mrec.normal];
+                    const TexDesc t_metal = sc.textures[mrec.type == MAT_PBR ? mrec.metalness : mrec.normal], t_rough = sc.textures[mrec.type == MAT_PBR ? mrec.roughness : mrec.normal];
+                    attrs = mesh_attributes_world(sc, opts.indexed_attributes != 0, hinst, 0u, 0u, F2(u2f(hrec.z), u2f(hrec.w)), geometry, htri, true);
+                    textureFrame = get_texture_frame<TEX>(sc, t_normal, opts.two_component_normal_texture != 0, attrs.texcoord, attrs.frame);
+                    const float4 em4 = tex_sample_desc<TEX>(sc, t_emissive, attrs.texcoord);
+                    emissiveLight = F3(em4.x, em4.y, em4.z);
+                    material = material_load_desc<TEX>(sc, mrec, t_color, t_metal, t_rough, attrs.texcoord);
+                }
 
                 const f3 woWs = neg(rayD);
                 const bool frontfacing = dot(attrs.triangleFrame.n, woWs) > 0.0f;
@@ -349,7 +366,7 @@ __global__ __launch_bounds__(SHADE_BLOCK, shade_spec_wps(SPEC)) void k_shade(Sce
                         const f2 at_texcoord = interp2(lbary, F2(u2f(lc.y), u2f(lc.z)), F2(u2f(lc.w), u2f(ld.x)), F2(u2f(ld.y), u2f(ld.z)));
                         const f3 at_n = F3(u2f(le.x), u2f(le.y), u2f(le.z));
                         LSample ls;
-                        { const float4 em = tex_sample_desc(sc, t_light, at_texcoord); ls.radiance = F3(em.x, em.y, em.z); }
+                        { const float4 em = tex_sample_desc<TEX>(sc, t_light, at_texcoord); ls.radiance = F3(em.x, em.y, em.z); }
                         ls.dirWs = normalize(sub(at_position, attrs.position));
                         ls.pdf = area_to_solid_angle(at_position, attrs.position, ls.dirWs, at_n) / sum;
                         if (ls.pdf > 0.0f) {
@@ -515,13 +532,18 @@ void launch_shade_probe(hipStream_t s, const SceneView& sc, int fn, const float*
 void launch_raygen(hipStream_t s, int grid, const ShardView& sh, const CameraConsts& cam, const PipelineOpts& o, uint32_t sample_base, uint32_t s_count, const PathState& st, BounceCounters* cnt) {
     hipLaunchKernelGGL(k_raygen, dim3(grid), dim3(SHADE_BLOCK), 0, s, sh, cam, o, sample_base, s_count, st, cnt);
 }
-void launch_shade(hipStream_t s, int grid, const SceneView& sc, const PipelineOpts& o, const PathState& cur, const HitBuf& hits, const PathState& nxt, const ShadowQueue& q, const float4* c_prev, float4* lbuf, BounceCounters* cnt, bool first_pass) {
+void launch_shade(hipStream_t s, int grid, const SceneView& sc, const PipelineOpts& o, const PathState& cur, const HitBuf& hits, const PathState& nxt, const ShadowQueue& q, const float4* c_prev, float4* lbuf, BounceCounters* cnt, bool first_pass, bool textured) {
     static const bool specialised = [] { const char* e = getenv("MSNE_SHADE_SPEC"); return e && atoi(e) != 0; }();
-    if (!specialised) { hipLaunchKernelGGL(k_shade<0>, dim3(grid), dim3(SHADE_BLOCK), 0, s, sc, o, cur, hits, nxt, q, c_prev, lbuf, cnt, first_pass ? 1u : 0u); return; }
-    hipLaunchKernelGGL(k_shade<1>, dim3(grid), dim3(SHADE_BLOCK), 0, s, sc, o, cur, hits, nxt, q, c_prev, lbuf, cnt, first_pass ? 1u : 0u);
-    hipLaunchKernelGGL(k_shade<2>, dim3(grid), dim3(SHADE_BLOCK), 0, s, sc, o, cur, hits, nxt, q, c_prev, lbuf, cnt, first_pass ? 1u : 0u);
-    hipLaunchKernelGGL(k_shade<3>, dim3(grid), dim3(SHADE_BLOCK), 0, s, sc, o, cur, hits, nxt, q, c_prev, lbuf, cnt, first_pass ? 1u : 0u);
-    hipLaunchKernelGGL(k_shade<4>, dim3(grid), dim3(SHADE_BLOCK), 0, s, sc, o, cur, hits, nxt, q, c_prev, lbuf, cnt, first_pass ? 1u : 0u);
+    const uint32_t fp = first_pass ? 1u : 0u;
+    if (!specialised) {
+        if (textured) hipLaunchKernelGGL((k_shade<0, true>), dim3(grid), dim3(SHADE_BLOCK), 0, s, sc, o, cur, hits, nxt, q, c_prev, lbuf, cnt, fp);
+        else hipLaunchKernelGGL((k_shade<0, false>), dim3(grid), dim3(SHADE_BLOCK), 0, s, sc, o, cur, hits, nxt, q, c_prev, lbuf, cnt, fp);
+        return;
+    }
+    hipLaunchKernelGGL((k_shade<1, true>), dim3(grid), dim3(SHADE_BLOCK), 0, s, sc, o, cur, hits, nxt, q, c_prev, lbuf, cnt, fp);
+    hipLaunchKernelGGL((k_shade<2, true>), dim3(grid), dim3(SHADE_BLOCK), 0, s, sc, o, cur, hits, nxt, q, c_prev, lbuf, cnt, fp);
+    hipLaunchKernelGGL((k_shade<3, true>), dim3(grid), dim3(SHADE_BLOCK), 0, s, sc, o, cur, hits, nxt, q, c_prev, lbuf, cnt, fp);
+    hipLaunchKernelGGL((k_shade<4, true>), dim3(grid), dim3(SHADE_BLOCK), 0, s, sc, o, cur, hits, nxt, q, c_prev, lbuf, cnt, fp);
 }
 void launch_light_tris(hipStream_t s, const SceneView& sc, uint32_t indexed_attributes, uint32_t n_instances, LightTri* out) {
     hipLaunchKernelGGL(k_light_tris, dim3((sc.alias_count + 1 + 255) / 256), dim3(256), 0, s, sc, indexed_attributes, n_instances, out);

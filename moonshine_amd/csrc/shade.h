@@ -63,8 +63,11 @@ __device__ __forceinline__ float4 sample_bilinear_fmt(const uint4* texels, const
 }
 // the lookup from a descriptor that is already in registers: k_shade fetches the (up to five) descriptors of a hit's material
 // together, before the first of them is needed, instead of one dependent descriptor -> texel chain after the other
+// TEX = false: the caller knows that every texture of the scene is 1x1 (constant material parameters, the glTF factors of World.zig:44-228) — the descriptor's inline
+// texel IS the lookup, and the bilinear sampler with its four texels in flight is not even compiled in (k_shade: 25-55 registers less)
+template <bool TEX = true>
 __device__ __forceinline__ float4 tex_sample_desc(const SceneView& sc, const TexDesc& t, f2 uv) {
-    if (t.w == 1 && t.h == 1) return t.first;
+    if (!TEX || (t.w == 1 && t.h == 1)) return t.first;
     return sample_bilinear_fmt(sc.texels, sc.srgb_lut, t.offset, t.w, t.h, t.format, uv.x, uv.y);
 }
 __device__ __forceinline__ float4 tex_sample(const SceneView& sc, uint32_t idx, f2 uv) { const TexDesc t = sc.textures[idx]; return tex_sample_desc(sc, t, uv); }
@@ -181,14 +184,15 @@ __device__ __forceinline__ Mat material_load(const SceneView& sc, const Material
     return o;
 }
 // ... with the descriptors of color / metalness / roughness already loaded (same lookups, same order)
+template <bool TEX = true>
 __device__ __forceinline__ Mat material_load_desc(const SceneView& sc, const MaterialRec& m, const TexDesc& tc, const TexDesc& tm, const TexDesc& tr, f2 uv) {
     Mat o; o.type = m.type; o.color = F3(0.0f, 0.0f, 0.0f); o.metalness = 0.0f; o.alpha = 0.0f; o.ior = m.ior;
     if (m.type == MAT_PBR) {
-        const float4 c = tex_sample_desc(sc, tc, uv); o.color = F3(c.x, c.y, c.z);
-        o.metalness = tex_sample_desc(sc, tm, uv).x;
-        const float roughness = tex_sample_desc(sc, tr, uv).x;
+        const float4 c = tex_sample_desc<TEX>(sc, tc, uv); o.color = F3(c.x, c.y, c.z);
+        o.metalness = tex_sample_desc<TEX>(sc, tm, uv).x;
+        const float roughness = tex_sample_desc<TEX>(sc, tr, uv).x;
         o.alpha = maxf(roughness * roughness, 0.001f);
-    } else if (m.type == MAT_LAMBERT) { const float4 c = tex_sample_desc(sc, tc, uv); o.color = F3(c.x, c.y, c.z); }
+    } else if (m.type == MAT_LAMBERT) { const float4 c = tex_sample_desc<TEX>(sc, tc, uv); o.color = F3(c.x, c.y, c.z); }
     return o;
 }
 // GGX :20-67
@@ -329,8 +333,9 @@ __device__ __forceinline__ Frame texture_frame_from_texel(float4 o, bool two_com
     Frame f = tangentFrame; f.n = nws; frame_reorthogonalize(f);
     return f;
 }
+template <bool TEX = true>
 __device__ __forceinline__ Frame get_texture_frame(const SceneView& sc, const TexDesc& normal_desc, bool two_component, f2 uv, const Frame& tangentFrame) {
-    return texture_frame_from_texel(tex_sample_desc(sc, normal_desc, uv), two_component, tangentFrame);
+    return texture_frame_from_texel(tex_sample_desc<TEX>(sc, normal_desc, uv), two_component, tangentFrame);
 }
 
 // ---------------- light.hlsl ----------------
