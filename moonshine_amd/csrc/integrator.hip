@@ -10,7 +10,10 @@
 
 namespace msne {
 
-constexpr int SHADE_BLOCK = 256;   // one wave per SIMD per workgroup; k_shade runs four workgroups per CU (128 registers, 39 KB of LDS each)
+#ifndef SHADE_BLOCK_THREADS
+#define SHADE_BLOCK_THREADS 256
+#endif
+constexpr int SHADE_BLOCK = SHADE_BLOCK_THREADS;   // one wave per SIMD per workgroup; k_shade runs four workgroups per CU (128 registers, 39 KB of LDS each)
 
 __device__ __forceinline__ uint32_t wave_append(uint32_t* counter, bool pred) {
     const unsigned long long m = __ballot(pred);
