@@ -2,10 +2,12 @@
 // TLAS (engine/hrtsystem/Accel.zig:94-184 makeBlases, :484 TLAS build, :629-679 recordRebuild).
 //
 // Pipeline (all HIP kernels, host only sequences launches and reads round / level counts):
-//   k_prim_boxes / k_bounds → k_morton (63-bit: 21 bits per axis) → stable LSD radix sort, 4 x 8 bit on the low word then 4 x 8 bit on the high word (k_radix_hist / _scan / _scatter)
-//   → PLOC rounds (k_ploc_nn / _mark / _scan / _merge: bottom-up agglomerative clustering, boxes come with the merges)
+//   k_prim_boxes / k_bounds → k_morton (63-bit: 21 bits per axis) → stable LSD radix sort, 4 x 8 bit on the low word then 4 x 8 bit on the high word (k_radix_hist / _scan_digit / _scatter)
+//   → PLOC rounds (k_ploc_nn / _mark / _scan / _merge: bottom-up agglomerative clustering, boxes come with the merges) down to the cluster count top_clusters() asks for
+//     (none at all up to 32 M primitives)
+//   → the top-down surface-area sweep over what is left (bvh_sweep.h: k_sw_*; one tree level per pass, every tree of the batch at once)
 //   → k_collapse (level-synchronous collapse to 8-wide in octant slot order, one item per leaf, quantised 80-B nodes)
-//   → k_emit_tris / k_emit_items.
+//   → k_emit_tris / k_emit_items; TLAS leaf records (k_tlas_leaves); in-place TLAS re-fit for transform edits (k_tlas_refit_*).
 // The same builder serves BLAS (items = triangles) and TLAS (items = instances).
 #include "msne_device.h"
 #include "../host/host.h"
