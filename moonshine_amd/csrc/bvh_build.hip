@@ -413,14 +413,16 @@ __global__ void k_collapse(const CollapseWork* work, uint32_t nwork, CollapseWor
     int child_of_slot[8];
     {
         float proj[8][3];
-        for (int i = 0; i < nch; i++) for (int k = 0; k < 3; k++) proj[i][k] = (cb[i].lo[k] + cb[i].hi[k]) - (nb.lo[k] + nb.hi[k]);
+        // (a child whose box is NaN — a triangle of NaN vertices — or a node of nothing else has no direction: projection 0.  Every round places ONE child that is
+        // still waiting into ONE free slot whatever the numbers are: a child left out would leave its reserved work entry unwritten)
+        for (int i = 0; i < nch; i++) for (int k = 0; k < 3; k++) { const float v = (cb[i].lo[k] + cb[i].hi[k]) - (nb.lo[k] + nb.hi[k]); proj[i][k] = (v == v && absf(v) < 3.0e38f) ? v : 0.0f; }
         for (int s = 0; s < 8; s++) child_of_slot[s] = -1;
         uint32_t child_done = 0;
         for (int r = 0; r < nch; r++) {
-            float bc = -3.0e38f; int bi = 0, bs = 0;
+            float bc = 0.0f; int bi = -1, bs = -1;
             for (int i = 0; i < nch; i++) if (!((child_done >> i) & 1u)) for (int s = 0; s < 8; s++) if (child_of_slot[s] < 0) {
                 const float c = ((s & 1) ? proj[i][0] : -proj[i][0]) + ((s & 2) ? proj[i][1] : -proj[i][1]) + ((s & 4) ? proj[i][2] : -proj[i][2]);
-                if (c > bc) { bc = c; bi = i; bs = s; }
+                if (bi < 0 || c > bc) { bc = c; bi = i; bs = s; }
             }
             child_of_slot[bs] = bi; child_done |= 1u << bi;
         }
@@ -572,6 +574,13 @@ struct BuildScratch {
         HIPCHK(hipMalloc(&cra, N * 4)); HIPCHK(hipMalloc(&crb, N * 4)); HIPCHK(hipMalloc(&nn, N * 4)); HIPCHK(hipMalloc(&pflags, N * 4));
         HIPCHK(hipMalloc(&bsum, nb * 4)); HIPCHK(hipMalloc(&bbase, nb * sizeof(uint2))); HIPCHK(hipMalloc(&totals, 2 * sizeof(PlocState)));
         HIPCHK(hipMalloc(&seg, N * 4)); HIPCHK(hipMalloc(&csa, N * 4)); HIPCHK(hipMalloc(&csb, N * 4));
+        if (getenv("MSNE_DEBUG_POISON")) {   // tests: scratch starts as garbage, as recycled device memory does in a long-lived process — an entry read before it is written shows
+            struct { void* p; size_t b; } all[] = { { boxes, N * sizeof(Box) }, { sorted, N * sizeof(Box) }, { ibox, N * sizeof(Box) }, { keys, N * 4 }, { keys2, N * 4 }, { idx, N * 4 }, { idx2, N * 4 },
+                { left, N * 4 }, { right, N * 4 }, { count, N * 4 }, { cost, N * 28 }, { split, N * 8 }, { wa, N * sizeof(CollapseWork) }, { wb, N * sizeof(CollapseWork) }, { cba, N * sizeof(Box) }, { cbb, N * sizeof(Box) },
+                { cra, N * 4 }, { crb, N * 4 }, { nn, N * 4 }, { pflags, N * 4 }, { seg, N * 4 }, { csa, N * 4 }, { csb, N * 4 } };
+            for (auto& a : all) HIPCHK(hipMemset(a.p, 0xCD, a.b));
+            HIPCHK(hipDeviceSynchronize());   // (the library's streams do not wait for the null stream)
+        }
         cap = n;
         return true;
     }
@@ -722,6 +731,8 @@ static bool sweep_on_gpu(BuildScratch& S, hipStream_t s, uint32_t n, uint32_t ns
         S.arena_bytes = off;
     }
     char* A = (char*)S.arena;
+    static const bool poison = getenv("MSNE_DEBUG_POISON") != nullptr;   // tests: the working set starts as garbage, as it does in a long-lived process
+    if (poison) HIPCHK(hipMemsetAsync(A, 0xCD, off, s));
     auto U32 = [&](size_t o) { return (uint32_t*)(A + o); };
     SwState St{};
     St.N = N; St.P0 = P0; St.ngc = ngc; St.node_base = node_base; St.ntile = ntile;

@@ -61,7 +61,13 @@ namespace {
 
 template <typename T> struct DevBuf {
     T* p = nullptr; size_t n = 0;
-    bool alloc(size_t count) { release(); if (count == 0) count = 1; if (hipMalloc(&p, count * sizeof(T)) != hipSuccess) { p = nullptr; return false; } n = count; return true; }
+    bool alloc(size_t count) {
+        release(); if (count == 0) count = 1;
+        if (hipMalloc(&p, count * sizeof(T)) != hipSuccess) { p = nullptr; return false; }
+        static const bool poison = getenv("MSNE_DEBUG_POISON") != nullptr;   // tests: device memory starts as garbage (0xCD), as recycled memory does in a long-lived process
+        if (poison && (hipMemset(p, 0xCD, count * sizeof(T)) != hipSuccess || hipDeviceSynchronize() != hipSuccess)) { (void)hipFree(p); p = nullptr; return false; }   // (the library's streams do not wait for the null stream)
+        n = count; return true;
+    }
     bool ensure(size_t count) { return count <= n && p ? true : alloc(count); }
     void release() { if (p) (void)hipFree(p); p = nullptr; n = 0; }
     ~DevBuf() { release(); }

@@ -15,6 +15,12 @@ if os.path.dirname(os.path.abspath(__file__)) not in sys.path:      # tests/asse
     sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 
 
+# Every device buffer the library allocates under test starts as garbage (0xCD) instead of whatever the allocator hands out — fresh device memory reads as zero,
+# recycled memory does not, and a value read before it is written must show here rather than in a long-lived process (round 4: an all-NaN leaf box left an entry of
+# the builder's work list unwritten; it only ever faulted on recycled memory).
+os.environ.setdefault("MSNE_DEBUG_POISON", "1")
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 

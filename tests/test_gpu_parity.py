@@ -1078,7 +1078,24 @@ def pile(c, extent):
     c.set_background(np.ones((1, 1, 4), np.float32), 1, 1)
     return c.create_sensor(*extent), c.create_lens(c.make_lens((0, 0, 5), (0, 0, -1), (0, 1, 0), 0.5))
 
-cases = [("s1", scenes.s1, dict(extent=(48, 27), grid=2, order=int(sys.argv[2]))), ("s2", scenes.s2, dict(extent=(48, 27), dims=(4, 4, 3), order=3)),
+def soup(n):
+    # n random triangles of very different sizes in one mesh, some of them copies of each other, some flat, one with NaN vertices: sizes around the sweep's
+    # tile (256 positions) and super-tile (64 tiles) boundaries exercise every carry of its segmented scans
+    def build(c, extent):
+        rs = np.random.default_rng(n)
+        centre = rs.normal(size=(n, 1, 3)) * 4.0
+        size = np.exp(rs.normal(size=(n, 1, 1)) * 1.5 - 1.5)
+        P = (centre + rs.normal(size=(n, 3, 3)) * size).astype(np.float32)
+        if n >= 8:
+            P[n // 2] = P[0]; P[n // 3, :, 2] = P[n // 3, 0, 2]; P[n // 5] = np.nan
+        mat = c.create_material(scenes.LAMBERT, c.solid_texture(0.5, 0.5), c.solid_texture(0, 0, 0), color=c.solid_texture(0.7, 0.7, 0.7))
+        c.create_instance([(c.create_mesh(P.reshape(-1, 3), np.arange(3 * n, dtype=np.uint32).reshape(-1, 3)), mat, False)])
+        c.set_background(np.ones((1, 1, 4), np.float32), 1, 1)
+        return c.create_sensor(*extent), c.create_lens(c.make_lens((0, 0, 14), (0, 0, -1), (0, 1, 0), 0.9))
+    return build
+
+cases = [("soup%d" % n, soup(n), dict(extent=(32, 32))) for n in ((1, 2, 3, 7, 255, 256, 257, 513, 16383, 16385, 33000) if sys.argv[2] == "4" else ())] + [
+         ("s1", scenes.s1, dict(extent=(48, 27), grid=2, order=int(sys.argv[2]))), ("s2", scenes.s2, dict(extent=(48, 27), dims=(4, 4, 3), order=3)),
          ("meshes", many_meshes, dict(extent=(48, 27))), ("pile", pile, dict(extent=(16, 16)))]
 for name, builder, kw in cases:
     got = {}
@@ -1105,12 +1122,14 @@ def test_gpu_sweep_builds_the_hosts_nodes(tmp_path, top, order):
     sequential statement of the same rules (csrc/bvh_topdown.h, $MSNE_TOPDOWN=host) must give the SAME trees: every wide node is compared by a hash of its whole
     subtree (grid, masks, child planes, leaf records, children in slot order) through MsneReadBvh — an 82 000-triangle S1 with the default 4096 clusters, and S1 / the
     instanced S2 / 40 distinct meshes in one batch (some with NaN vertices) / 6000 coincident triangles + a chain of shrinking ones with $MSNE_SAH_TOP = 48 and 300
-    (PLOC, cluster rebuilds and top trees in every mesh and in the TLAS)"""
+    (PLOC, cluster rebuilds and top trees in every mesh and in the TLAS), and triangle soups of 1 ... 33 000 triangles of very different sizes with copies, flat
+    triangles and an all-NaN one, their counts around the sweep's tile and super-tile boundaries.  The builder's scratch memory starts as garbage ($MSNE_DEBUG_POISON):
+    that is how an all-NaN leaf box was found to leave a reserved entry of k_collapse's work list unwritten (rounds 1-3; harmless only while fresh memory read as zero)"""
     import subprocess, sys, os
     script = tmp_path / "sweep_worker.py"
     script.write_text(SWEEP_WORKER)
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ)
+    env = dict(os.environ, MSNE_DEBUG_POISON="1")      # the builder's scratch starts as garbage (0xCD): whatever is read before it is written shows
     if top:
         env["MSNE_SAH_TOP"] = top
     out = subprocess.run([sys.executable, str(script), root, str(order)], capture_output=True, text=True, timeout=1500, env=env)
