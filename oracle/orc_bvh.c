@@ -239,16 +239,22 @@ static inline float safe_inv(float d) { return fabsf(d) < 1e-30f ? (d < 0.0f ? -
  * BVH).  Each axis interval is widened by 1e-5 of the larger of its two plane distances: that covers the rounding of
  * (plane - o) * id, keeps equal-t candidates, and — the case a slack relative to t itself misses — a ray that runs exactly
  * in a face plane of the box (direction component 0, id = +-1e30, origin on the plane: the interval is [-2e30, 0] or
- * [0, 2e30] depending on which face) stays inside. */
+ * [0, 2e30] depending on which face) stays inside.
+ * The comparison with the best hit so far carries a slack of 4e-6 of the LARGEST plane distance of the box: the watertight test computes t along the ray's dominant
+ * axis as a sum of terms the size of the triangle (T = U*Az + V*Bz + W*Cz), so a hit a few 1e-5 in front of the origin of a ray that grazes a triangle several units
+ * wide comes with an absolute error of ~1e-7 x that size — a relative error of 1e-2 — while the slab distance of its flat box is exact to 1e-7 relative: without the
+ * slack the second of two coincident triangles in different instances was culled against the first one's t, and the tie went to whichever instance the TLAS reached
+ * first instead of the smaller index (found by tests/test_gpu_parity.py::test_random_scenes_match_oracle, seed 13; the HIP traversal's quantised boxes carry a slack
+ * of 1e-3 grid steps of the parent node, which is larger). */
 static inline int box_hit(const float lo[3], const float hi[3], v3 o, v3 id, float tmax, float *tnear) {
-    float t1 = (lo[0] - o.x) * id.x, t2 = (hi[0] - o.x) * id.x, e = 1e-5f * orc_maxf(fabsf(t1), fabsf(t2));
+    float t1 = (lo[0] - o.x) * id.x, t2 = (hi[0] - o.x) * id.x, m = orc_maxf(fabsf(t1), fabsf(t2)), e = 1e-5f * m, far_ = m;
     float tn = orc_minf(t1, t2) - e, tf = orc_maxf(t1, t2) + e;
-    t1 = (lo[1] - o.y) * id.y; t2 = (hi[1] - o.y) * id.y; e = 1e-5f * orc_maxf(fabsf(t1), fabsf(t2));
+    t1 = (lo[1] - o.y) * id.y; t2 = (hi[1] - o.y) * id.y; m = orc_maxf(fabsf(t1), fabsf(t2)); e = 1e-5f * m; far_ = orc_maxf(far_, m);
     tn = orc_maxf(tn, orc_minf(t1, t2) - e); tf = orc_minf(tf, orc_maxf(t1, t2) + e);
-    t1 = (lo[2] - o.z) * id.z; t2 = (hi[2] - o.z) * id.z; e = 1e-5f * orc_maxf(fabsf(t1), fabsf(t2));
+    t1 = (lo[2] - o.z) * id.z; t2 = (hi[2] - o.z) * id.z; m = orc_maxf(fabsf(t1), fabsf(t2)); e = 1e-5f * m; far_ = orc_maxf(far_, m);
     tn = orc_maxf(tn, orc_minf(t1, t2) - e); tf = orc_minf(tf, orc_maxf(t1, t2) + e);
     *tnear = tn;
-    return tn <= tf && tf >= 0.0f && tn <= tmax;
+    return tn <= tf && tf >= 0.0f && tn <= tmax + 4e-6f * far_;
 }
 
 /* traverse one BLAS in instance space. any_hit: return at the first triangle with t < tmax */

@@ -57,7 +57,7 @@ static v3 incoming_radiance(const OrcContext *c, v3 rayO, v3 rayD, orc_rng *rng,
     orc_hit its;
     while (orc_closest_hit(c, rayO, rayD, rayTMax, &its, cnt)) {
         cnt->surface_hits++;
-        if (g_dbg && g_dbg_n < g_dbg_cap) { float *r = &g_dbg[8 * g_dbg_n++]; r[0] = (float)its.inst; r[1] = (float)its.prim; r[2] = its.t; r[3] = its.u; r[4] = its.v; r[5] = rayD.x; r[6] = rayD.y; r[7] = rayD.z; }
+        if (g_dbg && g_dbg_n < g_dbg_cap) { float *r = &g_dbg[12 * g_dbg_n++]; r[0] = (float)its.inst; r[1] = (float)its.prim; r[2] = its.t; r[3] = its.u; r[4] = its.v; r[5] = rayD.x; r[6] = rayD.y; r[7] = rayD.z; r[8] = rayO.x; r[9] = rayO.y; r[10] = rayO.z; r[11] = (float)its.geo; }
         uint32_t instanceID = c->instances[its.inst].geo_offset;
         const orc_geometry *geometry = &c->geometries[instanceID + its.geo];
         orc_attrs attrs = mesh_attributes_world(c, its.inst, its.geo, its.prim, V2(its.u, its.v));
@@ -484,7 +484,7 @@ int OrcRender(OrcContext *c, uint32_t sensor, uint32_t lens, uint32_t launches) 
     }
     return 0;
 }
-/* trace one camera path (sample index k, pixel x,y): returns radiance in rgb[3], hit records in rec (8 floats each) */
+/* trace one camera path (sample index k, pixel x,y): returns radiance in rgb[3], hit records in rec (12 floats each: instance, primitive, t, u, v, ray direction, ray origin, geometry) */
 uint32_t OrcDebugPath(OrcContext *c, uint32_t sensor, uint32_t lens, uint32_t k, uint32_t x, uint32_t y, float rgb[3], float *rec, uint32_t cap) {
     if (c->accel_dirty) rebuild_accel(c);
     orc_sensor *s = &c->sensors[sensor]; orc_counters cnt; memset(&cnt, 0, sizeof cnt);

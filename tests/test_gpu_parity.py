@@ -1201,6 +1201,95 @@ def _odd_scene(c, extent, ior, aperture):
     return c.create_sensor(*extent), lens
 
 
+def _random_scene(c, seed):
+    """a scene drawn from a seed: 3-9 meshes (icospheres, quads, triangle soups; with and without normals / texcoords), materials of every type with constant or
+    small image textures of every format, 4-14 instances under random affine transforms (rotations, non-uniform and NEGATIVE scales, identities, two-geometry
+    instances, hidden ones), zero to two sampled emitters, a constant or an image environment, a thin-lens or pinhole camera, an odd-sized sensor"""
+    rs = np.random.default_rng(seed)
+    black = c.solid_texture(0.0, 0.0, 0.0)
+    flat = c.solid_texture(0.5, 0.5)
+
+    def tex(kind):
+        w, h = int(rs.integers(1, 9)), int(rs.integers(1, 9))
+        if kind == "rgb":
+            return c.create_texture(rs.integers(0, 256, size=(h, w, 4), dtype=np.uint8), w, h, "r8g8b8a8_srgb") if rs.random() < 0.5 else c.solid_texture(*rs.random(3))
+        if kind == "scalar":
+            return c.create_texture(rs.integers(10, 250, size=(h, w), dtype=np.uint8), w, h, "r8_unorm") if rs.random() < 0.5 else c.solid_texture(float(rs.random()))
+        if kind == "normal":
+            return c.create_texture((128 + rs.integers(-40, 40, size=(h, w, 2))).astype(np.uint8), w, h, "r8g8_unorm") if rs.random() < 0.4 else flat
+        return c.create_texture((rs.random((h, w, 4)) * 8).astype(np.float16), w, h, "r16g16b16a16_sfloat") if rs.random() < 0.5 else c.solid_texture(*(rs.random(3) * 6))
+    mats = []
+    for _ in range(int(rs.integers(3, 7))):
+        kind = int(rs.integers(0, 4))
+        if kind == scenes.GLASS:
+            mats.append(c.create_material(scenes.GLASS, tex("normal"), black, ior=float(rs.uniform(1.05, 2.2))))
+        elif kind == scenes.PERFECT_MIRROR:
+            mats.append(c.create_material(scenes.PERFECT_MIRROR, tex("normal"), black))
+        elif kind == scenes.LAMBERT:
+            mats.append(c.create_material(scenes.LAMBERT, tex("normal"), black, color=tex("rgb")))
+        else:
+            mats.append(c.create_material(scenes.STANDARD_PBR, tex("normal"), black, color=tex("rgb"), metalness=tex("scalar"), roughness=tex("scalar"), ior=float(rs.uniform(1.2, 1.8))))
+    glow = [c.create_material(scenes.LAMBERT, flat, tex("emissive"), color=black) for _ in range(2)]
+    meshes = []
+    for _ in range(int(rs.integers(3, 10))):
+        kind = int(rs.integers(0, 3))
+        if kind == 0:
+            P, I = scenes.icosphere(int(rs.integers(0, 3))); P = (P * rs.uniform(0.3, 1.2, (1, 3))).astype(np.float32)
+        elif kind == 1:
+            e = float(rs.uniform(0.5, 3.0)); P, I = scenes.quad((-e, -e, 0), (e, -e, 0), (e, e, 0), (-e, e, 0))
+        else:
+            n = int(rs.integers(1, 40)); P = (rs.normal(size=(3 * n, 3)) * rs.uniform(0.1, 1.0)).astype(np.float32); I = np.arange(3 * n, dtype=np.uint32).reshape(-1, 3)
+        nrm = uv = None
+        if rs.random() < 0.5:
+            nrm = rs.normal(size=P.shape).astype(np.float32); nrm /= np.linalg.norm(nrm, axis=1, keepdims=True)
+        if rs.random() < 0.5:
+            uv = (rs.random((len(P), 2)) * rs.uniform(0.5, 4.0) - 0.7).astype(np.float32)
+        meshes.append(c.create_mesh(P, I, normals=nrm, texcoords=uv))
+    n_emit = int(rs.integers(0, 3))
+    for k in range(int(rs.integers(4, 15))):
+        A = rs.normal(size=(3, 3)) * rs.uniform(0.4, 1.3)
+        if rs.random() < 0.3:
+            A = scenes._rot(tuple(rs.normal(size=3) + 1e-3), rs.random() * 6.0) * np.array([1.0, 1.0, -1.0 if rs.random() < 0.5 else 1.0])[None, :] * rs.uniform(0.5, 1.5)
+        T = np.zeros((3, 4), np.float32); T[:, :3] = A; T[:, 3] = rs.normal(size=3) * 2.5
+        if rs.random() < 0.25:
+            T = np.eye(3, 4, dtype=np.float32)
+        geos = [(meshes[int(rs.integers(len(meshes)))], mats[int(rs.integers(len(mats)))], False)]
+        if rs.random() < 0.3:
+            geos.append((meshes[int(rs.integers(len(meshes)))], mats[int(rs.integers(len(mats)))], False))
+        if k < n_emit:
+            geos = [(meshes[int(rs.integers(len(meshes)))], glow[k % 2], True)]
+        c.create_instance(geos, transform=T, visible=bool(rs.random() > 0.1))
+    if rs.random() < 0.5:
+        c.set_background(np.array([*(rs.random(3) * 0.8), 1.0], np.float32), 1, 1)
+    else:
+        w, h = int(rs.integers(2, 40)), int(rs.integers(2, 24))
+        img = np.ones((h, w, 4), np.float32); img[..., :3] = rs.random((h, w, 3)) ** 4 * 5.0
+        c.set_background(img, w, h)
+    o = rs.normal(size=3); o = o / np.linalg.norm(o) * rs.uniform(5.0, 9.0)
+    lens = c.create_lens(c.make_lens(tuple(o), tuple(-o / np.linalg.norm(o)), (0, 0, 1), float(rs.uniform(0.4, 1.2)), aperture=float(rs.choice([0.0, 0.05, 0.3])), focus_distance=float(rs.uniform(3.0, 9.0))))
+    return c.create_sensor(int(rs.integers(5, 70)), int(rs.integers(5, 50))), lens
+
+
+@pytest.mark.parametrize("seed", list(range(16)))
+def test_random_scenes_match_oracle(orc, gpu_api, seed):
+    """sixteen scenes drawn from seeds — every material type, texture format, attribute combination, affine transforms with negative and non-uniform scales, hidden and
+    two-geometry instances, emitters, image environments, thin lenses, odd film sizes, pipelines with 0-2 light samples of either kind and 0-6 bounces — film, ray counts
+    and probe rays against the oracle, bit for bit"""
+    rs = np.random.default_rng(1000 + seed)
+    oc, so, lo, gc, sg, lg = both(orc, gpu_api, _random_scene, seed=seed)
+    pipe = dict(samples_per_run=int(rs.integers(1, 3)), max_bounces=int(rs.integers(0, 7)), env_samples_per_bounce=int(rs.integers(0, 3)), mesh_samples_per_bounce=int(rs.integers(0, 3)),
+                indexed_attributes=True, two_component_normal_texture=True)
+    for c in (oc, gc):
+        c.set_pipeline(**pipe)
+    n = int(rs.integers(1, 4))
+    gc.render(sg, lg, launches=n); oc.render(so, lo, launches=n)
+    go, oo = gc.sensor_data(sg), oc.sensor_data(so)
+    same = (go.view(np.uint32) == oo.view(np.uint32)) | (np.isnan(go) & np.isnan(oo))
+    assert same.all(), "seed %d %s: %d values differ" % (seed, pipe, int((~same).sum()))
+    assert gc.counters() == {k: v for k, v in oc.counters().items() if k in ("closest_rays", "shadow_rays", "samples")}
+    _check_rays(oc, gc, _random_rays(300, seed, radius=8.0))
+
+
 @pytest.mark.parametrize("extent,ior,aperture,bounces,spr", [((37, 23), 1.5, 0.0, 6, 1), ((16, 16), 1.0, 0.6, 3, 3), ((1, 1), 0.8, 0.1, 0, 2), ((130, 7), 2.4, 0.0, 1, 1)])
 def test_odd_parameters(orc, gpu_api, extent, ior, aperture, bounces, spr):
     oc, so, lo, gc, sg, lg = both(orc, gpu_api, _odd_scene, extent=extent, ior=ior, aperture=aperture)
