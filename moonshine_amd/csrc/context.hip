@@ -138,6 +138,7 @@ struct HdMoonshine {
     uint32_t dead_tris = 0;                               // triangles of evicted world BLASes still lying in the pools (reclaimed by a pool reset)
     BuildScratch* build_scratch = nullptr;                // this context's BVH build buffers: nothing is shared between contexts
     uint32_t tlas_root = MAX_UINT, root_in_blas = 0, n_tlas_items = 0;
+    float coord_radius = 0.0f;   // bound on the absolute vertex coordinates of the built scene, in world space and in every BLAS's object space (SceneView::coord_slack)
     // in-place TLAS update (Accel.zig:567-601): transform edits since the last build, and what a refit needs of that build
     std::vector<uint32_t> transform_edits;
     std::vector<char> built_in_world; std::vector<uint32_t> item_of_instance;   // per instance, as of the last rebuild (MAX_UINT: not in the TLAS)
@@ -325,6 +326,14 @@ static bool is_identity(const m34& m) {
     return true;
 }
 
+// largest absolute coordinate an instance's vertices can have: in the BLAS's own space (its root box) and under the transform (|T| applied to the box's reach)
+static float coord_reach(const m34& T, const float box[6]) {
+    float a[3], r = 0.0f;
+    for (int j = 0; j < 3; j++) { a[j] = std::max(fabsf(box[j]), fabsf(box[j + 3])); r = std::max(r, a[j]); }
+    for (int k = 0; k < 3; k++) r = std::max(r, fabsf(T.m[k][0]) * a[0] + fabsf(T.m[k][1]) * a[1] + fabsf(T.m[k][2]) * a[2] + fabsf(T.m[k][3]));
+    return r < 3.0e38f ? r : 3.0e38f;   // (NaN or infinite: no culling against the best hit at all)
+}
+
 bool HdMoonshine::rebuild_accel() {
     // $MSNE_BUILD_TIMING: host wall time of the phases of a rebuild on stderr
     static const bool timing = getenv("MSNE_BUILD_TIMING") != nullptr;
@@ -474,7 +483,9 @@ bool HdMoonshine::rebuild_accel() {
         if (mesh_ids && exact_boxes) for (uint32_t mi : *mesh_ids) tmesh.push_back(TlasMesh{ meshes[mi]->positions.p, meshes[mi]->position_count, 0u });
         t.mesh_end = (uint32_t)tmesh.size(); t.exact = t.mesh_end > t.mesh_begin ? 1u : 0u;
         tinst.push_back(t); ids.push_back(id);
+        coord_radius = std::max(coord_radius, coord_reach(T, box));
     };
+    coord_radius = 0.0f;
     for (size_t i = 0; i < N; i++) {
         InstanceRec& r = irec[i];
         r.transform = instances[i].transform;
@@ -579,6 +590,7 @@ bool HdMoonshine::refit_tlas() {
         if (exact_boxes) for (uint32_t mi : key) tmesh.push_back(TlasMesh{ meshes[mi]->positions.p, meshes[mi]->position_count, 0u });
         t.mesh_end = (uint32_t)tmesh.size(); t.exact = t.mesh_end > t.mesh_begin ? 1u : 0u;
         tinst.push_back(t); items.push_back(item_of_instance[h]);
+        coord_radius = std::max(coord_radius, coord_reach(instances[h].transform, bi->second.box));
     }
     if (transform_edits.size() > 64) CHECK_HIP(this, hipMemcpyAsync(d_instances.p, h_irec.data(), h_irec.size() * sizeof(InstanceRec), hipMemcpyHostToDevice, stream));   // many edits: the whole table in one copy
     if (!bvh_refit_tlas(stream, tinst.data(), tmesh.data(), (uint32_t)tmesh.size(), items.data(), (uint32_t)items.size(), d_nodes.p, tlas_node_begin, tlas_node_end - tlas_node_begin, tlas_item_begin, n_tlas_items,
@@ -617,6 +629,7 @@ SceneView HdMoonshine::scene_view() const {
     if (!h_alias.empty()) { v.alias_count = h_alias[0].alias; v.alias_sum = h_alias[0].select; }
     v.light_tris = d_light_tris.p;
     v.env = env; v.tlas_root = tlas_root; v.root_in_blas = root_in_blas;
+    v.coord_slack = 4e-6f * coord_radius;
     return v;
 }
 

@@ -106,6 +106,7 @@ struct Lane {
     int sp, sb;        // stack entries live in rows [sb, sp): sb moves up when the bottom entry is handed to an idle lane (launch tails)
     uint32_t own;      // closest-hit tails: bits 0..5 = the lane that owns this ray (itself unless this lane searches a handed-over piece), bits 8.. = pieces still out
     int ret_sp;        // two-level scenes: >= 0 while the lane is inside an instance = the stack height at which the instance's subtree is exhausted; -1 at world level
+    float slk;
     f3 wo, wid; uint32_t woct;   // two-level scenes: the world-space origin / reciprocal direction / octant, put aside while the lane is inside an instance
 };
 
@@ -129,15 +130,29 @@ __device__ __forceinline__ void lane_pop(Lane& L, const StackRef& S) {
     }
 }
 
-__device__ __forceinline__ void lane_set_space(Lane& L, f3 o, f3 d) {
+// Culling against the best hit so far needs an ABSOLUTE slack next to the box test's relative one: the watertight test computes t as a weighted mean of the three
+// distances (in t) from the origin to the planes through the vertices across the ray's dominant axis, so it carries an error of a few ulps of the LARGEST of them —
+// not of t.  A ray that starts 1e-5 in front of a large triangle gets t with a relative error of 1e-2, the slab distance of that triangle's flat box is exact, and of
+// two coplanar triangles the second one's box would be culled against the first one's t although its own t is smaller by rounding (found by the randomized scenes of
+// tests/test_gpu_parity.py, 5 of 20 000).  Every such distance is at most (largest coordinate of the scene + largest coordinate of the origin) / largest component
+// of the direction; 4e-6 = 64 ulps.  Per ray and space, kept in a register: recomputed at every node it costs 0.3 % more (profiles/r04_cull_slack.txt).
+#ifndef TRACE_CULL_SLACK
+#define TRACE_CULL_SLACK 1   // (0: measurements only)
+#endif
+__device__ __forceinline__ float cull_slack(const Lane& L, float coord_slack) {
+    if (!TRACE_CULL_SLACK) return 0.0f;
+    return __builtin_fmaf(fmaxf(fmaxf(absf(L.o.x), absf(L.o.y)), absf(L.o.z)), 4e-6f, coord_slack) * fminf(fminf(absf(L.id.x), absf(L.id.y)), absf(L.id.z));
+}
+__device__ __forceinline__ void lane_set_space(Lane& L, f3 o, f3 d, float coord_slack) {
     L.o = o;
     L.id = F3(safe_inv(d.x), safe_inv(d.y), safe_inv(d.z));
+    L.slk = cull_slack(L, coord_slack);
     L.rk = rayk_make(d);
     L.octbase = ((L.id.x < 0.0f ? 1u : 0u) | (L.id.y < 0.0f ? 2u : 0u) | (L.id.z < 0.0f ? 4u : 0u)) << 8;
 }
 
 __device__ __forceinline__ bool lane_begin(Lane& L, const SceneView& sc, f3 o, f3 d, float tmax) {
-    lane_set_space(L, o, d);
+    lane_set_space(L, o, d, sc.coord_slack);
     L.best.inst = MAX_UINT; L.best.tri = 0; L.best.t = tmax; L.best.u = 0.0f; L.best.v = 0.0f;
     L.sp = 0; L.sb = 0; L.ret_sp = -1; L.cur_inst = WORLD_INSTANCE;   // (cur_inst: only used when the root IS the world BLAS)
     L.g0 = sc.tlas_root; L.g1 = sc.tlas_root != MAX_UINT ? (GRP_NODE | 0x0101u) : 0u;   // a group of one: the root itself
@@ -183,7 +198,7 @@ __device__ __forceinline__ void step_node(Lane& L, const SceneView& sc, const St
     const uint32_t ny[2] = { sy ? w4.x : w2.z, sy ? w4.y : w2.w }, fy[2] = { sy ? w2.z : w4.x, sy ? w2.w : w4.y };
     const uint32_t nz[2] = { sz ? w4.z : w3.x, sz ? w4.w : w3.y }, fz[2] = { sz ? w3.x : w4.z, sz ? w3.y : w4.w };
     // (v_pk_fma_f32 for the {entry, exit} pairs was measured: 24 instructions fewer per node, 3 % slower overall)
-    const float tlimit = L.best.t;
+    const float tlimit = L.best.t + L.slk;   // (cull_slack: the absolute part of the slack; the relative part is the 1.00001 below)
     // hit <=> f * 1.00001 - n >= 0.  On gfx950 only v_fma / v_mul / v_add / v_sub (f32) and a few integer ops issue in 2 cycles per wave, everything else —
     // compares, selects, min / max, conversions — in 4 (profiles/r03_valu_microbench.txt): ONE fma, whose sign bit ONE v_alignbit shifts into a mask of
     // MISS bits, replaces mul + cmp + cndmask + or.  Children 7..0, so that child 0 ends up in bit 0.  (A NaN can only come from a NaN ray; either sign
@@ -344,7 +359,7 @@ __device__ __forceinline__ void trace_wave_loop(const SceneView& sc, uint32_t n,
             bool wait_t = false;
             if (INSTANCED && L.ret_sp >= 0 && L.sp == L.ret_sp) {
                 if (has_t) wait_t = true;
-                else { L.o = L.wo; L.id = L.wid; L.octbase = L.woct; L.ret_sp = -1; }
+                else { L.o = L.wo; L.id = L.wid; L.octbase = L.woct; L.ret_sp = -1; L.slk = cull_slack(L, sc.coord_slack); }
             }
             if (!wait_t) {
                 if (L.sp == L.sb) {
@@ -422,7 +437,7 @@ __device__ __forceinline__ void trace_wave_loop(const SceneView& sc, uint32_t n,
                         const uint32_t* dsp = S.spill - lane + dl;
                         L.g0 = dsp[(size_t)(2 * (dsb - STACK_LDS)) * S.spill_stride]; L.g1 = dsp[(size_t)(2 * (dsb - STACK_LDS) + 1) * S.spill_stride];
                     }
-                    L.o = F3(ox, oy, oz); L.id = F3(ix, iy, iz);
+                    L.o = F3(ox, oy, oz); L.id = F3(ix, iy, iz); L.slk = cull_slack(L, sc.coord_slack);
                     L.rk.kx = kx; L.rk.ky = ky; L.rk.kz = kz; L.rk.Sx = sx; L.rk.Sy = sy; L.rk.Sz = sz;
                     L.best.inst = binst; L.best.tri = btri; L.best.t = bt; L.best.u = bu; L.best.v = bv;
                     L.octbase = ob; L.cur_inst = ci; L.ret_sp = -1; my = dmy;
@@ -476,7 +491,7 @@ __device__ __forceinline__ void trace_wave_loop(const SceneView& sc, uint32_t n,
                     const f3 oi = m34_mul_point(M, o), di = m34_mul_vec(M, d);
                     o = oi; d = di;
                 }
-                lane_set_space(L, o, d);
+                lane_set_space(L, o, d, sc.coord_slack);
                 L.cur_inst = new_inst; L.g0 = root; L.g1 = GRP_NODE | 0x0101u;   // a group of one: the BLAS root
             }
         }

@@ -123,6 +123,7 @@ def lib():
         L.OrcBuildAliasTable.argtypes = [vp, u32, vp, vp, vp]
         L.OrcBsdfProbe.argtypes = [u32, vp, vp, vp, vp, vp]
         L.OrcProbeBatch.restype = C.c_int; L.OrcProbeBatch.argtypes = [vp, C.c_int, vp, u32, vp]
+        L.OrcDebugPath.restype = u32; L.OrcDebugPath.argtypes = [vp, u32, u32, u32, u32, u32, vp, vp, u32, C.POINTER(C.c_uint64)]
         _LIB = L
     return _LIB
 
@@ -239,6 +240,13 @@ class Context:
         w, h = self._extents[sensor]
         p = self.L.OrcGetSensorData(self.h, sensor)
         return np.ctypeslib.as_array(p, shape=(h, w, 4)).copy()
+
+    def debug_path(self, sensor, lens, k, x, y, cap=64):
+        """one camera path (sample index k of pixel x, y) -> (radiance (3,), records (n, 12): instance, primitive, t, u, v, direction, origin, geometry of every
+        surface hit, (closest rays, shadow rays) of the path)"""
+        rgb = np.zeros(3, np.float32); rec = np.zeros((cap, 12), np.float32); cnt = (C.c_uint64 * 2)()
+        n = self.L.OrcDebugPath(self.h, sensor, lens, k, x, y, _ptr(rgb), _ptr(rec), cap, cnt)
+        return rgb, rec[:n], (int(cnt[0]), int(cnt[1]))
 
     def counters(self):
         out = (C.c_uint64 * 8)()

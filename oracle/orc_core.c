@@ -485,7 +485,7 @@ int OrcRender(OrcContext *c, uint32_t sensor, uint32_t lens, uint32_t launches) 
     return 0;
 }
 /* trace one camera path (sample index k, pixel x,y): returns radiance in rgb[3], hit records in rec (12 floats each: instance, primitive, t, u, v, ray direction, ray origin, geometry) */
-uint32_t OrcDebugPath(OrcContext *c, uint32_t sensor, uint32_t lens, uint32_t k, uint32_t x, uint32_t y, float rgb[3], float *rec, uint32_t cap) {
+uint32_t OrcDebugPath(OrcContext *c, uint32_t sensor, uint32_t lens, uint32_t k, uint32_t x, uint32_t y, float rgb[3], float *rec, uint32_t cap, uint64_t counts[2] /* closest, shadow rays of the path; may be NULL */) {
     if (c->accel_dirty) rebuild_accel(c);
     orc_sensor *s = &c->sensors[sensor]; orc_counters cnt; memset(&cnt, 0, sizeof cnt);
     orc_rng rng = rng_from_seed(k, x, y);
@@ -500,6 +500,7 @@ uint32_t OrcDebugPath(OrcContext *c, uint32_t sensor, uint32_t lens, uint32_t k,
     v3 L = incoming_radiance(c, O, D, &rng, &cnt);
     g_dbg = NULL;
     rgb[0] = L.x; rgb[1] = L.y; rgb[2] = L.z;
+    if (counts) { counts[0] = cnt.closest_rays; counts[1] = cnt.shadow_rays; }
     return g_dbg_n;
 }
 void OrcGetCounters(OrcContext *c, uint64_t out[8]) {

@@ -1270,7 +1270,14 @@ def _random_scene(c, seed):
     return c.create_sensor(int(rs.integers(5, 70)), int(rs.integers(5, 50))), lens
 
 
-@pytest.mark.parametrize("seed", list(range(16)))
+def _fuzz_seeds():
+    """sixteen seeds in the suite; MSNE_FUZZ_SEEDS="a-b" widens the sweep (tools/fuzz_sweep.sh)"""
+    spec = os.environ.get("MSNE_FUZZ_SEEDS", "0-15")
+    a, _, b = spec.partition("-")
+    return list(range(int(a), int(b or a) + 1))
+
+
+@pytest.mark.parametrize("seed", _fuzz_seeds())
 def test_random_scenes_match_oracle(orc, gpu_api, seed):
     """sixteen scenes drawn from seeds — every material type, texture format, attribute combination, affine transforms with negative and non-uniform scales, hidden and
     two-geometry instances, emitters, image environments, thin lenses, odd film sizes, pipelines with 0-2 light samples of either kind and 0-6 bounces — film, ray counts
