@@ -1259,6 +1259,7 @@ def _random_scene(c, seed):
         if k < n_emit:
             geos = [(meshes[int(rs.integers(len(meshes)))], glow[k % 2], True)]
         c.create_instance(geos, transform=T, visible=bool(rs.random() > 0.1))
+    c.fuzz_instances, c.fuzz_emitters = k + 1, n_emit
     if rs.random() < 0.5:
         c.set_background(np.array([*(rs.random(3) * 0.8), 1.0], np.float32), 1, 1)
     else:
@@ -1295,6 +1296,45 @@ def test_random_scenes_match_oracle(orc, gpu_api, seed):
     assert same.all(), "seed %d %s: %d values differ" % (seed, pipe, int((~same).sum()))
     assert gc.counters() == {k: v for k, v in oc.counters().items() if k in ("closest_rays", "shadow_rays", "samples")}
     _check_rays(oc, gc, _random_rays(300, seed, radius=8.0))
+
+
+@pytest.mark.parametrize("seed", _fuzz_seeds())
+def test_random_edits_match_oracle(orc, gpu_api, seed):
+    """the randomized scenes again, edited between renders the way a Hydra session edits them (hydra.zig:495-513): five rounds of instance transforms (one instance, a few,
+    or most of them: re-fits in place and rebuilds), identities (an instance joins or leaves the merged world BLAS), visibility switches — film and ray counts against the
+    oracle after every round"""
+    rs = np.random.default_rng(5000 + seed)
+    oc, so, lo, gc, sg, lg = both(orc, gpu_api, _random_scene, seed=seed)
+    pipe = dict(samples_per_run=1, max_bounces=int(rs.integers(1, 5)), env_samples_per_bounce=int(rs.integers(0, 2)), mesh_samples_per_bounce=int(rs.integers(0, 2)),
+                indexed_attributes=True, two_component_normal_texture=True)
+    for c in (oc, gc):
+        c.set_pipeline(**pipe)
+    n = oc.fuzz_instances
+    for rnd in range(5):
+        kind = int(rs.integers(0, 4))
+        count = 1 if kind == 0 else int(rs.integers(1, 4)) if kind == 1 else n
+        for h in rs.choice(n, size=min(count, n), replace=False):
+            what = rs.random()
+            if what < 0.7:
+                T = np.zeros((3, 4), np.float32)
+                T[:, :3] = scenes._rot(tuple(rs.normal(size=3) + 1e-3), rs.random() * 6.0) * rs.uniform(0.5, 1.5)
+                T[:, 3] = rs.normal(size=3) * (0.2 if rs.random() < 0.5 else 2.5)
+                if rs.random() < 0.15:
+                    T = np.eye(3, 4, dtype=np.float32)
+                for c in (oc, gc):
+                    c.set_instance_transform(int(h), T)
+            else:
+                v = bool(rs.random() < 0.6)
+                for c in (oc, gc):
+                    c.set_instance_visibility(int(h), v)
+        for c, s_ in ((oc, so), (gc, sg)):
+            c.clear_sensor(s_); c.reset_counters()
+        gc.render(sg, lg, launches=1); oc.render(so, lo, launches=1)
+        go, oo = gc.sensor_data(sg), oc.sensor_data(so)
+        same = (go.view(np.uint32) == oo.view(np.uint32)) | (np.isnan(go) & np.isnan(oo))
+        assert same.all(), "seed %d round %d %s: %d values differ" % (seed, rnd, pipe, int((~same).sum()))
+        assert gc.counters() == {k: v for k, v in oc.counters().items() if k in ("closest_rays", "shadow_rays", "samples")}, "seed %d round %d" % (seed, rnd)
+    _check_rays(oc, gc, _random_rays(100, seed, radius=8.0))
 
 
 @pytest.mark.parametrize("extent,ior,aperture,bounces,spr", [((37, 23), 1.5, 0.0, 6, 1), ((16, 16), 1.0, 0.6, 3, 3), ((1, 1), 0.8, 0.1, 0, 2), ((130, 7), 2.4, 0.0, 1, 1)])
