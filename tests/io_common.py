@@ -203,3 +203,92 @@ def write_bathroom_standin(path_glb, path_exr, spheres=48, order=5, tex=64, env=
     sky = scenes.sky_sun_equirect(*env)
     open(path_exr, "wb").write(assets.exr_bytes(sky, "RGB", "half", "piz"))
     return dict(triangles=spheres * len(I) + 2 * 6, textures=len(b.j["textures"]), nodes=len(b.j["nodes"]))
+
+
+def write_random_glb(path_glb, path_exr, seed):
+    """a glTF file drawn from a seed, over everything World.zig:44-349 and Camera.zig:26-51 branch on: materials with every combination of base-colour / metallic-roughness /
+    normal / emissive textures and factors — the exact (0, 1) and (1, 0) factor pairs, transmission 1 and below 1, ior, emissive strength, names with and without the
+    "Emitter" prefix, materials without a pbrMetallicRoughness block —, meshes of one to three primitives with and without normals / texcoords (u16 and u32 indices,
+    separate and interleaved buffers), node trees up to four deep with TRS in every subset, matrices, empty nodes, meshes used by several nodes, the camera anywhere in
+    the tree (a second camera after it must be ignored)"""
+    rs = np.random.default_rng(seed)
+    b = assets.GlbBuilder(interleaved=bool(rs.random() < 0.3))
+    u32 = bool(rs.random() < 0.3)
+
+    def png(lo, hi, c=3):
+        w, h = int(rs.integers(1, 9)), int(rs.integers(1, 9))
+        return b.texture_png(rs.integers(lo, hi, (h, w, 3), dtype=np.uint8))
+    mats = []
+    for i in range(int(rs.integers(2, 7))):
+        kw = {}
+        r = rs.random()
+        if r < 0.2: kw.update(metallic=0.0, roughness=1.0)
+        elif r < 0.35: kw.update(metallic=1.0, roughness=0.0)
+        elif r < 0.45: kw.update(metallic=0.0, roughness=0.0)
+        else: kw.update(metallic=float(rs.random()), roughness=float(rs.uniform(0.05, 1.0)))
+        if rs.random() < 0.2: kw.update(transmission=1.0 if rs.random() < 0.7 else float(rs.uniform(0.1, 0.99)))
+        if rs.random() < 0.4: kw.update(ior=float(rs.uniform(1.1, 2.0)))
+        if rs.random() < 0.4: kw.update(base_color_texture=png(0, 256))
+        else: kw.update(base_color=tuple(rs.random(3)))
+        if rs.random() < 0.3: kw.update(metallic_roughness_texture=png(20, 230))
+        if rs.random() < 0.3: kw.update(normal_texture=b.texture_png(np.concatenate([128 + rs.integers(-30, 30, (4, 4, 2)), np.full((4, 4, 1), 255)], -1).astype(np.uint8)))
+        emit = rs.random() < 0.35
+        if emit and rs.random() < 0.4: kw.update(emissive_texture=png(0, 60))
+        elif emit: kw.update(emissive=tuple(rs.random(3)), **({"emissive_strength": float(rs.uniform(0.5, 20.0))} if rs.random() < 0.6 else {}))
+        name = ("Emitter %d" % i) if (emit and rs.random() < 0.6) else ("Emit%d" % i if rs.random() < 0.1 else "Mat %d" % i)
+        mats.append(b.material(name, **kw))
+    if rs.random() < 0.3:      # a material that names nothing but itself: every default of the glTF schema
+        b.j["materials"].append({"name": "Bare"}); mats.append(len(b.j["materials"]) - 1)
+
+    def prim():
+        kind = int(rs.integers(0, 3))
+        if kind == 0:
+            P, I = scenes.icosphere(int(rs.integers(0, 2))); P = P * rs.uniform(0.3, 1.0, (1, 3))
+        elif kind == 1:
+            e = float(rs.uniform(0.5, 2.5)); P = np.array([(-e, 0, -e), (e, 0, -e), (e, 0, e), (-e, 0, e)], np.float32); I = np.array([0, 2, 1, 0, 3, 2])
+        else:
+            n = int(rs.integers(1, 20)); P = rs.normal(size=(3 * n, 3)) * rs.uniform(0.2, 1.0); I = np.arange(3 * n)
+        d = dict(positions=np.asarray(P, np.float32), indices=np.asarray(I).reshape(-1), material=mats[int(rs.integers(len(mats)))], u32=u32)
+        both = rs.random() < 0.4
+        if both or rs.random() < 0.3:
+            N = rs.normal(size=(len(P), 3)); d["normals"] = (N / np.linalg.norm(N, axis=1, keepdims=True)).astype(np.float32)
+        if both or rs.random() < 0.3:
+            d["texcoords"] = (rs.random((len(P), 2)) * rs.uniform(0.5, 3.0) - 0.5).astype(np.float32)
+        return d
+    meshes = [b.mesh([prim() for _ in range(int(rs.integers(1, 4)))]) for _ in range(int(rs.integers(1, 5)))]
+
+    def xform():
+        kw = {}
+        r = rs.random()
+        if r < 0.25:
+            A = np.eye(4); A[:3, :3] = rs.normal(size=(3, 3)) * rs.uniform(0.4, 1.2); A[:3, 3] = rs.normal(size=3) * 2.0
+            kw["matrix"] = A
+        elif r < 0.9:
+            if rs.random() < 0.7: kw["translation"] = tuple(rs.normal(size=3) * 2.0)
+            if rs.random() < 0.6:
+                q = rs.normal(size=4); kw["rotation"] = tuple(q / np.linalg.norm(q))
+            if rs.random() < 0.4: kw["scale"] = tuple(rs.uniform(0.4, 1.6, 3) * rs.choice([-1.0, 1.0], 3, p=[0.15, 0.85]))
+        return kw
+    cam_at = int(rs.integers(0, 6))
+    placed = [0]
+
+    def camera_node(root):
+        q = rs.normal(size=4) * 0.15 + np.array([0, 0, 0, 1.0])
+        return b.node(camera=b.camera(float(rs.uniform(0.4, 1.1))), translation=(float(rs.normal() * 0.5), float(rs.normal() * 0.5 + 1.0), float(rs.uniform(5.0, 9.0))), rotation=tuple(q / np.linalg.norm(q)), root=root)
+
+    def tree(depth, root):
+        kids = []
+        if depth < 3:
+            kids = [tree(depth + 1, False) for _ in range(int(rs.integers(0, 3 if depth else 4)))]
+        if placed[0] == cam_at:
+            kids.append(camera_node(False))
+        placed[0] += 1
+        return b.node(mesh=meshes[int(rs.integers(len(meshes)))] if rs.random() < 0.75 else None, children=kids or None, root=root, **xform())
+    for _ in range(int(rs.integers(1, 4))):
+        tree(0, True)
+    camera_node(True)    # (the file's first camera node when none was placed in a tree; otherwise the one to ignore)
+    open(path_glb, "wb").write(b.tobytes())
+    if rs.random() < 0.5:
+        open(path_exr, "wb").write(assets.exr_bytes(np.array([[[*(rs.random(3) * 0.8), 1.0]]], np.float32)))
+    else:
+        open(path_exr, "wb").write(assets.exr_bytes(scenes.sky_sun_equirect(32, 16), "RGB", "half", "zip"))

@@ -1272,8 +1272,11 @@ def _random_scene(c, seed):
 
 
 def _fuzz_seeds():
-    """sixteen seeds in the suite; MSNE_FUZZ_SEEDS="a-b" widens the sweep (tools/fuzz_sweep.sh)"""
-    spec = os.environ.get("MSNE_FUZZ_SEEDS", "0-15")
+    """sixteen seeds in the suite, and the five of 0 .. 20 000 that failed in round 4 (coplanar triangles of two instances hit from 2e-3 away: trace.hip cull_slack);
+    MSNE_FUZZ_SEEDS="a-b" sweeps a range instead (tools/fuzz_sweep.sh)"""
+    spec = os.environ.get("MSNE_FUZZ_SEEDS")
+    if not spec:
+        return list(range(16)) + [1688, 2297, 7724, 18344, 19491]
     a, _, b = spec.partition("-")
     return list(range(int(a), int(b or a) + 1))
 

@@ -257,6 +257,40 @@ def test_glb_import_rules_against_a_second_source(tmp_path, orc, scene):
     assert np.array_equal(bits(films[0]), bits(films[1])), "%d pixels differ" % (bits(films[0]) != bits(films[1])).any(-1).sum()
 
 
+def _glb_fuzz_seeds():
+    spec = os.environ.get("MSNE_FUZZ_SEEDS")
+    if not spec:
+        return list(range(24))
+    a, _, b = spec.partition("-")
+    return list(range(int(a), int(b or a) + 1))
+
+
+@pytest.mark.parametrize("seed", _glb_fuzz_seeds())
+def test_random_glbs_against_a_second_source(tmp_path, orc, seed):
+    """glTF files drawn from seeds (tests/io_common.py write_random_glb: every branch of the import rules in random combination) through the importer and through
+    tests/second_source_glb.py: the same scene -> the oracle renders bit-identical films; MSNE_FUZZ_SEEDS="a-b" sweeps a range"""
+    import second_source_glb
+    glb, exr = str(tmp_path / "scene.glb"), str(tmp_path / "sky.exr")
+    io.write_random_glb(glb, exr, seed)
+    films, infos = [], []
+    for how in ("importer", "second source"):
+        c = orc.Context(threads=usable_cores())
+        if how == "importer":
+            lens, info = io.oracle_load(orc, c, glb, exr)
+            infos.append(info)
+        else:
+            lens = second_source_glb.load(c, glb)
+            assert io.shim(orc).ShimSetBackgroundExr(C.c_void_p(c.h), exr.encode()) == 0
+        s = c.create_sensor(40, 28)
+        c.set_pipeline(samples_per_run=1, max_bounces=4, env_samples_per_bounce=1, mesh_samples_per_bounce=1)
+        c.render(s, lens, launches=2)
+        films.append(c.sensor_data(s))
+        infos.append(c.alias_table()[0]["alias"])
+    same = (bits(films[0]) == bits(films[1])) | (np.isnan(films[0]) & np.isnan(films[1]))
+    assert same.all(), "seed %d: %d values differ (%s)" % (seed, int((~same).sum()), infos[0])
+    assert infos[1] == infos[2], "sampled emitter triangles"
+
+
 def rel_l2(a, b):
     return float(np.linalg.norm(a[..., :3].astype(np.float64) - b[..., :3]) / np.linalg.norm(b[..., :3].astype(np.float64)))
 
