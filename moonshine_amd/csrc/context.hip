@@ -629,7 +629,7 @@ SceneView HdMoonshine::scene_view() const {
     if (!h_alias.empty()) { v.alias_count = h_alias[0].alias; v.alias_sum = h_alias[0].select; }
     v.light_tris = d_light_tris.p;
     v.env = env; v.tlas_root = tlas_root; v.root_in_blas = root_in_blas;
-    v.coord_slack = 4e-6f * coord_radius;
+    v.coord_slack = 1.5e-6f * coord_radius;
     return v;
 }
 

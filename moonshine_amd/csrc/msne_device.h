@@ -138,7 +138,7 @@ struct SceneView {
     EnvView env;
     uint32_t tlas_root;               // MAX_UINT when the scene is empty
     uint32_t root_in_blas;            // 1: tlas_root is the root of the merged world BLAS (no TLAS level at all)
-    float coord_slack;                // 4e-6 x the largest absolute vertex coordinate of the scene, in world space or in the object space of any BLAS (trace.hip step_node)
+    float coord_slack;                // 1.5e-6 x the largest absolute vertex coordinate of the scene, in world space or in the object space of any BLAS (trace.hip step_node)
 };
 // All visible identity-transform instances are merged into ONE "world BLAS" whose triangle records carry their owning
 // instance in TriRec::pad; the TLAS then holds one pseudo-instance for it (InstanceRec flag bit 2) next to the

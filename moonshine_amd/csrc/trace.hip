@@ -135,13 +135,16 @@ __device__ __forceinline__ void lane_pop(Lane& L, const StackRef& S) {
 // not of t.  A ray that starts 1e-5 in front of a large triangle gets t with a relative error of 1e-2, the slab distance of that triangle's flat box is exact, and of
 // two coplanar triangles the second one's box would be culled against the first one's t although its own t is smaller by rounding (found by the randomized scenes of
 // tests/test_gpu_parity.py, 5 of 20 000).  Every such distance is at most (largest coordinate of the scene + largest coordinate of the origin) / largest component
-// of the direction; 4e-6 = 64 ulps.  Per ray and space, kept in a register: recomputed at every node it costs 0.3 % more (profiles/r04_cull_slack.txt).
+// of the direction.  With every operation rounded once the error is at most 10 ulps (6e-7) of that distance; 1.5e-6 of a bound that is itself twice too large for
+// most rays.  (4e-6 was measured first: on S1 it reaches past the ~1.2e-4 by which a light sample's shadow ray stops short of the emitter, every such ray then visits
+// the emitter's box and tests its triangles — k_trace_shadow +3 %.)  Per ray and space, kept in a register: recomputed at every node it costs 0.3 % more
+// (profiles/r04_cull_slack.txt).
 #ifndef TRACE_CULL_SLACK
 #define TRACE_CULL_SLACK 1   // (0: measurements only)
 #endif
 __device__ __forceinline__ float cull_slack(const Lane& L, float coord_slack) {
     if (!TRACE_CULL_SLACK) return 0.0f;
-    return __builtin_fmaf(fmaxf(fmaxf(absf(L.o.x), absf(L.o.y)), absf(L.o.z)), 4e-6f, coord_slack) * fminf(fminf(absf(L.id.x), absf(L.id.y)), absf(L.id.z));
+    return __builtin_fmaf(fmaxf(fmaxf(absf(L.o.x), absf(L.o.y)), absf(L.o.z)), 1.5e-6f, coord_slack) * fminf(fminf(absf(L.id.x), absf(L.id.y)), absf(L.id.z));
 }
 __device__ __forceinline__ void lane_set_space(Lane& L, f3 o, f3 d, float coord_slack) {
     L.o = o;
@@ -182,7 +185,7 @@ __device__ __forceinline__ uint32_t group_take(Lane& L, const StackRef& S, const
 
 // internal node: 5 x 16-B loads, 8 quantised box tests → 8 hit bits.  Straight-line code, no per-child entries:
 // the hit internal children become the lane's new group, the hit leaves its leaf group (BLAS) or an instance group (TLAS).
-template <bool STATS>
+template <bool STATS, bool ANY_HIT>
 __device__ __forceinline__ void step_node(Lane& L, const SceneView& sc, const StackRef& S, uint32_t node, bool in_blas /* the node belongs to a BLAS: its leaves are triangles */, unsigned long long& nv) {
     const uint4* np = reinterpret_cast<const uint4*>(sc.nodes + node);
     const uint4 w0 = np[0], w1 = np[1], w2 = np[2], w3 = np[3], w4 = np[4];
@@ -198,7 +201,9 @@ __device__ __forceinline__ void step_node(Lane& L, const SceneView& sc, const St
     const uint32_t ny[2] = { sy ? w4.x : w2.z, sy ? w4.y : w2.w }, fy[2] = { sy ? w2.z : w4.x, sy ? w2.w : w4.y };
     const uint32_t nz[2] = { sz ? w4.z : w3.x, sz ? w4.w : w3.y }, fz[2] = { sz ? w3.x : w4.z, sz ? w3.y : w4.w };
     // (v_pk_fma_f32 for the {entry, exit} pairs was measured: 24 instructions fewer per node, 3 % slower overall)
-    const float tlimit = L.best.t + L.slk;   // (cull_slack: the absolute part of the slack; the relative part is the 1.00001 below)
+    // (cull_slack: the absolute part of the slack; the relative part is the 1.00001 below.  An any-hit ray's tmax never changes: the sum is made once per
+    // space and kept where a closest-hit ray keeps u — any_hit_cull)
+    const float tlimit = ANY_HIT ? L.best.u : L.best.t + L.slk;
     // hit <=> f * 1.00001 - n >= 0.  On gfx950 only v_fma / v_mul / v_add / v_sub (f32) and a few integer ops issue in 2 cycles per wave, everything else —
     // compares, selects, min / max, conversions — in 4 (profiles/r03_valu_microbench.txt): ONE fma, whose sign bit ONE v_alignbit shifts into a mask of
     // MISS bits, replaces mul + cmp + cndmask + or.  Children 7..0, so that child 0 ends up in bit 0.  (A NaN can only come from a NaN ray; either sign
@@ -359,7 +364,7 @@ __device__ __forceinline__ void trace_wave_loop(const SceneView& sc, uint32_t n,
             bool wait_t = false;
             if (INSTANCED && L.ret_sp >= 0 && L.sp == L.ret_sp) {
                 if (has_t) wait_t = true;
-                else { L.o = L.wo; L.id = L.wid; L.octbase = L.woct; L.ret_sp = -1; L.slk = cull_slack(L, sc.coord_slack); }
+                else { L.o = L.wo; L.id = L.wid; L.octbase = L.woct; L.ret_sp = -1; L.slk = cull_slack(L, sc.coord_slack); if (ANY_HIT) L.best.u = L.best.t + L.slk; }
             }
             if (!wait_t) {
                 if (L.sp == L.sb) {
@@ -401,7 +406,7 @@ __device__ __forceinline__ void trace_wave_loop(const SceneView& sc, uint32_t n,
             if (!active && r < got) {
                 my = base + r;
                 f3 o, d; float tmax;
-                if (load(my, o, d, tmax)) { n_rays++; L.own = lane; active = lane_begin(L, sc, o, d, tmax); if (!active) store(my, L); }
+                if (load(my, o, d, tmax)) { n_rays++; L.own = lane; active = lane_begin(L, sc, o, d, tmax); if (ANY_HIT) L.best.u = tmax + L.slk; if (!active) store(my, L); }
                 else { L.best.inst = MAX_UINT; L.best.tri = 0; L.best.u = 0.0f; L.best.v = 0.0f; L.best.t = 0.0f; store(my, L); }
             }
         }
@@ -439,7 +444,7 @@ __device__ __forceinline__ void trace_wave_loop(const SceneView& sc, uint32_t n,
                     }
                     L.o = F3(ox, oy, oz); L.id = F3(ix, iy, iz); L.slk = cull_slack(L, sc.coord_slack);
                     L.rk.kx = kx; L.rk.ky = ky; L.rk.kz = kz; L.rk.Sx = sx; L.rk.Sy = sy; L.rk.Sz = sz;
-                    L.best.inst = binst; L.best.tri = btri; L.best.t = bt; L.best.u = bu; L.best.v = bv;
+                    L.best.inst = binst; L.best.tri = btri; L.best.t = bt; L.best.u = ANY_HIT ? bt + L.slk : bu; L.best.v = bv;
                     L.octbase = ob; L.cur_inst = ci; L.ret_sp = -1; my = dmy;
                     L.sp = 0; L.sb = 0; L.ta1 = 0; L.tb1 = 0; L.own = downer;
                     active = true;
@@ -492,6 +497,7 @@ __device__ __forceinline__ void trace_wave_loop(const SceneView& sc, uint32_t n,
                     o = oi; d = di;
                 }
                 lane_set_space(L, o, d, sc.coord_slack);
+                if (ANY_HIT) L.best.u = L.best.t + L.slk;
                 L.cur_inst = new_inst; L.g0 = root; L.g1 = GRP_NODE | 0x0101u;   // a group of one: the BLAS root
             }
         }
@@ -500,7 +506,7 @@ __device__ __forceinline__ void trace_wave_loop(const SceneView& sc, uint32_t n,
         const bool do_n2 = INSTANCED && do_s ? __ballot(want_n2) != 0ull : do_n;
         if (do_n2 && want_n2) {
             const uint32_t idx = group_take(L, S, lut);
-            step_node<STATS>(L, sc, S, idx, INSTANCED ? (L.ret_sp >= 0 || sc.root_in_blas != 0u) : true, nv);
+            step_node<STATS, ANY_HIT>(L, sc, S, idx, INSTANCED ? (L.ret_sp >= 0 || sc.root_in_blas != 0u) : true, nv);
         }
         lap(3);
         if (STATS && do_n2) cyc[6] += __popcll(__ballot(want_n2));   // node-lane steps

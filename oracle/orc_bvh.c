@@ -240,21 +240,28 @@ static inline float safe_inv(float d) { return fabsf(d) < 1e-30f ? (d < 0.0f ? -
  * (plane - o) * id, keeps equal-t candidates, and — the case a slack relative to t itself misses — a ray that runs exactly
  * in a face plane of the box (direction component 0, id = +-1e30, origin on the plane: the interval is [-2e30, 0] or
  * [0, 2e30] depending on which face) stays inside.
- * The comparison with the best hit so far carries a slack of 4e-6 of the LARGEST plane distance of the box: the watertight test computes t along the ray's dominant
- * axis as a sum of terms the size of the triangle (T = U*Az + V*Bz + W*Cz), so a hit a few 1e-5 in front of the origin of a ray that grazes a triangle several units
- * wide comes with an absolute error of ~1e-7 x that size — a relative error of 1e-2 — while the slab distance of its flat box is exact to 1e-7 relative: without the
- * slack the second of two coincident triangles in different instances was culled against the first one's t, and the tie went to whichever instance the TLAS reached
- * first instead of the smaller index (found by tests/test_gpu_parity.py::test_random_scenes_match_oracle, seed 13; the HIP traversal's quantised boxes carry a slack
- * of 1e-3 grid steps of the parent node, which is larger). */
+ * The comparison with the best hit so far carries a slack of 1.5e-6 of the box's larger plane distance ACROSS THE RAY'S DOMINANT AXIS: the watertight test computes
+ * t = (U*Az + V*Bz + W*Cz) / (U + V + W), a weighted mean of the distances Az, Bz, Cz (in t) from the origin to the planes through the three vertices across that axis;
+ * with every operation rounded once (A - o, 1/d, the products, the sums, the quotient) its error is at most 10 ulps (6e-7) of the LARGEST of the three — not of t.
+ * A ray that starts 1e-5 in front of a triangle several units wide gets a t with a relative error of 1e-2, while the slab distance of its flat box is exact to 1e-7:
+ * without the slack the second of two coincident triangles in different instances was culled against the first one's t, and the tie went to whichever instance the
+ * TLAS reached first instead of the smaller index (found by tests/test_gpu_parity.py::test_random_scenes_match_oracle, seed 13).  The HIP traversal bounds the same
+ * quantity per ray and space instead of per box (trace.hip cull_slack): neither side may cull a triangle that could still win, then both take the same minimum. */
 static inline int box_hit(const float lo[3], const float hi[3], v3 o, v3 id, float tmax, float *tnear) {
-    float t1 = (lo[0] - o.x) * id.x, t2 = (hi[0] - o.x) * id.x, m = orc_maxf(fabsf(t1), fabsf(t2)), e = 1e-5f * m, far_ = m;
+    float t1 = (lo[0] - o.x) * id.x, t2 = (hi[0] - o.x) * id.x, mx = orc_maxf(fabsf(t1), fabsf(t2)), e = 1e-5f * mx;
     float tn = orc_minf(t1, t2) - e, tf = orc_maxf(t1, t2) + e;
-    t1 = (lo[1] - o.y) * id.y; t2 = (hi[1] - o.y) * id.y; m = orc_maxf(fabsf(t1), fabsf(t2)); e = 1e-5f * m; far_ = orc_maxf(far_, m);
+    t1 = (lo[1] - o.y) * id.y; t2 = (hi[1] - o.y) * id.y; const float my = orc_maxf(fabsf(t1), fabsf(t2)); e = 1e-5f * my;
     tn = orc_maxf(tn, orc_minf(t1, t2) - e); tf = orc_minf(tf, orc_maxf(t1, t2) + e);
-    t1 = (lo[2] - o.z) * id.z; t2 = (hi[2] - o.z) * id.z; m = orc_maxf(fabsf(t1), fabsf(t2)); e = 1e-5f * m; far_ = orc_maxf(far_, m);
+    t1 = (lo[2] - o.z) * id.z; t2 = (hi[2] - o.z) * id.z; const float mz = orc_maxf(fabsf(t1), fabsf(t2)); e = 1e-5f * mz;
     tn = orc_maxf(tn, orc_minf(t1, t2) - e); tf = orc_minf(tf, orc_maxf(t1, t2) + e);
     *tnear = tn;
-    return tn <= tf && tf >= 0.0f && tn <= tmax + 4e-6f * far_;
+    /* the dominant axis has the smallest |1/d|; among equals the larger distance */
+    const float ax = fabsf(id.x), ay = fabsf(id.y), az = fabsf(id.z), amin = orc_minf(ax, orc_minf(ay, az));
+    float far_ = 0.0f;
+    if (ax == amin) far_ = orc_maxf(far_, mx);
+    if (ay == amin) far_ = orc_maxf(far_, my);
+    if (az == amin) far_ = orc_maxf(far_, mz);
+    return tn <= tf && tf >= 0.0f && tn <= tmax + 1.5e-6f * far_;
 }
 
 /* traverse one BLAS in instance space. any_hit: return at the first triangle with t < tmax */
