@@ -1454,6 +1454,64 @@ def test_contexts_build_concurrently_from_threads(gpu_api):
             assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), "context %d" % k
 
 
+def test_one_context_is_synced_from_many_threads(orc, gpu_api):
+    """USD's Sync runs in parallel: HdMoonshineCreateMesh / CreateMaterial / CreateInstance / SetInstanceTransform arrive on one context from many threads at once
+    (hydra/mesh.cpp:169-264; one mutex taken by every call, hydra.zig:76-78).  Eight threads describe six objects each — mesh, textures, material, instance, a transform
+    edit — while a ninth renders; every handle comes back exactly once, and the final film is the one the oracle renders for the same objects created one after the other
+    (non-overlapping objects: the film does not depend on the order the handles were given out in)"""
+    import threading
+    gc = gpu_api.Context(); oc = orc.Context(threads=8)
+    sg, lg = _odd_scene(gc, extent=(96, 54), ior=1.5, aperture=0.0); so, lo = _odd_scene(oc, extent=(96, 54), ior=1.5, aperture=0.0)
+    for c in (gc, oc):
+        c.set_pipeline(samples_per_run=1, max_bounces=4, env_samples_per_bounce=1, mesh_samples_per_bounce=0)
+
+    def objects(k):
+        rs = np.random.default_rng(100 + k)
+        for j in range(6):
+            P, I = scenes.icosphere(int(rs.integers(0, 3)))
+            P = (P * 0.25).astype(np.float32)
+            T0 = np.hstack([np.eye(3), np.zeros((3, 1))]).astype(np.float32)
+            T1 = T0.copy(); T1[:, :3] = scenes._rot((0.3, 0.5, 1.0), 0.1 * (k + j)) * 0.9; T1[:, 3] = (-4.0 + 0.7 * j, -3.0 + 0.8 * k, 0.3 + 0.05 * k)
+            yield P, I, tuple(rs.random(3)), float(rs.random()), float(rs.uniform(0.1, 1.0)), T0, T1
+
+    def describe(c, k, got):
+        for P, I, col, metal, rough, T0, T1 in objects(k):
+            m = c.create_mesh(P, I)
+            mat = c.create_material(scenes.STANDARD_PBR, c.solid_texture(0.5, 0.5), c.solid_texture(0.0, 0.0, 0.0), color=c.solid_texture(*col), metalness=c.solid_texture(metal), roughness=c.solid_texture(rough), ior=1.5)
+            h = c.create_instance([(m, mat, False)], transform=T0)
+            c.set_instance_transform(h, T1)
+            got.append((m, mat, h))
+    got = [[] for _ in range(8)]; err = []; stop = threading.Event()
+
+    def sync(k):
+        try:
+            describe(gc, k, got[k])
+        except Exception as e:   # noqa
+            err.append(e)
+
+    def draw():
+        try:
+            for _ in range(12):      # (every render in between rebuilds the scene as far as it has been described)
+                if stop.is_set():
+                    break
+                gc.render(sg, lg, launches=1)
+        except Exception as e:   # noqa
+            err.append(e)
+    th = [threading.Thread(target=sync, args=(k,)) for k in range(8)]
+    dr = threading.Thread(target=draw); dr.start()
+    [t.start() for t in th]; [t.join() for t in th]
+    stop.set(); dr.join()
+    assert not err, err
+    for col in range(3):
+        hs = [g[col] for gk in got for g in gk]
+        assert len(set(hs)) == len(hs) == 48, "handles given out twice"
+    for k in range(8):
+        describe(oc, k, [])
+    gc.clear_sensor(sg)
+    gc.render(sg, lg, launches=2); oc.render(so, lo, launches=2)
+    assert_film_equal(gc.sensor_data(sg), oc.sensor_data(so), "scene described from eight threads")
+
+
 def test_world_blas_is_evicted_not_accumulated(gpu_api):
     """Hydra-style visibility edits of identity instances rebuild the merged world BLAS; the pools must not grow without bound
     (one world BLAS is kept, evicted ones are reclaimed by a pool reset) and the films stay those of a fresh context"""
