@@ -144,7 +144,14 @@ void orc_build_blas(OrcContext *c, orc_bvh *out, const uint32_t *mesh_ids, uint3
         for (uint32_t p = 0; p < m->index_count; p++, k++) {
             v3 p0 = m->positions[m->indices[3 * p + 0]], p1 = m->positions[m->indices[3 * p + 1]], p2 = m->positions[m->indices[3 * p + 2]];
             tris[k].v0 = p0; tris[k].v1 = p1; tris[k].v2 = p2; tris[k].geo = g; tris[k].prim = p;
-            boxes[k] = aabb_empty(); aabb_grow(&boxes[k], p0); aabb_grow(&boxes[k], p1); aabb_grow(&boxes[k], p2);
+            /* a triangle with a NaN corner is inactive (VkAccelerationStructureGeometryTrianglesDataKHR: "NaN in the first component of a vertex"; the watertight test
+             * rejects it anyway): its box stays empty — grown with a NaN, min / max written as comparisons would hand the NaN on or drop it depending on the order
+             * of the corners, and with it the boxes of the up to three active triangles that share its leaf and of every node above them (found by
+             * tests/test_gpu_parity.py::test_random_big_scenes_match_oracle: the oracle missed hits the HIP path found) */
+            boxes[k] = aabb_empty();
+            if (p0.x == p0.x && p0.y == p0.y && p0.z == p0.z && p1.x == p1.x && p1.y == p1.y && p1.z == p1.z && p2.x == p2.x && p2.y == p2.y && p2.z == p2.z) {
+                aabb_grow(&boxes[k], p0); aabb_grow(&boxes[k], p1); aabb_grow(&boxes[k], p2);
+            }
         }
     }
     uint32_t *order = bvh_build_boxes(out, boxes, total, 4);

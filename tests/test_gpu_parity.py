@@ -1201,7 +1201,7 @@ def _odd_scene(c, extent, ior, aperture):
     return c.create_sensor(*extent), lens
 
 
-def _random_scene(c, seed):
+def _random_scene(c, seed, big=False):
     """a scene drawn from a seed: 3-9 meshes (icospheres, quads, triangle soups; with and without normals / texcoords), materials of every type with constant or
     small image textures of every format, 4-14 instances under random affine transforms (rotations, non-uniform and NEGATIVE scales, identities, two-geometry
     instances, hidden ones), zero to two sampled emitters, a constant or an image environment, a thin-lens or pinhole camera, an odd-sized sensor"""
@@ -1213,8 +1213,8 @@ def _random_scene(c, seed):
         w, h = int(rs.integers(1, 9)), int(rs.integers(1, 9))
         if kind == "rgb":
             return c.create_texture(rs.integers(0, 256, size=(h, w, 4), dtype=np.uint8), w, h, "r8g8b8a8_srgb") if rs.random() < 0.5 else c.solid_texture(*rs.random(3))
-        if kind == "scalar":
-            return c.create_texture(rs.integers(10, 250, size=(h, w), dtype=np.uint8), w, h, "r8_unorm") if rs.random() < 0.5 else c.solid_texture(float(rs.random()))
+        if kind in ("scalar", "rough"):   # (a roughness below ~0.01 overflows GGX's D to inf and the BSDF to inf - inf = NaN, in the reference too: NaN pixels compare equal and test nothing)
+            return c.create_texture(rs.integers(10, 250, size=(h, w), dtype=np.uint8), w, h, "r8_unorm") if rs.random() < 0.5 else c.solid_texture(float(rs.random()) * (0.97 if kind == "rough" else 1.0) + (0.03 if kind == "rough" else 0.0))
         if kind == "normal":
             return c.create_texture((128 + rs.integers(-40, 40, size=(h, w, 2))).astype(np.uint8), w, h, "r8g8_unorm") if rs.random() < 0.4 else flat
         return c.create_texture((rs.random((h, w, 4)) * 8).astype(np.float16), w, h, "r16g16b16a16_sfloat") if rs.random() < 0.5 else c.solid_texture(*(rs.random(3) * 6))
@@ -1228,25 +1228,38 @@ def _random_scene(c, seed):
         elif kind == scenes.LAMBERT:
             mats.append(c.create_material(scenes.LAMBERT, tex("normal"), black, color=tex("rgb")))
         else:
-            mats.append(c.create_material(scenes.STANDARD_PBR, tex("normal"), black, color=tex("rgb"), metalness=tex("scalar"), roughness=tex("scalar"), ior=float(rs.uniform(1.2, 1.8))))
+            mats.append(c.create_material(scenes.STANDARD_PBR, tex("normal"), black, color=tex("rgb"), metalness=tex("scalar"), roughness=tex("rough"), ior=float(rs.uniform(1.2, 1.8))))
     glow = [c.create_material(scenes.LAMBERT, flat, tex("emissive"), color=black) for _ in range(2)]
-    meshes = []
+    meshes, not_finite = [], []
     for _ in range(int(rs.integers(3, 10))):
         kind = int(rs.integers(0, 3))
         if kind == 0:
-            P, I = scenes.icosphere(int(rs.integers(0, 3))); P = (P * rs.uniform(0.3, 1.2, (1, 3))).astype(np.float32)
+            P, I = scenes.icosphere(int(rs.integers(2, 5) if big else rs.integers(0, 3))); P = (P * rs.uniform(0.3, 1.2, (1, 3))).astype(np.float32)
         elif kind == 1:
             e = float(rs.uniform(0.5, 3.0)); P, I = scenes.quad((-e, -e, 0), (e, -e, 0), (e, e, 0), (-e, e, 0))
         else:
-            n = int(rs.integers(1, 40)); P = (rs.normal(size=(3 * n, 3)) * rs.uniform(0.1, 1.0)).astype(np.float32); I = np.arange(3 * n, dtype=np.uint32).reshape(-1, 3)
+            n = int(rs.integers(200, 3000) if big else rs.integers(1, 40)); P = (rs.normal(size=(3 * n, 3)) * rs.uniform(0.1, 1.0)).astype(np.float32); I = np.arange(3 * n, dtype=np.uint32).reshape(-1, 3)
+            if big:   # small triangles scattered in a cloud instead of a ball of long slivers, some of them degenerate (two equal corners) or not finite
+                c0 = rs.normal(size=(n, 1, 3)) * 1.5; P = (c0 + rs.normal(size=(n, 3, 3)) * 0.08).reshape(-1, 3).astype(np.float32)
+                P[3 * int(rs.integers(n)) + 1] = P[3 * int(rs.integers(n))]
+                if rs.random() < 0.3: P[int(rs.integers(3 * n))] = np.nan; not_finite.append(len(meshes))
         nrm = uv = None
-        if rs.random() < 0.5:
+        if rs.random() < 0.5:   # shading normals: the surface's own direction, bent by up to ~30 degrees (arbitrary directions make frames whose tangent is parallel to the
+            #                     normal: NaN in the reference too, and NaN pixels compare equal and test nothing)
             nrm = rs.normal(size=P.shape).astype(np.float32); nrm /= np.linalg.norm(nrm, axis=1, keepdims=True)
+            if kind == 0:
+                base = P / np.linalg.norm(P, axis=1, keepdims=True)
+            elif kind == 1:
+                base = np.tile(np.array([[0, 0, 1]], np.float32), (len(P), 1))
+            else:
+                t = np.nan_to_num(P.reshape(-1, 3, 3)); g = np.cross(t[:, 1] - t[:, 0], t[:, 2] - t[:, 0]); g /= np.maximum(np.linalg.norm(g, axis=1, keepdims=True), 1e-20)
+                base = np.repeat(g, 3, axis=0)
+            nrm = (0.5 * nrm + base).astype(np.float32); nrm /= np.linalg.norm(nrm, axis=1, keepdims=True)
         if rs.random() < 0.5:
             uv = (rs.random((len(P), 2)) * rs.uniform(0.5, 4.0) - 0.7).astype(np.float32)
         meshes.append(c.create_mesh(P, I, normals=nrm, texcoords=uv))
     n_emit = int(rs.integers(0, 3))
-    for k in range(int(rs.integers(4, 15))):
+    for k in range(int(rs.integers(20, 60) if big else rs.integers(4, 15))):
         A = rs.normal(size=(3, 3)) * rs.uniform(0.4, 1.3)
         if rs.random() < 0.3:
             A = scenes._rot(tuple(rs.normal(size=3) + 1e-3), rs.random() * 6.0) * np.array([1.0, 1.0, -1.0 if rs.random() < 0.5 else 1.0])[None, :] * rs.uniform(0.5, 1.5)
@@ -1256,8 +1269,8 @@ def _random_scene(c, seed):
         geos = [(meshes[int(rs.integers(len(meshes)))], mats[int(rs.integers(len(mats)))], False)]
         if rs.random() < 0.3:
             geos.append((meshes[int(rs.integers(len(meshes)))], mats[int(rs.integers(len(mats)))], False))
-        if k < n_emit:
-            geos = [(meshes[int(rs.integers(len(meshes)))], glow[k % 2], True)]
+        if k < n_emit:   # (a sampled triangle with a NaN corner has a NaN area: every light sample of the scene would be NaN, in the reference too)
+            geos = [(meshes[[m for m in range(len(meshes)) if m not in not_finite][int(rs.integers(len(meshes) - len(not_finite)))]], glow[k % 2], True)]
         c.create_instance(geos, transform=T, visible=bool(rs.random() > 0.1))
     c.fuzz_instances, c.fuzz_emitters = k + 1, n_emit
     if rs.random() < 0.5:
@@ -1268,6 +1281,8 @@ def _random_scene(c, seed):
         c.set_background(img, w, h)
     o = rs.normal(size=3); o = o / np.linalg.norm(o) * rs.uniform(5.0, 9.0)
     lens = c.create_lens(c.make_lens(tuple(o), tuple(-o / np.linalg.norm(o)), (0, 0, 1), float(rs.uniform(0.4, 1.2)), aperture=float(rs.choice([0.0, 0.05, 0.3])), focus_distance=float(rs.uniform(3.0, 9.0))))
+    if big:
+        return c.create_sensor(int(rs.integers(100, 300)), int(rs.integers(60, 200))), lens
     return c.create_sensor(int(rs.integers(5, 70)), int(rs.integers(5, 50))), lens
 
 
@@ -1294,6 +1309,32 @@ def test_random_scenes_match_oracle(orc, gpu_api, seed):
         c.set_pipeline(**pipe)
     n = int(rs.integers(1, 4))
     gc.render(sg, lg, launches=n); oc.render(so, lo, launches=n)
+    go, oo = gc.sensor_data(sg), oc.sensor_data(so)
+    same = (go.view(np.uint32) == oo.view(np.uint32)) | (np.isnan(go) & np.isnan(oo))
+    assert same.all(), "seed %d %s: %d values differ" % (seed, pipe, int((~same).sum()))
+    assert gc.counters() == {k: v for k, v in oc.counters().items() if k in ("closest_rays", "shadow_rays", "samples")}
+    _check_rays(oc, gc, _random_rays(300, seed, radius=8.0))
+
+
+def _fuzz_seeds_big():
+    spec = os.environ.get("MSNE_FUZZ_SEEDS")
+    if not spec:
+        return list(range(4))
+    a, _, b = spec.partition("-")
+    return list(range(int(a), int(b or a) + 1))
+
+
+@pytest.mark.parametrize("seed", _fuzz_seeds_big())
+def test_random_big_scenes_match_oracle(orc, gpu_api, seed):
+    """the randomized scenes at a size where the builder's sweep runs many levels and the traversal uses its stack: meshes of 320 .. 5120 triangles, clouds of 200 .. 3000
+    small triangles with degenerate and non-finite ones among them, 20 .. 60 instances, films of several tiles"""
+    rs = np.random.default_rng(9000 + seed)
+    oc, so, lo, gc, sg, lg = both(orc, gpu_api, _random_scene, seed=70000 + seed, big=True)
+    pipe = dict(samples_per_run=int(rs.integers(1, 4)), max_bounces=int(rs.integers(0, 9)), env_samples_per_bounce=int(rs.integers(0, 3)), mesh_samples_per_bounce=int(rs.integers(0, 3)),
+                indexed_attributes=True, two_component_normal_texture=True)
+    for c in (oc, gc):
+        c.set_pipeline(**pipe)
+    gc.render(sg, lg, launches=2); oc.render(so, lo, launches=2)
     go, oo = gc.sensor_data(sg), oc.sensor_data(so)
     same = (go.view(np.uint32) == oo.view(np.uint32)) | (np.isnan(go) & np.isnan(oo))
     assert same.all(), "seed %d %s: %d values differ" % (seed, pipe, int((~same).sum()))

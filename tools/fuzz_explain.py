@@ -1,4 +1,4 @@
-"""Why does a randomized scene of tests/test_gpu_parity.py::test_random_scenes_match_oracle fail?   gpurun -- python tools/fuzz_explain.py SEED [SEED ...]
+"""Why does a randomized scene of tests/test_gpu_parity.py::test_random_scenes_match_oracle fail?   gpurun -- python tools/fuzz_explain.py [--big] SEED [SEED ...]
 Renders the seed's scene with the oracle and the HIP path, lists the film values that differ, and follows the oracle's camera paths of those pixels (every pixel when
 only the ray counts differ) through OrcDebugPath: every ray of a path is traced again on the GPU (MsneTraceRays) and the first vertex whose hit differs is printed —
 instance, geometry, primitive, t, u, v of both sides and the ray.  (Round 4: all five failures of seeds 0..20000 were coplanar triangles of two instances hit from
@@ -11,11 +11,18 @@ from oracle import orc
 from moonshine_amd import api
 import test_gpu_parity as T
 orc.build(); api.load_library()
-for seed in [int(s) for s in sys.argv[1:]]:
-    rs = np.random.default_rng(1000 + seed)
-    oc, so, lo, gc, sg, lg = T.both(orc, api, T._random_scene, seed=seed)
-    pipe = dict(samples_per_run=int(rs.integers(1, 3)), max_bounces=int(rs.integers(0, 7)), env_samples_per_bounce=int(rs.integers(0, 3)), mesh_samples_per_bounce=int(rs.integers(0, 3)), indexed_attributes=True, two_component_normal_texture=True)
-    n = int(rs.integers(1, 4))
+BIG = "--big" in sys.argv      # seeds of test_random_big_scenes_match_oracle
+for seed in [int(s) for s in sys.argv[1:] if s != "--big"]:
+    if BIG:
+        rs = np.random.default_rng(9000 + seed)
+        oc, so, lo, gc, sg, lg = T.both(orc, api, T._random_scene, seed=70000 + seed, big=True)
+        pipe = dict(samples_per_run=int(rs.integers(1, 4)), max_bounces=int(rs.integers(0, 9)), env_samples_per_bounce=int(rs.integers(0, 3)), mesh_samples_per_bounce=int(rs.integers(0, 3)), indexed_attributes=True, two_component_normal_texture=True)
+        n = 2
+    else:
+        rs = np.random.default_rng(1000 + seed)
+        oc, so, lo, gc, sg, lg = T.both(orc, api, T._random_scene, seed=seed)
+        pipe = dict(samples_per_run=int(rs.integers(1, 3)), max_bounces=int(rs.integers(0, 7)), env_samples_per_bounce=int(rs.integers(0, 3)), mesh_samples_per_bounce=int(rs.integers(0, 3)), indexed_attributes=True, two_component_normal_texture=True)
+        n = int(rs.integers(1, 4))
     print("seed", seed, pipe, "launches", n)
     for c in (oc, gc):
         c.set_pipeline(**pipe)
