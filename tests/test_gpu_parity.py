@@ -1201,16 +1201,20 @@ def _odd_scene(c, extent, ior, aperture):
     return c.create_sensor(*extent), lens
 
 
-def _random_scene(c, seed, big=False):
+def _random_scene(c, seed, big=False, hydra=False):
     """a scene drawn from a seed: 3-9 meshes (icospheres, quads, triangle soups; with and without normals / texcoords), materials of every type with constant or
     small image textures of every format, 4-14 instances under random affine transforms (rotations, non-uniform and NEGATIVE scales, identities, two-geometry
     instances, hidden ones), zero to two sampled emitters, a constant or an image environment, a thin-lens or pinhole camera, an odd-sized sensor"""
     rs = np.random.default_rng(seed)
     black = c.solid_texture(0.0, 0.0, 0.0)
-    flat = c.solid_texture(0.5, 0.5)
+    # hydra: the scene as Hydra's pipeline reads it (hydra.zig:97-105) — normal textures hold raw three-component normals, attributes come per face corner
+    flat = c.solid_texture(0.0, 0.0, 1.0) if hydra else c.solid_texture(0.5, 0.5)
 
     def tex(kind):
         w, h = int(rs.integers(1, 9)), int(rs.integers(1, 9))
+        if kind == "normal" and hydra:
+            n = np.concatenate([rs.normal(size=(h, w, 2)) * 0.15, np.ones((h, w, 1)), np.zeros((h, w, 1))], -1)
+            return c.create_texture(n.astype(np.float16), w, h, "r16g16b16a16_sfloat") if rs.random() < 0.4 else flat
         if kind == "rgb":
             return c.create_texture(rs.integers(0, 256, size=(h, w, 4), dtype=np.uint8), w, h, "r8g8b8a8_srgb") if rs.random() < 0.5 else c.solid_texture(*rs.random(3))
         if kind in ("scalar", "rough"):   # (a roughness below ~0.01 overflows GGX's D to inf and the BSDF to inf - inf = NaN, in the reference too: NaN pixels compare equal and test nothing)
@@ -1257,6 +1261,9 @@ def _random_scene(c, seed, big=False):
             nrm = (0.5 * nrm + base).astype(np.float32); nrm /= np.linalg.norm(nrm, axis=1, keepdims=True)
         if rs.random() < 0.5:
             uv = (rs.random((len(P), 2)) * rs.uniform(0.5, 4.0) - 0.7).astype(np.float32)
+        if hydra:   # world.hlsl:127-135: corner 3 * triangle + k
+            nrm = None if nrm is None else np.ascontiguousarray(nrm[np.asarray(I).reshape(-1)])
+            uv = None if uv is None else np.ascontiguousarray(uv[np.asarray(I).reshape(-1)])
         meshes.append(c.create_mesh(P, I, normals=nrm, texcoords=uv))
     n_emit = int(rs.integers(0, 3))
     for k in range(int(rs.integers(20, 60) if big else rs.integers(4, 15))):
@@ -1340,6 +1347,32 @@ def test_random_big_scenes_match_oracle(orc, gpu_api, seed):
     assert same.all(), "seed %d %s: %d values differ" % (seed, pipe, int((~same).sum()))
     assert gc.counters() == {k: v for k, v in oc.counters().items() if k in ("closest_rays", "shadow_rays", "samples")}
     _check_rays(oc, gc, _random_rays(300, seed, radius=8.0))
+
+
+def _fuzz_seeds_hydra():
+    spec = os.environ.get("MSNE_FUZZ_SEEDS")
+    if not spec:
+        return list(range(8))
+    a, _, b = spec.partition("-")
+    return list(range(int(a), int(b or a) + 1))
+
+
+@pytest.mark.parametrize("seed", _fuzz_seeds_hydra())
+def test_random_hydra_scenes_match_oracle(orc, gpu_api, seed):
+    """the randomized scenes the way Hydra's pipeline reads them (hydra.zig:97-105): normals and texture coordinates per face corner (world.hlsl:127-135), raw three-component
+    normal textures (material.hlsl:509-514), the film either way up; every fourth one at size"""
+    rs = np.random.default_rng(300000 + seed)
+    oc, so, lo, gc, sg, lg = both(orc, gpu_api, _random_scene, seed=200000 + seed, big=seed % 4 == 3, hydra=True)
+    pipe = dict(samples_per_run=int(rs.integers(1, 3)), max_bounces=int(rs.integers(0, 7)), env_samples_per_bounce=int(rs.integers(0, 3)), mesh_samples_per_bounce=int(rs.integers(0, 3)),
+                flip_image=bool(rs.random() < 0.5), indexed_attributes=False, two_component_normal_texture=False)
+    for c in (oc, gc):
+        c.set_pipeline(**pipe)
+    n = int(rs.integers(1, 4))
+    gc.render(sg, lg, launches=n); oc.render(so, lo, launches=n)
+    go, oo = gc.sensor_data(sg), oc.sensor_data(so)
+    same = (go.view(np.uint32) == oo.view(np.uint32)) | (np.isnan(go) & np.isnan(oo))
+    assert same.all(), "seed %d %s: %d values differ" % (seed, pipe, int((~same).sum()))
+    assert gc.counters() == {k: v for k, v in oc.counters().items() if k in ("closest_rays", "shadow_rays", "samples")}
 
 
 @pytest.mark.parametrize("seed", _fuzz_seeds())
