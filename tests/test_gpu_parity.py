@@ -1629,6 +1629,39 @@ def test_group_render_equals_single_context(gpu_api, members):
     g.close()
 
 
+def _fuzz_seeds_group():
+    spec = os.environ.get("MSNE_FUZZ_SEEDS")
+    if not spec:
+        return list(range(12))
+    a, _, b = spec.partition("-")
+    return list(range(int(a), int(b or a) + 1))
+
+
+@pytest.mark.parametrize("seed", _fuzz_seeds_group())
+def test_random_groups_equal_single_context(gpu_api, seed):
+    """SURVEY.md §8(e) drawn from seeds: a randomized scene (films from 5 x 5 pixels up, any aspect) rendered by a group of 1 .. 8 members with tiles of 8 .. 64 pixels —
+    more members than tiles, tiles larger than the film, progressive calls of uneven length — assembles to the film of one unsharded context, bit for bit"""
+    rs = np.random.default_rng(400000 + seed)
+    members, tile = int(rs.integers(1, 9)), int(rs.choice([8, 16, 32, 64]))
+    pipe = dict(samples_per_run=int(rs.integers(1, 3)), max_bounces=int(rs.integers(0, 6)), env_samples_per_bounce=int(rs.integers(0, 2)), mesh_samples_per_bounce=int(rs.integers(0, 2)),
+                indexed_attributes=True, two_component_normal_texture=True)
+    calls = [int(v) for v in rs.integers(1, 4, size=int(rs.integers(1, 4)))]
+    ref = gpu_api.Context()
+    s, l = _random_scene(ref, seed=500000 + seed)
+    ref.set_pipeline(**pipe)
+    ref.render(s, l, launches=sum(calls))
+    want = ref.sensor_data(s)
+    g = gpu_api.Group([0] * members, tile_size=tile)
+    gs, gl = g.build(_random_scene, seed=500000 + seed)
+    g.set_pipeline(**pipe)
+    for n in calls:
+        g.render(gs, gl, launches=n)
+    got = g.sensor_data(gs)
+    same = (got.view(np.uint32) == want.view(np.uint32)) | (np.isnan(got) & np.isnan(want))
+    assert same.all(), "seed %d: %d members, tiles of %d, calls %s, film %s: %d values differ" % (seed, members, tile, calls, want.shape, int((~same).sum()))
+    g.close(); ref.close()
+
+
 def test_group_rccl_gather_path(gpu_api, monkeypatch):
     """the RCCL leg of the gather (dlopen of librccl.so, ncclCommInitAll, ncclGather inside a group call) runs with the one
     communicator a one-GPU box can form; with n distinct GPUs the same code gathers n films"""
