@@ -1,8 +1,10 @@
 """GPU tests of the file-level boundary: MsneLoadGlb / MsneSetBackgroundExr / MsneSaveSensorExr and the `offline` CLI
 (offline/main.zig:27-203) against the oracle loaded with the same files through tests/shim."""
+import ctypes as C
 import os
-from moonshine_amd.hostinfo import usable_cores
 import subprocess
+
+from moonshine_amd.hostinfo import usable_cores
 
 import numpy as np
 import pytest
@@ -97,6 +99,38 @@ def test_glb_import_rules_against_a_second_source_on_the_gpu(tmp_path, gpu_api, 
         films.append(c.sensor_data(s))
     assert np.isfinite(films[0]).all() and float(films[0][..., :3].mean()) > 0.01
     assert np.array_equal(bits(films[0]), bits(films[1])), "%d pixels differ" % (bits(films[0]) != bits(films[1])).any(-1).sum()
+
+
+def _glb_fuzz_seeds():
+    spec = os.environ.get("MSNE_FUZZ_SEEDS")
+    if not spec:
+        return list(range(8))
+    a, _, b = spec.partition("-")
+    return list(range(int(a), int(b or a) + 1))
+
+
+@pytest.mark.parametrize("seed", _glb_fuzz_seeds())
+def test_random_glbs_against_a_second_source_on_the_gpu(tmp_path, gpu_api, orc, seed):
+    """glTF files drawn from seeds (tests/io_common.py write_random_glb) through MsneLoadGlb and through tests/second_source_glb.py on two HIP contexts, and through the
+    second source on the oracle: three bit-identical films.  MSNE_FUZZ_SEEDS="a-b" sweeps a range (tools/fuzz_sweep.sh a b seconds random_glbs tests/test_gpu_io.py)"""
+    import second_source_glb
+    glb, exr = str(tmp_path / "scene.glb"), str(tmp_path / "sky.exr")
+    io.write_random_glb(glb, exr, 100000 + seed)
+    films = []
+    for how in ("MsneLoadGlb", "second source", "second source on the oracle"):
+        c = orc.Context(threads=usable_cores()) if "oracle" in how else gpu_api.Context()
+        lens = c.load_glb(glb)[0] if how == "MsneLoadGlb" else second_source_glb.load(c, glb)
+        if "oracle" in how:
+            assert io.shim(orc).ShimSetBackgroundExr(C.c_void_p(c.h), exr.encode()) == 0
+        else:
+            c.set_background_exr(exr)
+        s = c.create_sensor(64, 40)
+        c.set_pipeline(samples_per_run=1, max_bounces=5, env_samples_per_bounce=1, mesh_samples_per_bounce=1)
+        c.render(s, lens, launches=2)
+        films.append(c.sensor_data(s))
+    for k in (1, 2):
+        same = (bits(films[0]) == bits(films[k])) | (np.isnan(films[0]) & np.isnan(films[k]))
+        assert same.all(), "seed %d, film %d: %d values differ" % (seed, k, int((~same).sum()))
 
 
 def test_offline_cli(tmp_path, orc):
