@@ -318,13 +318,16 @@ bool exr_load(const std::string& path, Image& img, std::string& err) {
     if (!r.ok) { err = "truncated EXR offset table"; return false; }
     size_t px_bytes = 0;
     for (size_t c = 0; c < channels.size(); c++) px_bytes += channels[c].type == 1 ? 2 : 4;
-    // which channel feeds which of R,G,B,A (tinyexr: by name; a single channel is replicated)
+    // which channel feeds which of R,G,B,A.  tinyexr's LoadEXR: a file with ONE channel, whatever its name, is a grey image whose value goes to all four components;
+    // otherwise by name, A optional (1.0).  (More lenient than tinyexr, which refuses a file without R, G or B: a missing colour channel reads as 0, a luminance
+    // channel "Y" next to others as grey.)
     int src[4] = { -1, -1, -1, -1 };
     for (size_t c = 0; c < channels.size(); c++) {
         const std::string& nm = channels[c].name;
         if (nm == "R") src[0] = (int)c; else if (nm == "G") src[1] = (int)c; else if (nm == "B") src[2] = (int)c; else if (nm == "A") src[3] = (int)c;
     }
-    if (src[0] < 0 && src[1] < 0 && src[2] < 0) { if (channels.size() == 1 || channels[0].name == "Y") src[0] = src[1] = src[2] = 0; else { err = "EXR has no R/G/B channels"; return false; } }
+    if (channels.size() == 1) src[0] = src[1] = src[2] = src[3] = 0;
+    else if (src[0] < 0 && src[1] < 0 && src[2] < 0) { if (channels[0].name == "Y") src[0] = src[1] = src[2] = 0; else { err = "EXR has no R/G/B channels"; return false; } }
     // a header may claim more pixels than the file can hold: deflate expands at most ~1032:1, RLE 64:1
     if ((double)px_bytes * (double)W * (double)H > (double)file.size() * 1100.0) { err = "EXR data window exceeds the file's data"; return false; }
     img.w = (uint32_t)W; img.h = (uint32_t)H; img.rgba.assign((size_t)W * H * 4, 0.0f);

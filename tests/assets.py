@@ -316,7 +316,7 @@ def exr_bytes(rgba, channels="RGB", pixel_type="float", compression="none", piz_
     if tiles:
         hdr += attr("tiles", "tiledesc", struct.pack("<IIB", tiles[0], tiles[1], {"one": 0, "mipmap": 1, "ripmap": 2}[levels]))   # rounding mode ROUND_DOWN (high nibble 0)
     hdr += b"\0"
-    col = {"R": 0, "G": 1, "B": 2, "A": 3}
+    col = {"R": 0, "G": 1, "B": 2, "A": 3, "Y": 0}
 
     def pack(img, y0, y1, x0, x1):
         """the pixels [y0, y1) x [x0, x1) of img as a chunk's data: per line the channels in file order; compressed when that is smaller"""
@@ -326,7 +326,8 @@ def exr_bytes(rgba, channels="RGB", pixel_type="float", compression="none", piz_
             rows.append([])
             for n in names:
                 v = img[y, x0:x1, col[n]]
-                enc = (v.astype(np.float16) if ptype == 1 else v).tobytes()
+                with np.errstate(over="ignore"):    # (values beyond HALF's range become infinities, as in OpenEXR's float -> half conversion)
+                    enc = (v.astype(np.float16) if ptype == 1 else v).tobytes()
                 raw += enc
                 rows[-1].append(np.frombuffer(enc, "<u2"))
         data = bytes(raw)
@@ -424,7 +425,7 @@ def exr_decode(data):
     nblocks = (h + lines - 1) // lines
     offs = struct.unpack_from("<%dQ" % nblocks, data, pos)
     out = np.zeros((h, w, 4), np.float32); out[..., 3] = 1.0
-    col = {"R": 0, "G": 1, "B": 2, "A": 3}
+    col = {"R": 0, "G": 1, "B": 2, "A": 3, "Y": 0}
     bpp = {1: 2, 2: 4}
     line_bytes = sum(bpp[t] for _, t in chans) * w
     for o in offs:

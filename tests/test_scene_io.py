@@ -73,8 +73,8 @@ def test_exr_piz_reader_against_independent_encoder(tmp_path, name, channels, pt
         ref = img.astype(np.float16).astype(np.float32) if ptype == "half" else img.copy()
         if "A" not in channels:
             ref[..., 3] = 1.0
-        if channels == "G":
-            ref[..., 0] = ref[..., 2] = 0.0
+        if channels == "G":      # one channel, whatever its name: tinyexr's grey image, the value in all four components
+            ref[..., 0] = ref[..., 2] = ref[..., 3] = ref[..., 1]
         assert np.array_equal(bits(got), bits(ref)), (name, channels, ptype, rle)
     if name in ("smooth", "flat"):
         assert len(data) < 0.8 * len(assets.exr_bytes(img, channels, ptype, "none"))     # ... and the encoder does compress
@@ -163,6 +163,55 @@ def test_exr_tiled_reader_against_independent_writer(tmp_path, tiles, levels, ch
         assert sorted(dec) == sorted(channels)
         for ch in channels:
             assert np.array_equal(bits(dec[ch].astype(np.float32)), bits(ref[..., "RGBA".index(ch)]))
+
+
+def _exr_fuzz_seeds():
+    spec = os.environ.get("MSNE_FUZZ_SEEDS")
+    if not spec:
+        return list(range(40))
+    a, _, b = spec.partition("-")
+    return list(range(int(a), int(b or a) + 1))
+
+
+@pytest.mark.parametrize("seed", _exr_fuzz_seeds())
+def test_random_exr_files(tmp_path, seed):
+    """OpenEXR files drawn from seeds — 1 .. 90 x 1 .. 70 pixels of smooth, flat, noisy or special values (zeros, denormals, infinities, huge), channel sets RGB / RGBA / BGR /
+    G / Y, half and float, no / ZIPS / ZIP / PIZ compression, scanline or tiled (tiles of 1 .. 100, one level / mipmap / ripmap, either line order) — written by
+    tests/assets.py, read by the product's reader (moonshine_amd/host/exr.cpp) and by tests/exr_reference.py: the pixels that went in; MSNE_FUZZ_SEEDS="a-b" sweeps a range"""
+    import exr_reference
+    rs = np.random.default_rng(700000 + seed)
+    h, w = int(rs.integers(1, 71)), int(rs.integers(1, 91))
+    kind = int(rs.integers(0, 4))
+    if kind == 0:
+        yy, xx = np.mgrid[0:h, 0:w]
+        img = np.stack([np.sin(xx / 7.0) + 1.5, (yy / max(h, 1)) ** 2 * 9.0, np.cos((xx + yy) / 5.0) * 3.0, np.full((h, w), 0.75)], -1).astype(np.float32)
+    elif kind == 1:
+        img = np.zeros((h, w, 4), np.float32); img[..., 0] = 0.25; img[h // 3: h // 2 + 1, w // 4: w // 2 + 1, 1] = 3.0; img[..., 3] = 1.0
+    elif kind == 2:
+        img = (rs.random((h, w, 4)) * float(rs.choice([1.0, 1000.0]))).astype(np.float32)
+    else:
+        img = rs.choice(np.float32([0.0, -0.0, 1e-40, 6e-8, 1.0, 65504.0, 1e30, np.inf, -2.5]), (h, w, 4)).astype(np.float32)
+    channels = str(rs.choice(["RGB", "RGBA", "BGR", "G", "Y"]))
+    ptype, comp = str(rs.choice(["half", "float"])), str(rs.choice(["none", "zips", "zip", "piz"]))
+    tiles = (int(rs.integers(1, 101)), int(rs.integers(1, 101))) if rs.random() < 0.5 else None
+    levels, order = (str(rs.choice(["one", "mipmap", "ripmap"])), int(rs.integers(0, 2))) if tiles else ("one", int(rs.integers(0, 2)))
+    data = assets.exr_bytes(img, channels, ptype, comp, tiles=tiles, levels=levels, line_order=order)
+    p = str(tmp_path / "f.exr"); open(p, "wb").write(data)
+    with np.errstate(over="ignore"):
+        src = img.astype(np.float16).astype(np.float32) if ptype == "half" else img.copy()
+    dec = exr_reference.read(data)
+    assert sorted(dec) == sorted(channels)
+    for ch in channels:
+        k = "RGBA".index(ch) if ch in "RGBA" else 0
+        assert np.array_equal(bits(dec[ch].astype(np.float32)), bits(src[..., k])), "second reader, channel %s (%s)" % (ch, (w, h, channels, ptype, comp, tiles, levels, order))
+    got = api.exr_load(p)
+    ref = np.zeros((h, w, 4), np.float32); ref[..., 3] = 1.0
+    if channels in ("G", "Y"):        # one channel, whatever its name: grey (exr.zig:109-110 -> tinyexr's LoadEXR puts the value into all four components)
+        ref[..., 0] = ref[..., 1] = ref[..., 2] = ref[..., 3] = src[..., "RGBA".index(channels) if channels in "RGBA" else 0]
+    else:
+        for ch in channels:
+            ref[..., "RGBA".index(ch)] = src[..., "RGBA".index(ch)]
+    assert np.array_equal(bits(got), bits(ref)), "product reader (%s)" % ((w, h, channels, ptype, comp, tiles, levels, order),)
 
 
 def test_exr_tiled_files_that_must_be_rejected(tmp_path):
