@@ -414,7 +414,7 @@ def test_png_decoder_against_pillow(orc, mode, size):
     base = np.clip(base, 0, 255).astype(np.uint8)
     if mode == "I;16":
         a16 = (base[..., 0].astype(np.uint16) << 8) | base[..., 1]
-        im = Image.fromarray(a16, "I;16")
+        im = Image.fromarray(a16)
         want = np.repeat((a16 >> 8).astype(np.uint8)[..., None], 3, -1)
     else:
         nch = {"RGB": 3, "RGBA": 4, "L": 1, "LA": 2, "P": 3, "P4": 3, "P2": 3, "1": 1}[mode]
@@ -430,6 +430,44 @@ def test_png_decoder_against_pillow(orc, mode, size):
         im.save(buf, "PNG", **kw)
         got = io.png_decode(orc, buf.getvalue())
         assert got.shape == want.shape and np.array_equal(got, want), (mode, size, kw)
+
+
+@pytest.mark.parametrize("seed", _exr_fuzz_seeds())
+def test_random_png_files(orc, seed):
+    """PNG files drawn from seeds and written by Pillow — 1 .. 80 x 1 .. 60 pixels of gradients, noise or flat areas (which filter type Pillow picks per row depends on the
+    content), every mode it writes (RGB, RGBA, L, LA, palettes of 2 .. 256 colours, 1-bit, 16-bit grey), any compression level — decoded by the product's reader into the RGB
+    bytes Pillow's own decoder gives; MSNE_FUZZ_SEEDS="a-b" sweeps a range"""
+    Image = pytest.importorskip("PIL.Image")
+    import io as _io
+    rs = np.random.default_rng(800000 + seed)
+    h, w = int(rs.integers(1, 61)), int(rs.integers(1, 81))
+    yy, xx = np.mgrid[0:h, 0:w]
+    kind = int(rs.integers(0, 3))
+    if kind == 0:
+        base = np.stack([(xx * 5 + yy * 3) % 256, (xx * yy) % 256, (255 - xx * 2 - yy) % 256, (xx + yy * 7) % 256], -1) + rs.integers(-6, 7, (h, w, 4))
+    elif kind == 1:
+        base = rs.integers(0, 256, (h, w, 4))
+    else:
+        base = np.zeros((h, w, 4), np.int64) + rs.integers(0, 256, 4); base[h // 3: h // 2 + 1, w // 4: w // 2 + 1] = rs.integers(0, 256, 4)
+    base = np.clip(base, 0, 255).astype(np.uint8)
+    mode = str(rs.choice(["RGB", "RGBA", "L", "LA", "P", "1", "I;16"]))
+    if mode == "I;16":
+        a16 = (base[..., 0].astype(np.uint16) << 8) | base[..., 1]
+        im = Image.fromarray(a16)
+        want = np.repeat((a16 >> 8).astype(np.uint8)[..., None], 3, -1)      # 16-bit samples: the high byte (World.zig reads 8-bit textures)
+    else:
+        nch = {"RGB": 3, "RGBA": 4, "L": 1, "LA": 2, "P": 3, "1": 1}[mode]
+        arr = base[..., :nch] if nch > 1 else base[..., 0]
+        im = Image.fromarray(arr, "RGB" if mode == "P" else "L" if mode == "1" else mode)
+        if mode == "P":
+            im = im.quantize(int(rs.integers(2, 257)))
+        if mode == "1":
+            im = im.convert("1")
+        want = np.asarray(im.convert("RGB"))
+    buf = _io.BytesIO()
+    im.save(buf, "PNG", optimize=bool(rs.random() < 0.3), compress_level=int(rs.integers(0, 10)))
+    got = io.png_decode(orc, buf.getvalue())
+    assert got.shape == want.shape and np.array_equal(got, want), (seed, mode, (w, h), kind)
 
 
 def test_third_party_png_and_exr_files(orc):
