@@ -46,7 +46,7 @@ __global__ __launch_bounds__(SHADE_BLOCK) void k_raygen(ShardView sh, CameraCons
     for (uint32_t slot = blockIdx.x * SHADE_BLOCK + threadIdx.x; slot < total; slot += gridDim.x * SHADE_BLOCK) {
         uint32_t x = 0, y = 0;
         const uint32_t i = slot;
-        if (!shard_pixel(sh, slot % sh.pixels, x, y)) { st.ro[i] = make_float4(0.0f, 0.0f, 0.0f, u2f(PATH_FLAG_ZOMBIE | PATH_FLAG_MASKED)); continue; }
+        if (!shard_pixel(sh, slot % sh.pixels, x, y)) { nt_store(&st.ro[i], make_float4(0.0f, 0.0f, 0.0f, u2f(PATH_FLAG_ZOMBIE | PATH_FLAG_MASKED))); continue; }
         const uint32_t s_local = slot / sh.pixels;
         uint32_t rng = rng_seed(sample_base + s_local, x, y);                       // main.hlsl:85
         f2 r1; r1.x = rng_float(rng); r1.y = rng_float(rng);
@@ -59,7 +59,7 @@ __global__ __launch_bounds__(SHADE_BLOCK) void k_raygen(ShardView sh, CameraCons
         camera_generate_ray(cam, uv, r2, O, D);
         // a camera path starts with throughput 1, radiance 0 and its queue index as its slot: only the ray and the RNG state (in rd.w, which nothing else uses) are
         // written — 32 B per path instead of 80; the first k_shade (first_pass) fills in the rest itself
-        st.ro[i] = make_float4(O.x, O.y, O.z, u2f(0u)); st.rd[i] = make_float4(D.x, D.y, D.z, u2f(rng));
+        nt_store(&st.ro[i], make_float4(O.x, O.y, O.z, u2f(0u))); nt_store(&st.rd[i], make_float4(D.x, D.y, D.z, u2f(rng)));
     }
 }
 
@@ -160,16 +160,16 @@ __global__ __launch_bounds__(SHADE_BLOCK, shade_spec_wps(SPEC, TEX)) void k_shad
         {
             const uint32_t i0 = base_i + threadIdx.x;
             if (i0 < n) {
-                const float4 ro_own = cur.ro[i0];
-                const float4 rd_own = cur.rd[i0];
+                const float4 ro_own = nt_load(&cur.ro[i0]);
+                const float4 rd_own = nt_load(&cur.rd[i0]);
                 s_ro[threadIdx.x] = ro_own; s_rd[threadIdx.x] = rd_own;
                 if (first_pass) { s_tp[threadIdx.x] = make_float4(1.0f, 1.0f, 1.0f, 0.0f); s_lr[threadIdx.x] = make_float4(0.0f, 0.0f, 0.0f, rd_own.w); s_sq[threadIdx.x] = make_uint2(i0, 0u); }
-                else { s_tp[threadIdx.x] = cur.tp[i0]; s_lr[threadIdx.x] = cur.lr[i0]; s_sq[threadIdx.x] = cur.sq[i0]; }
+                else { s_tp[threadIdx.x] = nt_load(&cur.tp[i0]); s_lr[threadIdx.x] = nt_load(&cur.lr[i0]); s_sq[threadIdx.x] = nt_load(&cur.sq[i0]); }
                 const uint32_t fl = f2u(ro_own.w);
                 if (!(fl & (PATH_FLAG_MASKED | PATH_FLAG_DEAD))) {
                     if (fl & PATH_FLAG_ZOMBIE) cat = 0u;
                     else {
-                        const uint4 hr = hits.rec[i0];
+                        const uint4 hr = nt_load(&hits.rec[i0]);
                         s_hit[threadIdx.x] = hr;
                         if (hr.x == MAX_UINT) cat = 1u;
                         else {
@@ -226,7 +226,7 @@ __global__ __launch_bounds__(SHADE_BLOCK, shade_spec_wps(SPEC, TEX)) void k_shad
             if (flags & PATH_FLAG_NEE) {
                 const uint32_t pq = sq2.y;
                 const uint32_t ps = (flags >> PATH_STRIDE_SHIFT) & 0x1ffu;
-                for (uint32_t k = 0; k < n_nee; k++) { const float4 c = c_prev[pq + k * ps]; L = add(L, F3(c.x, c.y, c.z)); }
+                for (uint32_t k = 0; k < n_nee; k++) { const float4 c = nt_load(&c_prev[pq + k * ps]); L = add(L, F3(c.x, c.y, c.z)); }
             }
             bounceCount = flags & 0xFFFFu;
             const bool isLastMaterialDelta = (flags & PATH_FLAG_DELTA) != 0;
@@ -300,7 +300,7 @@ __global__ __launch_bounds__(SHADE_BLOCK, shade_spec_wps(SPEC, TEX)) void k_shad
                 }
                 if (!done) { alive = true; delta = SPEC == 2 ? true : (SPEC >= 3 ? false : material_is_delta(material)); nee = !delta && n_nee != 0u; }
             }
-            if (done) lbuf[slot] = make_float4(L.x, L.y, L.z, 0.0f);
+            if (done) nt_store(&lbuf[slot], make_float4(L.x, L.y, L.z, 0.0f));
         }
         // ---- phase B: queue slots.  One 64-bit atomic per WORKGROUP reserves both ranges (low word: one next-path entry per
         // surviving path, high word: n_nee shadow-ray entries per path that samples lights) — per-wave atomics on one counter
@@ -335,10 +335,10 @@ __global__ __launch_bounds__(SHADE_BLOCK, shade_spec_wps(SPEC, TEX)) void k_shad
                         const f3 so = offset_along_normal(attrs.position, face_forward(attrs.triangleFrame.n, ls.dirWs));
                         const f3 e = estimate_direct_mis(shadingFrame, ls, material, woSs, env_n);
                         const f3 cc = divs(mul(throughput, e), (float)env_n);
-                        shq.o[e_] = make_float4(so.x, so.y, so.z, INFINITY_F); shq.d[e_] = make_float4(ls.dirWs.x, ls.dirWs.y, ls.dirWs.z, 0.0f);
-                        shq.c[e_] = make_float4(cc.x, cc.y, cc.z, 0.0f);
+                        nt_store(&shq.o[e_], make_float4(so.x, so.y, so.z, INFINITY_F)); nt_store(&shq.d[e_], make_float4(ls.dirWs.x, ls.dirWs.y, ls.dirWs.z, 0.0f));
+                        nt_store(&shq.c[e_], make_float4(cc.x, cc.y, cc.z, 0.0f));
                         valid++;
-                    } else { shq.o[e_] = make_float4(0.0f, 0.0f, 0.0f, -1.0f); shq.c[e_] = make_float4(0.0f, 0.0f, 0.0f, 0.0f); }
+                    } else { nt_store(&shq.o[e_], make_float4(0.0f, 0.0f, 0.0f, -1.0f)); nt_store(&shq.c[e_], make_float4(0.0f, 0.0f, 0.0f, 0.0f)); }
                 }
                 for (uint32_t k = 0; k < mesh_n; k++) {  // integrator.hlsl:147-150 + MeshLights::sample light.hlsl:130-158
                     f2 rand; rand.x = rng_float(rng); rand.y = rng_float(rng);
@@ -378,12 +378,12 @@ __global__ __launch_bounds__(SHADE_BLOCK, shade_spec_wps(SPEC, TEX)) void k_shad
                             const float st_ = length(sub(offL, offS)); const f3 sd = normalize(sub(offL, offS));
                             const f3 e = estimate_direct_mis(shadingFrame, ls, material, woSs, mesh_n);
                             const f3 cc = divs(mul(throughput, e), (float)mesh_n);
-                            shq.o[e_] = make_float4(offS.x, offS.y, offS.z, st_); shq.d[e_] = make_float4(sd.x, sd.y, sd.z, 0.0f);
-                            shq.c[e_] = make_float4(cc.x, cc.y, cc.z, 0.0f);
+                            nt_store(&shq.o[e_], make_float4(offS.x, offS.y, offS.z, st_)); nt_store(&shq.d[e_], make_float4(sd.x, sd.y, sd.z, 0.0f));
+                            nt_store(&shq.c[e_], make_float4(cc.x, cc.y, cc.z, 0.0f));
                             ok = true; valid++;
                         }
                     }
-                    if (!ok) { shq.o[e_] = make_float4(0.0f, 0.0f, 0.0f, -1.0f); shq.c[e_] = make_float4(0.0f, 0.0f, 0.0f, 0.0f); }
+                    if (!ok) { nt_store(&shq.o[e_], make_float4(0.0f, 0.0f, 0.0f, -1.0f)); nt_store(&shq.c[e_], make_float4(0.0f, 0.0f, 0.0f, 0.0f)); }
                 }
             }
             // next direction, integrator.hlsl:153-165
@@ -392,8 +392,8 @@ __global__ __launch_bounds__(SHADE_BLOCK, shade_spec_wps(SPEC, TEX)) void k_shad
             if (sample.pdf == 0.0f) {
                 // the path ends here; with light samples in flight it is finalised one pass later (after their shadow rays)
                 atomicAdd(&cnt[1].zombies, 1u);
-                if (valid) { nxt.ro[j] = make_float4(0.0f, 0.0f, 0.0f, u2f(PATH_FLAG_ZOMBIE | PATH_FLAG_NEE | (stride << PATH_STRIDE_SHIFT))); nxt.lr[j] = make_float4(L.x, L.y, L.z, 0.0f); nxt.sq[j] = make_uint2(slot, q); }
-                else { nxt.ro[j] = make_float4(0.0f, 0.0f, 0.0f, u2f(PATH_FLAG_ZOMBIE | PATH_FLAG_DEAD)); lbuf[slot] = make_float4(L.x, L.y, L.z, 0.0f); }
+                if (valid) { nt_store(&nxt.ro[j], make_float4(0.0f, 0.0f, 0.0f, u2f(PATH_FLAG_ZOMBIE | PATH_FLAG_NEE | (stride << PATH_STRIDE_SHIFT)))); nt_store(&nxt.lr[j], make_float4(L.x, L.y, L.z, 0.0f)); nt_store(&nxt.sq[j], make_uint2(slot, q)); }
+                else { nt_store(&nxt.ro[j], make_float4(0.0f, 0.0f, 0.0f, u2f(PATH_FLAG_ZOMBIE | PATH_FLAG_DEAD))); nt_store(&lbuf[slot], make_float4(L.x, L.y, L.z, 0.0f)); }
             } else {
                 const f3 nd = frame_frame_to_world(shadingFrame, sample.dirFs);
                 const f3 no = offset_along_normal(attrs.position, face_forward(attrs.triangleFrame.n, nd));
@@ -401,8 +401,8 @@ __global__ __launch_bounds__(SHADE_BLOCK, shade_spec_wps(SPEC, TEX)) void k_shad
                 const float ac = absf(sample.dirFs.z);
                 const f3 tp = mul(throughput, F3(f.x * ac / sample.pdf, f.y * ac / sample.pdf, f.z * ac / sample.pdf));
                 const uint32_t nf = ((bounceCount + 1u) & 0xFFFFu) | (delta ? PATH_FLAG_DELTA : 0u) | (nee ? (PATH_FLAG_NEE | (stride << PATH_STRIDE_SHIFT)) : 0u);
-                nxt.ro[j] = make_float4(no.x, no.y, no.z, u2f(nf)); nxt.rd[j] = make_float4(nd.x, nd.y, nd.z, 0.0f);
-                nxt.tp[j] = make_float4(tp.x, tp.y, tp.z, sample.pdf); nxt.lr[j] = make_float4(L.x, L.y, L.z, u2f(rng)); nxt.sq[j] = make_uint2(slot, q);
+                nt_store(&nxt.ro[j], make_float4(no.x, no.y, no.z, u2f(nf))); nt_store(&nxt.rd[j], make_float4(nd.x, nd.y, nd.z, 0.0f));
+                nt_store(&nxt.tp[j], make_float4(tp.x, tp.y, tp.z, sample.pdf)); nt_store(&nxt.lr[j], make_float4(L.x, L.y, L.z, u2f(rng))); nt_store(&nxt.sq[j], make_uint2(slot, q));
             }
         }
     }
@@ -431,7 +431,7 @@ __global__ __launch_bounds__(SHADE_BLOCK) void k_film(ShardView sh, PipelineOpts
         for (uint32_t j = 0; j < n_launches; j++) {
             f3 c = F3(0.0f, 0.0f, 0.0f);
             if (!first_chunk) { const float4 q = color[p]; c = F3(q.x, q.y, q.z); }
-            for (uint32_t s = 0; s < s_count; s++) { const float4 l = lbuf[((size_t)j * s_count + s) * sh.pixels + p]; c = add(c, F3(l.x, l.y, l.z)); }
+            for (uint32_t s = 0; s < s_count; s++) { const float4 l = nt_load(&lbuf[((size_t)j * s_count + s) * sh.pixels + p]); c = add(c, F3(l.x, l.y, l.z)); }
             if (!last_chunk) { color[p] = make_float4(c.x, c.y, c.z, 0.0f); continue; }
             const float spr = (float)opts.samples_per_run;
             const uint32_t count = sample_count + j * opts.samples_per_run;

@@ -146,6 +146,23 @@ struct SceneView {
 constexpr uint32_t WORLD_INSTANCE = 0xFFFFFFFEu;
 constexpr uint32_t INST_FLAG_VISIBLE = 1u, INST_FLAG_IDENTITY = 2u, INST_FLAG_WORLD = 4u;
 
+// ---- streaming accesses: path state, queues, hit records and finished samples are written once and read once per bounce — 38 GB per 64-launch batch of S1 next to
+// a BVH of tens of MB.  Marked non-temporal (the `nt` bit of global_load / global_store) they do not push the BVH out of L2 / Infinity Cache: S1 +0.6 %, 20-launch
+// batches +1.1 %, S2 +0.6 %, sky +1.0 % (profiles/r04_nontemporal.txt; -DMSNE_NT=0 for the comparison).  What a kernel reads AGAIN stays temporal: the ray
+// direction a two-level scene reloads at every instance entry (non-temporal it cost S2's k_trace_shadow 3 %). ----
+#ifndef MSNE_NT
+#define MSNE_NT 1
+#endif
+typedef float nt_f4 __attribute__((ext_vector_type(4)));
+typedef uint32_t nt_u4 __attribute__((ext_vector_type(4)));
+typedef uint32_t nt_u2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void nt_store(float4* p, float4 v) { if (MSNE_NT) __builtin_nontemporal_store(nt_f4{ v.x, v.y, v.z, v.w }, reinterpret_cast<nt_f4*>(p)); else *p = v; }
+__device__ __forceinline__ void nt_store(uint4* p, uint4 v) { if (MSNE_NT) __builtin_nontemporal_store(nt_u4{ v.x, v.y, v.z, v.w }, reinterpret_cast<nt_u4*>(p)); else *p = v; }
+__device__ __forceinline__ void nt_store(uint2* p, uint2 v) { if (MSNE_NT) __builtin_nontemporal_store(nt_u2{ v.x, v.y }, reinterpret_cast<nt_u2*>(p)); else *p = v; }
+__device__ __forceinline__ float4 nt_load(const float4* p) { if (!MSNE_NT) return *p; const nt_f4 v = __builtin_nontemporal_load(reinterpret_cast<const nt_f4*>(p)); return make_float4(v.x, v.y, v.z, v.w); }
+__device__ __forceinline__ uint4 nt_load(const uint4* p) { if (!MSNE_NT) return *p; const nt_u4 v = __builtin_nontemporal_load(reinterpret_cast<const nt_u4*>(p)); return make_uint4(v.x, v.y, v.z, v.w); }
+__device__ __forceinline__ uint2 nt_load(const uint2* p) { if (!MSNE_NT) return *p; const nt_u2 v = __builtin_nontemporal_load(reinterpret_cast<const nt_u2*>(p)); return make_uint2(v.x, v.y); }
+
 // ---- wavefront state (one slot per in-flight path; two sets ping-pong between bounces).  Arrays of 16-B records: a wave
 // moves each with one coalesced instruction (five loads per path in k_shade instead of twelve 4-B ones) ----
 struct PathState {

@@ -545,15 +545,15 @@ __global__ __launch_bounds__(TRACE_BLOCK, INSTANCED ? TRACE_WPS_TLAS : TRACE_WPS
     unsigned long long nv = 0, nt = 0;
     trace_wave_loop<false, STATS, INSTANCED>(sc, n, &cnt->head_closest, lds_stack, lds_lut, spill, overflow, refill,
         [&](uint32_t i, f3& o, f3& d, float& tmax) -> bool {
-            const float4 ro = st.ro[i];
+            const float4 ro = nt_load(&st.ro[i]);
             if (f2u(ro.w) & PATH_FLAG_ZOMBIE) return false;
-            const float4 rd = st.rd[i];
+            const float4 rd = INSTANCED ? st.rd[i] : nt_load(&st.rd[i]);   // (two-level scenes read the direction again at every instance they enter: it stays cached)
             o = F3(ro.x, ro.y, ro.z); d = F3(rd.x, rd.y, rd.z); tmax = INFINITY_F;
             return true;
         },
         [&](uint32_t i) -> f3 { const float4 rd = st.rd[i]; return F3(rd.x, rd.y, rd.z); },
         [&](uint32_t i, const Lane& L) {
-            hits.rec[i] = make_uint4(L.best.inst, L.best.tri, f2u(L.best.u), f2u(L.best.v));
+            nt_store(&hits.rec[i], make_uint4(L.best.inst, L.best.tri, f2u(L.best.u), f2u(L.best.v)));
         }, nv, nt, stat_out + 4, nullptr, stat_out + 20);
     if (STATS) { atomicAdd(&stat_out[0], nv); atomicAdd(&stat_out[1], nt); }
 }
@@ -566,7 +566,7 @@ __global__ __launch_bounds__(TRACE_BLOCK, INSTANCED ? TRACE_WPS_TLAS : TRACE_WPS
     unsigned long long nv = 0, nt = 0;
     trace_wave_loop<true, STATS, INSTANCED>(sc, n, &cnt->head_shadow, lds_stack, lds_lut, spill, overflow, refill,
         [&](uint32_t i, f3& o, f3& d, float& tmax) -> bool {
-            const float4 qo = q.o[i], qd = q.d[i];
+            const float4 qo = nt_load(&q.o[i]), qd = INSTANCED ? q.d[i] : nt_load(&q.d[i]);
             if (qo.w < 0.0f) return false;   // unused entry
             o = F3(qo.x, qo.y, qo.z); d = F3(qd.x, qd.y, qd.z); tmax = qo.w;
             return true;
