@@ -1293,14 +1293,19 @@ def _random_scene(c, seed, big=False, hydra=False):
     return c.create_sensor(int(rs.integers(5, 70)), int(rs.integers(5, 50))), lens
 
 
+def _seed_range(default):
+    """the suite's seeds, or every seed of MSNE_FUZZ_SEEDS="a-b" (tools/fuzz_sweep.sh)"""
+    spec = os.environ.get("MSNE_FUZZ_SEEDS")
+    if not spec:
+        return default
+    a, _, b = spec.partition("-")
+    return list(range(int(a), int(b or a) + 1))
+
+
 def _fuzz_seeds():
     """sixteen seeds in the suite, and the five of 0 .. 20 000 that failed in round 4 (coplanar triangles of two instances hit from 2e-3 away: trace.hip cull_slack);
     MSNE_FUZZ_SEEDS="a-b" sweeps a range instead (tools/fuzz_sweep.sh)"""
-    spec = os.environ.get("MSNE_FUZZ_SEEDS")
-    if not spec:
-        return list(range(16)) + [1688, 2297, 7724, 18344, 19491]
-    a, _, b = spec.partition("-")
-    return list(range(int(a), int(b or a) + 1))
+    return _seed_range(list(range(16)) + [1688, 2297, 7724, 18344, 19491])
 
 
 @pytest.mark.parametrize("seed", _fuzz_seeds())
@@ -1324,11 +1329,7 @@ def test_random_scenes_match_oracle(orc, gpu_api, seed):
 
 
 def _fuzz_seeds_big():
-    spec = os.environ.get("MSNE_FUZZ_SEEDS")
-    if not spec:
-        return list(range(4))
-    a, _, b = spec.partition("-")
-    return list(range(int(a), int(b or a) + 1))
+    return _seed_range(list(range(4)))
 
 
 @pytest.mark.parametrize("seed", _fuzz_seeds_big())
@@ -1350,11 +1351,7 @@ def test_random_big_scenes_match_oracle(orc, gpu_api, seed):
 
 
 def _fuzz_seeds_hydra():
-    spec = os.environ.get("MSNE_FUZZ_SEEDS")
-    if not spec:
-        return list(range(8))
-    a, _, b = spec.partition("-")
-    return list(range(int(a), int(b or a) + 1))
+    return _seed_range(list(range(8)))
 
 
 @pytest.mark.parametrize("seed", _fuzz_seeds_hydra())
@@ -1630,11 +1627,7 @@ def test_group_render_equals_single_context(gpu_api, members):
 
 
 def _fuzz_seeds_group():
-    spec = os.environ.get("MSNE_FUZZ_SEEDS")
-    if not spec:
-        return list(range(12))
-    a, _, b = spec.partition("-")
-    return list(range(int(a), int(b or a) + 1))
+    return _seed_range(list(range(12)))
 
 
 @pytest.mark.parametrize("seed", _fuzz_seeds_group())
