@@ -69,6 +69,18 @@ stats = glob.glob(os.path.join(G + "_trace", "**", "*kernel_stats.csv"), recursi
 for r in csv.DictReader(open(stats)):
     lines.append("%-44s %6d %14d %12.0f %10d %12d %6.2f%%" % (short(r["Name"])[:44], int(r["Calls"]), int(r["TotalDurationNs"]), float(r["AverageNs"]),
                                                           int(r["MinNs"]), int(r["MaxNs"]), float(r["Percentage"])))
+# the table above averages over the warm-up batch (4 launches in flight) and the full batches alike; per BATCH — one launch of the kernel per bounce pass — the
+# trace gives the average the bench line's roofline.avg_launch_ms is measured as
+trace = glob.glob(os.path.join(G + "_trace", "**", "*kernel_trace.csv"), recursive=True)
+if trace and line.get("roofline", {}).get("launches"):
+    per_batch = int(line["roofline"]["launches"])
+    for kern in ("k_trace_closest", "k_shade", "k_trace_shadow"):
+        d = sorted((int(r["Start_Timestamp"]), int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) for r in csv.DictReader(open(trace[0])) if ("msne::" + kern) in r["Kernel_Name"])
+        n = per_batch if kern != "k_trace_shadow" else per_batch - 1
+        groups = [[v for _, v in d[g:g + n]] for g in range(0, len(d), n)]
+        lines.append("# %s, batches of %d launches in trace order: %s ms in all, %s ms per launch%s" % (
+            kern, n, " / ".join("%.2f" % (sum(g) / 1e6) for g in groups), " / ".join("%.3f" % (sum(g) / 1e6 / len(g)) for g in groups),
+            "   <- the first is the warm-up batch; roofline.avg_launch_ms of the line below: %.3f" % line["roofline"]["avg_launch_ms"] if kern == line["roofline"].get("kernel") else ""))
 lines += ["", "# the command's own line (HIP-event kernel times inside the timed region; under the profiler)", json.dumps(line)]
 open(os.path.join(ROOT, "profiles", "%s_kernel_stats_%s.txt" % (tag, scene)), "w").write("\n".join(lines) + "\n")
 
