@@ -119,10 +119,82 @@ def spec_lights():
                 extent=(52, 40), opts=dict(max_bounces=4, env_samples_per_bounce=0, mesh_samples_per_bounce=2))
 
 
+def spec_random(seed):
+    """a scene drawn from a seed in the restatement's own description: 2-5 meshes (icospheres with smooth normals and spherical texcoords, quads with texcoords, single
+    triangles), 3-6 materials of every type with constant or image textures (colour, two-component normal map, metalness / roughness, emissive), 3-8 instances under
+    rotations, non-uniform and mirrored scales (one or two geometries each), zero to two sampled emitters, a constant or an image environment, a pinhole or thin-lens
+    camera, 0-2 light samples of either kind, 1-6 bounces.  Parameters stay where f32 follows float64 to 1e-4 (roughness >= 0.3, see spec_textured)."""
+    rs = np.random.default_rng(seed)
+    textures = [_tex(0.5, 0.5, 1.0), _tex(0, 0, 0)]          # 0 = flat normal map, 1 = black
+
+    def tex(kind):
+        w, h = int(rs.integers(2, 7)), int(rs.integers(2, 7))
+        image = rs.random() < 0.4
+        if kind == "rgb":
+            t = np.ones((h, w, 4), np.float32); t[..., :3] = rs.uniform(0.2, 0.9, (h, w, 3)) if image else rs.uniform(0.2, 0.9, 3)
+        elif kind == "normal":
+            if not image:
+                return 0
+            t = np.ones((h, w, 4), np.float32); t[..., :2] = 0.5 + rs.uniform(-0.2, 0.2, (h, w, 2))
+        elif kind == "rough":
+            t = np.ones((h, w, 4), np.float32); t[..., :3] = (rs.uniform(0.3, 0.95, (h, w, 1)) if image else rs.uniform(0.3, 0.95))
+        elif kind == "metal":
+            t = np.ones((h, w, 4), np.float32); t[..., :3] = (rs.uniform(0.0, 1.0, (h, w, 1)) if image else rs.uniform(0.0, 1.0))
+        else:
+            t = np.ones((h, w, 4), np.float32); t[..., :3] = rs.uniform(0.5, 8.0, (h, w, 3)) if image else rs.uniform(0.5, 8.0, 3)
+        textures.append(t if image else t[:1, :1].copy())
+        return len(textures) - 1
+    materials = []
+    for _ in range(int(rs.integers(3, 7))):
+        t = int(rs.integers(0, 4))
+        materials.append(dict(type=t, normal=tex("normal"), emissive=1, color=tex("rgb"), metalness=tex("metal"), roughness=tex("rough"), ior=float(rs.uniform(1.2, 1.9))))
+    glow = len(materials)
+    materials.append(dict(type=ss.LAMBERT, normal=0, emissive=tex("emissive"), color=1, metalness=1, roughness=1, ior=1.5))
+    meshes = []
+    for _ in range(int(rs.integers(2, 6))):
+        k = int(rs.integers(0, 3))
+        if k == 0:
+            P, I = scenes.icosphere(int(rs.integers(0, 2)))
+            m = dict(positions=P, indices=I)
+            if rs.random() < 0.6:
+                m["normals"] = (P / np.linalg.norm(P, axis=1, keepdims=True)).astype(np.float32)
+            if rs.random() < 0.6:
+                m["texcoords"] = (np.stack([np.arctan2(P[:, 1], P[:, 0]) / (2 * math.pi) + 0.5, np.arccos(np.clip(P[:, 2], -1, 1)) / math.pi], -1) * float(rs.uniform(0.8, 2.5))).astype(np.float32)
+        elif k == 1:
+            # (every quad in a plane of its own: two coplanar surfaces of one instance are a tie the brute-force tracer and a BVH tracer break differently)
+            e = float(rs.uniform(0.6, 3.5)); z = float(rs.uniform(-0.5, 0.5)); m = _quad_mesh((-e, -e, z), (e, -e, z), (e, e, z), (-e, e, z), uv=bool(rs.random() < 0.6))
+        else:
+            m = dict(positions=rs.normal(size=(3, 3)).astype(np.float32), indices=np.array([[0, 1, 2]], np.uint32))
+        meshes.append(m)
+    n_emit = int(rs.integers(0, 3))
+    inst = [dict(transform=None, geometries=[(len(meshes), int(rs.integers(len(materials) - 1)), False)])]      # a floor under everything
+    meshes.append(_quad_mesh((-5, -5, 0), (5, -5, 0), (5, 5, 0), (-5, 5, 0), uv=True))
+    for k in range(int(rs.integers(3, 9))):
+        R = _rot(rs.normal(size=3) + 1e-3, rs.random() * 6.0) * (rs.uniform(0.5, 1.3, 3) * rs.choice([-1.0, 1.0], 3, p=[0.15, 0.85]) if rs.random() < 0.5 else float(rs.uniform(0.5, 1.3)))
+        T = _xf(R, (float(rs.normal() * 1.8), float(rs.normal() * 1.8), float(rs.uniform(0.4, 2.8))))
+        if k < n_emit:
+            geos = [(int(rs.integers(len(meshes) - 1)), glow, True)]
+        else:
+            geos = [(int(rs.integers(len(meshes) - 1)), int(rs.integers(len(materials) - 1)), False) for _ in range(1 + int(rs.random() < 0.25))]
+        inst.append(dict(transform=T, geometries=geos))
+    if rs.random() < 0.5:
+        bg = np.ones((1, 1, 4), np.float32); bg[..., :3] = rs.uniform(0.1, 0.9, 3)
+    else:
+        bg = scenes.sky_sun_equirect(32, 16)
+    o = rs.normal(size=3); o[2] = abs(o[2]) + 0.4; o = o / np.linalg.norm(o) * rs.uniform(6.0, 9.0); f = np.array([0, 0, 0.8]) - o
+    lens = dict(origin=tuple(np.float32(o)), forward=tuple(np.float32(f / np.linalg.norm(f))), up=(0, 0, 1), vfov=float(rs.uniform(0.5, 1.0)),
+                aperture=float(rs.choice([0.0, 0.05])), focus_distance=float(rs.uniform(4.0, 9.0)))
+    return dict(textures=textures, materials=materials, meshes=meshes, instances=inst, background=bg, lens=lens, extent=(int(rs.integers(24, 49)), int(rs.integers(18, 37))),
+                opts=dict(max_bounces=int(rs.integers(1, 7)), env_samples_per_bounce=int(rs.integers(0, 3)), mesh_samples_per_bounce=int(rs.integers(0, 3))))
+
+
 SPECS = {"mixed": spec_mixed, "textured": spec_textured, "hydra_mode": lambda: spec_textured(indexed=False, two_component=False, env_n=1, mesh_n=1), "lights": spec_lights}
 
 
-def compare(ctx, spec, launches=2):
+def compare(ctx, spec, launches=2, strict=True):
+    """strict: the thresholds of the four hand-made scenes.  Scenes drawn from seeds are 400-1700 pixels small and one bright ill-conditioned pixel moves their relative
+    L2 and their mean: for them the typical pixel is held to 1e-5 (median), the image to 1e-3, the mean to 5 % (5200 seeds: 13 beyond the strict thresholds, all by
+    one to four pixels, worst relative L2 4.7e-4)"""
     sensor, lens = ssr.build_context(ctx, spec)
     rgb, lum = ctx.env()
     env = ss.EnvMap(rgb, [np.asarray(l, np.float32) for l in lum])              # the textures the shader reads (their construction is checked in test_second_source.py)
@@ -142,20 +214,44 @@ def compare(ctx, spec, launches=2):
         # a pixel either follows the same path as the restatement — then it differs by f32 rounding, amplified where the formulas are ill-conditioned
         # (the rescaled random numbers of the mip descent, GGX's D near its peak, bilinear weights): up to a few 1e-3 on single pixels — or a decision
         # flipped somewhere along it and the sample is a different one altogether
-        scale = np.maximum(np.abs(ref), np.abs(ref).mean())
         finite = np.isfinite(ref).all(-1) & np.isfinite(got).all(-1)
+        scale = np.maximum(np.abs(ref), np.abs(ref[finite]).mean())      # (the image scale over the finite pixels: one NaN pixel must not turn every error into NaN)
         err = np.where(finite[..., None], np.abs(got - ref) / scale, 0.0).max(-1)
         diverged = finite & (err > 5e-3)
         same = finite & ~diverged
         rel = float(np.linalg.norm(got[same] - ref[same]) / np.linalg.norm(ref[same]))
         report.append(dict(sample=k, pixels=int(finite.sum()), diverged=int(diverged.sum()), beyond_1e4=int((same & (err > 1e-4)).sum()), rel_l2=rel,
                            mean_ratio=float(got[finite].mean() / ref[finite].mean())))
-        assert finite.mean() > 0.995, report
+        assert finite.mean() > (0.995 if strict else 0.98), report
         assert diverged.mean() <= 0.01, "sample %d: %.2f %% of the paths diverge from the float64 restatement: %s" % (k, 100 * diverged.mean(), report)
         assert (same & (err > 1e-4)).mean() <= 0.03, report
-        assert rel < 1e-4, report                                  # north_star: relative per-pixel L2 below 1e-4
-        assert abs(report[-1]["mean_ratio"] - 1) < 0.02, report
+        assert rel < (1e-4 if strict else 1e-3), report            # north_star: relative per-pixel L2 below 1e-4
+        assert abs(report[-1]["mean_ratio"] - 1) < (0.02 if strict else 0.05), report
+        assert strict or float(np.median(err[same])) < 1e-5, report
     return report
+
+
+def _random_seeds():
+    import os
+    spec = os.environ.get("MSNE_FUZZ_SEEDS")
+    if not spec:
+        return list(range(6))
+    a, _, b = spec.partition("-")
+    return list(range(int(a), int(b or a) + 1))
+
+
+@pytest.mark.parametrize("seed", _random_seeds())
+def test_oracle_images_match_the_float64_path_tracer_on_random_scenes(orc, seed):
+    """scenes drawn from seeds (spec_random) through the oracle and through the float64 restatement, pixel by pixel; MSNE_FUZZ_SEEDS="a-b" sweeps a range"""
+    rep = compare(orc.Context(threads=8), spec_random(seed), launches=1, strict=False)
+    print(seed, rep)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", _random_seeds())
+def test_hip_images_match_the_float64_path_tracer_on_random_scenes(gpu_api, seed):
+    rep = compare(gpu_api.Context(), spec_random(seed), launches=1, strict=False)
+    print(seed, rep)
 
 
 @pytest.mark.parametrize("name", list(SPECS))
