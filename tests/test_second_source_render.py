@@ -125,7 +125,8 @@ def spec_random(seed):
     rotations, non-uniform and mirrored scales (one or two geometries each), zero to two sampled emitters, a constant or an image environment, a pinhole or thin-lens
     camera, 0-2 light samples of either kind, 1-6 bounces.  Parameters stay where f32 follows float64 to 1e-4 (roughness >= 0.3, see spec_textured)."""
     rs = np.random.default_rng(seed)
-    textures = [_tex(0.5, 0.5, 1.0), _tex(0, 0, 0)]          # 0 = flat normal map, 1 = black
+    hydra = bool(rs.random() < 0.3)                           # Hydra's reading (hydra.zig:97-105): attributes per face corner, raw three-component normal maps, either film orientation
+    textures = [_tex(0, 0, 1.0) if hydra else _tex(0.5, 0.5, 1.0), _tex(0, 0, 0)]          # 0 = flat normal map, 1 = black
 
     def tex(kind):
         w, h = int(rs.integers(2, 7)), int(rs.integers(2, 7))
@@ -135,7 +136,7 @@ def spec_random(seed):
         elif kind == "normal":
             if not image:
                 return 0
-            t = np.ones((h, w, 4), np.float32); t[..., :2] = 0.5 + rs.uniform(-0.2, 0.2, (h, w, 2))
+            t = np.ones((h, w, 4), np.float32); t[..., :2] = (rs.normal(size=(h, w, 2)) * 0.2) if hydra else (0.5 + rs.uniform(-0.2, 0.2, (h, w, 2)))
         elif kind == "rough":
             t = np.ones((h, w, 4), np.float32); t[..., :3] = (rs.uniform(0.3, 0.95, (h, w, 1)) if image else rs.uniform(0.3, 0.95))
         elif kind == "metal":
@@ -165,10 +166,18 @@ def spec_random(seed):
             e = float(rs.uniform(0.6, 3.5)); z = float(rs.uniform(-0.5, 0.5)); m = _quad_mesh((-e, -e, z), (e, -e, z), (e, e, z), (-e, e, z), uv=bool(rs.random() < 0.6))
         else:
             m = dict(positions=rs.normal(size=(3, 3)).astype(np.float32), indices=np.array([[0, 1, 2]], np.uint32))
+        if hydra:      # world.hlsl:127-135: attribute 3 * triangle + corner
+            c = np.asarray(m["indices"]).reshape(-1)
+            for key in ("normals", "texcoords"):
+                if m.get(key) is not None:
+                    m[key] = np.ascontiguousarray(np.asarray(m[key])[c])
         meshes.append(m)
     n_emit = int(rs.integers(0, 3))
     inst = [dict(transform=None, geometries=[(len(meshes), int(rs.integers(len(materials) - 1)), False)])]      # a floor under everything
-    meshes.append(_quad_mesh((-5, -5, 0), (5, -5, 0), (5, 5, 0), (-5, 5, 0), uv=True))
+    floor = _quad_mesh((-5, -5, 0), (5, -5, 0), (5, 5, 0), (-5, 5, 0), uv=True)
+    if hydra:
+        floor["texcoords"] = np.ascontiguousarray(floor["texcoords"][floor["indices"].reshape(-1)])
+    meshes.append(floor)
     for k in range(int(rs.integers(3, 9))):
         R = _rot(rs.normal(size=3) + 1e-3, rs.random() * 6.0) * (rs.uniform(0.5, 1.3, 3) * rs.choice([-1.0, 1.0], 3, p=[0.15, 0.85]) if rs.random() < 0.5 else float(rs.uniform(0.5, 1.3)))
         T = _xf(R, (float(rs.normal() * 1.8), float(rs.normal() * 1.8), float(rs.uniform(0.4, 2.8))))
@@ -185,7 +194,8 @@ def spec_random(seed):
     lens = dict(origin=tuple(np.float32(o)), forward=tuple(np.float32(f / np.linalg.norm(f))), up=(0, 0, 1), vfov=float(rs.uniform(0.5, 1.0)),
                 aperture=float(rs.choice([0.0, 0.05])), focus_distance=float(rs.uniform(4.0, 9.0)))
     return dict(textures=textures, materials=materials, meshes=meshes, instances=inst, background=bg, lens=lens, extent=(int(rs.integers(24, 49)), int(rs.integers(18, 37))),
-                opts=dict(max_bounces=int(rs.integers(1, 7)), env_samples_per_bounce=int(rs.integers(0, 3)), mesh_samples_per_bounce=int(rs.integers(0, 3))))
+                opts=dict(max_bounces=int(rs.integers(1, 7)), env_samples_per_bounce=int(rs.integers(0, 3)), mesh_samples_per_bounce=int(rs.integers(0, 3)),
+                          indexed_attributes=not hydra, two_component_normal_texture=not hydra, flip_image=bool(rs.random() < 0.5) if hydra else True))
 
 
 SPECS = {"mixed": spec_mixed, "textured": spec_textured, "hydra_mode": lambda: spec_textured(indexed=False, two_component=False, env_n=1, mesh_n=1), "lights": spec_lights}
@@ -219,9 +229,9 @@ def compare(ctx, spec, launches=2, strict=True):
         err = np.where(finite[..., None], np.abs(got - ref) / scale, 0.0).max(-1)
         diverged = finite & (err > 5e-3)
         same = finite & ~diverged
-        rel = float(np.linalg.norm(got[same] - ref[same]) / np.linalg.norm(ref[same]))
+        rel = float(np.linalg.norm(got[same] - ref[same]) / max(np.linalg.norm(ref[same]), 1e-300))      # (a black image: both must be black)
         report.append(dict(sample=k, pixels=int(finite.sum()), diverged=int(diverged.sum()), beyond_1e4=int((same & (err > 1e-4)).sum()), rel_l2=rel,
-                           mean_ratio=float(got[finite].mean() / ref[finite].mean())))
+                           mean_ratio=float(got[finite].mean() / ref[finite].mean()) if ref[finite].mean() != 0 else (1.0 if got[finite].mean() == 0 else float("inf"))))
         assert finite.mean() > (0.995 if strict else 0.98), report
         assert diverged.mean() <= 0.01, "sample %d: %.2f %% of the paths diverge from the float64 restatement: %s" % (k, 100 * diverged.mean(), report)
         assert (same & (err > 1e-4)).mean() <= 0.03, report
