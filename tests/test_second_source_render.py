@@ -225,7 +225,7 @@ def compare(ctx, spec, launches=2, strict=True):
         # (the rescaled random numbers of the mip descent, GGX's D near its peak, bilinear weights): up to a few 1e-3 on single pixels — or a decision
         # flipped somewhere along it and the sample is a different one altogether
         finite = np.isfinite(ref).all(-1) & np.isfinite(got).all(-1)
-        scale = np.maximum(np.abs(ref), np.abs(ref[finite]).mean())      # (the image scale over the finite pixels: one NaN pixel must not turn every error into NaN)
+        scale = np.maximum(np.maximum(np.abs(ref), np.abs(ref[finite]).mean()), 1e-300)      # (the image scale over the finite pixels: one NaN pixel must not turn every error into NaN; a black image: 0 / tiny = 0)
         err = np.where(finite[..., None], np.abs(got - ref) / scale, 0.0).max(-1)
         diverged = finite & (err > 5e-3)
         same = finite & ~diverged
