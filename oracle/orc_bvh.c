@@ -93,8 +93,8 @@ static uint32_t collapse(const bnode *bn, uint32_t root, orc_wnode *wn, uint32_t
     w.nchild = (uint8_t)nch;
     for (int i = 0; i < nch; i++) {
         const bnode *c = &bn[ch[i]];
-        w.lo[i][0] = c->box.lo.x; w.lo[i][1] = c->box.lo.y; w.lo[i][2] = c->box.lo.z;
-        w.hi[i][0] = c->box.hi.x; w.hi[i][1] = c->box.hi.y; w.hi[i][2] = c->box.hi.z;
+        w.lo[0][i] = c->box.lo.x; w.lo[1][i] = c->box.lo.y; w.lo[2][i] = c->box.lo.z;
+        w.hi[0][i] = c->box.hi.x; w.hi[1][i] = c->box.hi.y; w.hi[2][i] = c->box.hi.z;
         if (c->count > 0) { w.child[i] = c->first; w.count[i] = (uint8_t)c->count; }
     }
     for (int i = 0; i < nch; i++) if (bn[ch[i]].count == 0) w.child[i] = collapse(bn, ch[i], wn, nw);
@@ -254,37 +254,54 @@ static inline float safe_inv(float d) { return fabsf(d) < 1e-30f ? (d < 0.0f ? -
  * without the slack the second of two coincident triangles in different instances was culled against the first one's t, and the tie went to whichever instance the
  * TLAS reached first instead of the smaller index (found by tests/test_gpu_parity.py::test_random_scenes_match_oracle, seed 13).  The HIP traversal bounds the same
  * quantity per ray and space instead of per box (trace.hip cull_slack): neither side may cull a triangle that could still win, then both take the same minimum. */
-static inline int box_hit(const float lo[3], const float hi[3], v3 o, v3 id, float tmax, float *tnear) {
-    float t1 = (lo[0] - o.x) * id.x, t2 = (hi[0] - o.x) * id.x, mx = orc_maxf(fabsf(t1), fabsf(t2)), e = 1e-5f * mx;
-    float tn = orc_minf(t1, t2) - e, tf = orc_maxf(t1, t2) + e;
-    t1 = (lo[1] - o.y) * id.y; t2 = (hi[1] - o.y) * id.y; const float my = orc_maxf(fabsf(t1), fabsf(t2)); e = 1e-5f * my;
-    tn = orc_maxf(tn, orc_minf(t1, t2) - e); tf = orc_minf(tf, orc_maxf(t1, t2) + e);
-    t1 = (lo[2] - o.z) * id.z; t2 = (hi[2] - o.z) * id.z; const float mz = orc_maxf(fabsf(t1), fabsf(t2)); e = 1e-5f * mz;
-    tn = orc_maxf(tn, orc_minf(t1, t2) - e); tf = orc_minf(tf, orc_maxf(t1, t2) + e);
-    *tnear = tn;
-    /* the dominant axis has the smallest |1/d|; among equals the larger distance */
+/* What box_hit needs of the ray beyond (o, 1/d), once per ray and space instead of once per box: which axes are dominant (smallest |1/d|; all that tie). */
+typedef struct { v3 o, id; int domx, domy, domz; } orc_rayb;
+static inline orc_rayb rayb_make(v3 o, v3 id) {
+    orc_rayb r; r.o = o; r.id = id;
     const float ax = fabsf(id.x), ay = fabsf(id.y), az = fabsf(id.z), amin = orc_minf(ax, orc_minf(ay, az));
-    float far_ = 0.0f;
-    if (ax == amin) far_ = orc_maxf(far_, mx);
-    if (ay == amin) far_ = orc_maxf(far_, my);
-    if (az == amin) far_ = orc_maxf(far_, mz);
-    return tn <= tf && tf >= 0.0f && tn <= tmax + 1.5e-6f * far_;
+    r.domx = ax == amin; r.domy = ay == amin; r.domz = az == amin;
+    return r;
+}
+/* All eight boxes of a node at once (the best hit does not change between the box tests of one visit): bit i of the result = box i is hit, tnear[i] its entry
+ * distance.  Every box goes through the expressions above one by one — the loop only lets the compiler use vector registers for them. */
+static inline unsigned box_hit8(const orc_wnode *n, const orc_rayb *r, float tmax, float tnear[8]) {
+    const float ox = r->o.x, oy = r->o.y, oz = r->o.z, ix = r->id.x, iy = r->id.y, iz = r->id.z;
+    const float fx = r->domx ? 1.0f : 0.0f, fy = r->domy ? 1.0f : 0.0f, fz = r->domz ? 1.0f : 0.0f;   /* the dominant axis has the smallest |1/d|; among equals the larger distance */
+    int ok[8];
+    for (int i = 0; i < 8; i++) {
+        float t1 = (n->lo[0][i] - ox) * ix, t2 = (n->hi[0][i] - ox) * ix; const float mx = orc_maxf(fabsf(t1), fabsf(t2)); float e = 1e-5f * mx;
+        float tn = orc_minf(t1, t2) - e, tf = orc_maxf(t1, t2) + e;
+        t1 = (n->lo[1][i] - oy) * iy; t2 = (n->hi[1][i] - oy) * iy; const float my = orc_maxf(fabsf(t1), fabsf(t2)); e = 1e-5f * my;
+        tn = orc_maxf(tn, orc_minf(t1, t2) - e); tf = orc_minf(tf, orc_maxf(t1, t2) + e);
+        t1 = (n->lo[2][i] - oz) * iz; t2 = (n->hi[2][i] - oz) * iz; const float mz = orc_maxf(fabsf(t1), fabsf(t2)); e = 1e-5f * mz;
+        tn = orc_maxf(tn, orc_minf(t1, t2) - e); tf = orc_minf(tf, orc_maxf(t1, t2) + e);
+        tnear[i] = tn;
+        float far_ = 0.0f;   /* (m >= 0: max(0, m) = m for a dominant axis, and an axis that is not dominant contributes 0) */
+        far_ = orc_maxf(far_, fx != 0.0f ? mx : 0.0f);
+        far_ = orc_maxf(far_, fy != 0.0f ? my : 0.0f);
+        far_ = orc_maxf(far_, fz != 0.0f ? mz : 0.0f);
+        ok[i] = (tn <= tf) & (tf >= 0.0f) & (tn <= tmax + 1.5e-6f * far_);
+    }
+    unsigned m = 0;
+    for (int i = 0; i < n->nchild; i++) m |= (unsigned)(ok[i] != 0) << i;
+    return m;
 }
 
 /* traverse one BLAS in instance space. any_hit: return at the first triangle with t < tmax */
 static int blas_traverse(const orc_bvh *b, v3 o, v3 d, uint32_t inst, orc_hit *best, int any_hit, orc_counters *cnt) {
     if (b->node_count == 0) return 0;
-    v3 id = V3(safe_inv(d.x), safe_inv(d.y), safe_inv(d.z));
+    const orc_rayb rb = rayb_make(o, V3(safe_inv(d.x), safe_inv(d.y), safe_inv(d.z)));
     const orc_rayk rk = rayk_make(d);
     uint32_t stack[256]; int sp = 0; int found = 0;
     stack[sp++] = 0;
     while (sp > 0) {
         const orc_wnode *n = &b->nodes[stack[--sp]];
         cnt->node_visits++; if (any_hit) cnt->shadow_node_visits++;
-        float tn[8]; int idx[8]; int nh = 0;
+        float tn[8], tb[8]; int idx[8]; int nh = 0;
+        const unsigned hm = box_hit8(n, &rb, best->t, tb);
         for (int i = 0; i < n->nchild; i++) {
-            float t;
-            if (box_hit(n->lo[i], n->hi[i], o, id, best->t, &t)) {
+            const float t = tb[i];
+            if (hm >> i & 1u) {
                 int j = nh++;
                 while (j > 0 && tn[j - 1] < t) { tn[j] = tn[j - 1]; idx[j] = idx[j - 1]; j--; } /* far first */
                 tn[j] = t; idx[j] = i;
@@ -292,7 +309,11 @@ static int blas_traverse(const orc_bvh *b, v3 o, v3 d, uint32_t inst, orc_hit *b
         }
         for (int k = 0; k < nh; k++) {
             int i = idx[k];
-            if (n->count[i] == 0) { if (sp < 255) stack[sp++] = n->child[i]; else { fprintf(stderr, "orc: bvh stack overflow\n"); abort(); } }
+            if (n->count[i] == 0) {
+                if (sp < 255) stack[sp++] = n->child[i]; else { fprintf(stderr, "orc: bvh stack overflow\n"); abort(); }
+                const char *pf = (const char *)&b->nodes[n->child[i]];   /* (the tree is far larger than the caches: a visit is a chain of misses) */
+                __builtin_prefetch(pf); __builtin_prefetch(pf + 64); __builtin_prefetch(pf + 128); __builtin_prefetch(pf + 192);
+            } else __builtin_prefetch(&b->tris[n->child[i]]);
         }
         for (int k = nh - 1; k >= 0; k--) { /* leaves: near first */
             int i = idx[k];
@@ -318,16 +339,17 @@ static int scene_traverse(const OrcContext *c, v3 o, v3 d, float tmax, orc_hit *
     best->inst = ORC_MAX_UINT; best->t = tmax; best->geo = best->prim = 0; best->u = best->v = 0.0f;
     const orc_bvh *tl = &c->tlas;
     if (tl->node_count == 0) return 0;
-    v3 id = V3(safe_inv(d.x), safe_inv(d.y), safe_inv(d.z));
+    const orc_rayb rb = rayb_make(o, V3(safe_inv(d.x), safe_inv(d.y), safe_inv(d.z)));
     uint32_t stack[256]; int sp = 0; int found = 0;
     stack[sp++] = 0;
     while (sp > 0) {
         const orc_wnode *n = &tl->nodes[stack[--sp]];
         cnt->node_visits++; if (any_hit) cnt->shadow_node_visits++;
-        float tn[8]; int idx[8]; int nh = 0;
+        float tn[8], tb[8]; int idx[8]; int nh = 0;
+        const unsigned hm = box_hit8(n, &rb, best->t, tb);
         for (int i = 0; i < n->nchild; i++) {
-            float t;
-            if (box_hit(n->lo[i], n->hi[i], o, id, best->t, &t)) {
+            const float t = tb[i];
+            if (hm >> i & 1u) {
                 int j = nh++;
                 while (j > 0 && tn[j - 1] < t) { tn[j] = tn[j - 1]; idx[j] = idx[j - 1]; j--; }
                 tn[j] = t; idx[j] = i;

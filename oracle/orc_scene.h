@@ -30,7 +30,7 @@ typedef struct {
 /* canonical BVH: LBVH, 30-bit Morton, leaves <=4, collapsed to <=8-wide */
 typedef struct { v3 v0, v1, v2; uint32_t geo, prim; } orc_tri;          /* object space */
 typedef struct {
-    float lo[8][3], hi[8][3];
+    float lo[3][8], hi[3][8];   /* [axis][child]: the eight box tests of a visit are one loop the compiler vectorises (slots >= nchild hold zeros and are ignored) */
     uint32_t child[8];      /* internal: node index; leaf: first item */
     uint8_t  count[8];      /* 0 = internal, else number of items in the leaf */
     uint8_t  nchild;
