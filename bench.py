@@ -174,6 +174,8 @@ def main():
     ap.add_argument("--scene", default="s1", choices=["s1", "s2"])
     ap.add_argument("--env", default="constant", choices=["constant", "sky"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--sustain-seconds", type=float, default=0.0,
+                    help="after the timed repeats: back-to-back K-step batches for at least this long, reported as `sustained` (rate per 1-s window, shader clock at both ends); 0 = off")
     ap.add_argument("--dump-film", default=None, help="rank 0 saves the assembled film of the last repeat here (.npy): parity tests of the gather path")
     a = ap.parse_args()
 
@@ -262,6 +264,45 @@ def main():
     sync()
     sa = ctx.stats()
     ctx.set_profiling(kernel_events=False, traversal_counters=False)
+
+    # A render is seconds of launches (offline/main.zig:131-165), the timed region above a burst of tens of milliseconds: with --sustain-seconds S the same K-step batch
+    # runs back to back for at least S seconds.  Per-batch wall times give the rate per 1-s window; the shader clock is probed by one wave on a stream of its own
+    # (MsneProbeClockGhz) from a second host thread while the batches run.
+    sustained = None
+    if a.sustain_seconds > 0:
+        import threading
+        clocks, stop = [], threading.Event()
+
+        def probe():
+            while not stop.is_set():
+                g = api.load_library().MsneProbeClockGhz(dev)
+                if g > 0:
+                    clocks.append((time.perf_counter(), g))
+                stop.wait(0.25)
+        ctx.reset_stats(); sync()
+        th = threading.Thread(target=probe, daemon=True); th.start()
+        marks = [time.perf_counter()]
+        while marks[-1] - marks[0] < a.sustain_seconds:
+            ctx.clear_sensor(sensor)
+            ctx.render(sensor, lens, launches=a.steps, readback=False)
+            gather()
+            marks.append(time.perf_counter())
+        sync()
+        stop.set(); th.join()
+        ss = ctx.stats(); nb = len(marks) - 1
+        rays_batch = (ss["closest_rays"] + ss["shadow_rays"]) / float(nb)
+        total_s = marks[-1] - marks[0]
+        wins, w0, k0 = [], marks[0], 0      # rate of every whole 1-s window: batches completed in it / its length
+        for k in range(1, len(marks)):
+            if marks[k] - w0 >= 1.0:
+                wins.append(rays_batch * (k - k0) / (marks[k] - w0) / 1e6); w0, k0 = marks[k], k
+        third = max(len(clocks) // 3, 1)
+        sustained = {"mrays_per_s": rays_batch * nb / total_s / 1e6, "seconds": total_s, "batches": nb, "steps_per_batch": a.steps,
+                     "min_1s": min(wins) if wins else None, "median_1s": statistics.median(wins) if wins else None, "max_1s": max(wins) if wins else None,
+                     "clock_ghz_first": statistics.median([g for _, g in clocks[:third]]) if clocks else None,
+                     "clock_ghz_last": statistics.median([g for _, g in clocks[-third:]]) if clocks else None,
+                     "clock_ghz_min": min(g for _, g in clocks) if clocks else None, "clock_probes": len(clocks),
+                     "clock_from": "s_memtime / s_memrealtime (100 MHz) around a 0.2-ms spin of one probe wave, while the batches run"}
 
     NDEV = 64
     tt = torch.tensor(times + [float(st["closest_rays"]) / R, float(st["shadow_rays"]) / R, float(st["samples"]) / R, 1.0] + [float(i == dev) for i in range(NDEV)],
@@ -375,6 +416,8 @@ def main():
             "profile_totals": {"closest_rays": warm["closest_rays"] + st["closest_rays"] + sa["closest_rays"], "shadow_rays": warm["shadow_rays"] + st["shadow_rays"] + sa["shadow_rays"],
                                "samples": warm["samples"] + st["samples"] + sa["samples"]},
         }
+        if sustained is not None:
+            out["sustained"] = sustained     # this rank's batches (at N > 1 every rank runs the same loop, gather included)
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(a)
         print(json.dumps(out))

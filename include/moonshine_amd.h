@@ -185,6 +185,9 @@ int64_t MsneCreateMesh(HdMoonshine*, const F32x3* positions, const F32x3* normal
 int64_t MsneCreateTexture(HdMoonshine*, const void* bytes, Extent2D, MsneTextureFormat);
 /* MaterialManager.upload (MaterialManager.zig:140-170) with any variant */
 int64_t MsneCreateMaterial(HdMoonshine*, const MsneMaterialDesc*);
+/* Accel.recordUpdateSingleMaterial (Accel.zig:609-628; caller online/main.zig:229-233): geometry `geometry_index` of `instance` uses `material` from the next
+ * render on.  One record update — no rebuild; nothing is cleared (the reference's caller clears the sensor itself).  0 on success, negative for unknown handles. */
+int MsneSetGeometryMaterial(HdMoonshine*, InstanceHandle instance, uint32_t geometry_index, MaterialHandle material);
 /* StandardPipeline.create / recreate (pipeline.zig:85,180): change specialization constants; clears all sensors */
 int MsneSetPipeline(HdMoonshine*, const MsnePipelineOpts*);
 int MsneGetPipeline(const HdMoonshine*, MsnePipelineOpts*);
@@ -274,6 +277,9 @@ const char* MsneGroupGetLastError(const MsneGroup*);     /* NULL group -> last c
  * the next one), so that per-kernel durations are exclusive — what bench.py's roofline attribution pass uses;
  * traversal_counters: count BVH node visits / triangle tests inside the trace kernels. */
 void MsneSetProfiling(HdMoonshine*, int kernel_events, int traversal_counters);
+/* The shader clock right now, in GHz (negative on failure): one probe wave on a stream of its own reads the chip's clock counter and its 100 MHz reference counter
+ * around a ~0.2 ms spin — callable from another host thread while a render is running (bench.py --sustain-seconds). */
+double MsneProbeClockGhz(int device);
 /* out[0] = acceleration-structure rebuilds so far, out[1] = in-place TLAS updates (instance transform edits that left the structure alone, Accel.zig:567-601) */
 void MsneGetAccelStats(HdMoonshine*, uint64_t out[2]);
 /* bytes of texture data the context keeps in HBM: every texture in the format it was created with (MaterialManager.zig:351-390), each rounded up to 16 B */

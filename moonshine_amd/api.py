@@ -112,6 +112,8 @@ SYMBOLS = [
     ("MsneCreateMesh", _i64, [_vp, _vp, _vp, _vp, C.c_size_t, C.c_size_t, _vp, C.c_size_t]),
     ("MsneCreateTexture", _i64, [_vp, _vp, Extent2D, C.c_int]),
     ("MsneCreateMaterial", _i64, [_vp, C.POINTER(MsneMaterialDesc)]),
+    ("MsneSetGeometryMaterial", C.c_int, [_vp, C.c_uint32, C.c_uint32, C.c_uint32]),
+    ("MsneProbeClockGhz", C.c_double, [C.c_int]),
     ("MsneSetPipeline", C.c_int, [_vp, C.POINTER(MsnePipelineOpts)]),
     ("MsneGetPipeline", C.c_int, [_vp, C.POINTER(MsnePipelineOpts)]),
     ("MsneSetBackground", C.c_int, [_vp, _vp, Extent2D]),
@@ -302,6 +304,11 @@ class Context:
 
     def set_instance_visibility(self, h, v):
         self.L.HdMoonshineSetInstanceVisibility(self.h, h, v)
+
+    def set_geometry_material(self, instance, geometry_index, material):
+        """Accel.recordUpdateSingleMaterial (Accel.zig:609-628): takes effect at the next render; the caller clears the sensor."""
+        if self.L.MsneSetGeometryMaterial(self.h, instance, geometry_index, material) != 0:
+            self._err("MsneSetGeometryMaterial")
 
     def set_pipeline(self, samples_per_run=1, max_bounces=4, env_samples_per_bounce=1, mesh_samples_per_bounce=1,
                      flip_image=True, indexed_attributes=True, two_component_normal_texture=True):

@@ -574,7 +574,7 @@ struct BuildScratch {
         HIPCHK(hipMalloc(&cra, N * 4)); HIPCHK(hipMalloc(&crb, N * 4)); HIPCHK(hipMalloc(&nn, N * 4)); HIPCHK(hipMalloc(&pflags, N * 4));
         HIPCHK(hipMalloc(&bsum, nb * 4)); HIPCHK(hipMalloc(&bbase, nb * sizeof(uint2))); HIPCHK(hipMalloc(&totals, 2 * sizeof(PlocState)));
         HIPCHK(hipMalloc(&seg, N * 4)); HIPCHK(hipMalloc(&csa, N * 4)); HIPCHK(hipMalloc(&csb, N * 4));
-        if (getenv("MSNE_DEBUG_POISON")) {   // tests: scratch starts as garbage, as recycled device memory does in a long-lived process — an entry read before it is written shows
+        if (debug_poison()) {   // tests: scratch starts as garbage, as recycled device memory does in a long-lived process — an entry read before it is written shows
             struct { void* p; size_t b; } all[] = { { boxes, N * sizeof(Box) }, { sorted, N * sizeof(Box) }, { ibox, N * sizeof(Box) }, { keys, N * 4 }, { keys2, N * 4 }, { idx, N * 4 }, { idx2, N * 4 },
                 { left, N * 4 }, { right, N * 4 }, { count, N * 4 }, { cost, N * 28 }, { split, N * 8 }, { wa, N * sizeof(CollapseWork) }, { wb, N * sizeof(CollapseWork) }, { cba, N * sizeof(Box) }, { cbb, N * sizeof(Box) },
                 { cra, N * 4 }, { crb, N * 4 }, { nn, N * 4 }, { pflags, N * 4 }, { seg, N * 4 }, { csa, N * 4 }, { csb, N * 4 } };
@@ -731,7 +731,7 @@ static bool sweep_on_gpu(BuildScratch& S, hipStream_t s, uint32_t n, uint32_t ns
         S.arena_bytes = off;
     }
     char* A = (char*)S.arena;
-    static const bool poison = getenv("MSNE_DEBUG_POISON") != nullptr;   // tests: the working set starts as garbage, as it does in a long-lived process
+    static const bool poison = debug_poison();   // tests: the working set starts as garbage, as it does in a long-lived process
     if (poison) HIPCHK(hipMemsetAsync(A, 0xCD, off, s));
     auto U32 = [&](size_t o) { return (uint32_t*)(A + o); };
     SwState St{};

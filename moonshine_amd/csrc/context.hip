@@ -64,7 +64,7 @@ template <typename T> struct DevBuf {
     bool alloc(size_t count) {
         release(); if (count == 0) count = 1;
         if (hipMalloc(&p, count * sizeof(T)) != hipSuccess) { p = nullptr; return false; }
-        static const bool poison = getenv("MSNE_DEBUG_POISON") != nullptr;   // tests: device memory starts as garbage (0xCD), as recycled memory does in a long-lived process
+        static const bool poison = debug_poison();   // tests: device memory starts as garbage (0xCD), as recycled memory does in a long-lived process
         if (poison && (hipMemset(p, 0xCD, count * sizeof(T)) != hipSuccess || hipDeviceSynchronize() != hipSuccess)) { (void)hipFree(p); p = nullptr; return false; }   // (the library's streams do not wait for the null stream)
         n = count; return true;
     }
@@ -118,6 +118,7 @@ struct HdMoonshine {
     std::vector<MaterialRec> materials; bool materials_dirty = true;
     std::map<uint32_t, MaterialUpdate> material_updates;   // deferred edits (hydra.zig:152-223)
     std::vector<InstanceH> instances; bool accel_dirty = true; bool tlas_only_dirty = false;
+    std::vector<std::pair<uint32_t, uint32_t>> geometry_edits;   // {instance, geometry} whose material changed since the tables were uploaded (Accel.zig:609-628)
     std::vector<Lens> lenses;
     std::vector<SensorH*> sensors;
 
@@ -609,7 +610,16 @@ bool HdMoonshine::ensure_scene() {
     // outward, so its boxes only ever grow: after 64 re-fits in a row it is rebuilt (the reference's UPDATE-mode builds degrade the same way, Accel.zig:567-601).
     if (!accel_dirty && !transform_edits.empty() &&
         (transform_edits.size() > std::max<size_t>(256, instances.size() / 4) || refits_since_rebuild >= 64 || !refit_tlas())) accel_dirty = true;
+    if (accel_dirty) geometry_edits.clear();   // (the rebuild writes the whole geometry table from the instances)
     if (accel_dirty && !rebuild_accel()) return false;
+    // Accel.recordUpdateSingleMaterial (Accel.zig:609-628): one 4-byte update of the geometry's record — the acceleration structure, the triangle records and the
+    // alias table (areas only) do not know materials; the gathered light triangles do (material index + emissive descriptor) and are gathered again
+    for (auto& e : geometry_edits) {
+        const GeometryRec& g = instances[e.first].geos[e.second];
+        CHECK_HIP(this, hipMemcpyAsync(reinterpret_cast<char*>(d_geometries.p + h_irec[e.first].geo_offset + e.second) + offsetof(GeometryRec, material), &g.material, 4, hipMemcpyHostToDevice, stream));
+        if (g.sampled) lights_dirty = true;
+    }
+    if (!geometry_edits.empty()) { CHECK_HIP(this, hipStreamSynchronize(stream)); geometry_edits.clear(); }
     if (lights_dirty || lights_indexed != opts.indexed_attributes) {
         const uint32_t count = h_alias.empty() ? 0u : h_alias[0].alias;
         if (count) {
@@ -1012,6 +1022,18 @@ void HdMoonshineSetInstanceTransform(HdMoonshine* c, InstanceHandle h, Mat3x4 t)
     c->clear_all_sensors();
 }
 
+// Accel.recordUpdateSingleMaterial (Accel.zig:609-628) as the online editor calls it (online/main.zig:229-233): geometry `geometry_index` of `instance`
+// (the reference's flat geometry index = the instance's custom index + geometry_index) gets another material from the next render on.  The sensors are NOT
+// cleared: the reference's caller does that (online/main.zig:231).
+int MsneSetGeometryMaterial(HdMoonshine* c, InstanceHandle h, uint32_t geometry_index, MaterialHandle m) {
+    LOCK(c);
+    if (h >= c->instances.size() || geometry_index >= c->instances[h].geos.size()) { c->fail("geometry material: unknown instance or geometry"); return -1; }
+    if (m >= c->materials.size()) { c->fail("geometry material: unknown material"); return -2; }   // (online/main.zig:229 checks the same bound)
+    c->instances[h].geos[geometry_index].material = m;
+    if (!c->accel_dirty) c->geometry_edits.emplace_back((uint32_t)h, geometry_index);
+    return 0;
+}
+
 int MsneSetPipeline(HdMoonshine* c, const MsnePipelineOpts* o) {
     LOCK(c);
     if (!o || o->samples_per_run == 0) { c->fail("pipeline: samples_per_run must be >= 1"); return -1; }
@@ -1140,6 +1162,27 @@ void MsneSetProfiling(HdMoonshine* c, int kernel_events, int traversal_counters)
     else if (c->serial_saved != -2) { c->serial_mode = c->serial_saved; c->serial_saved = -2; }
 }
 void MsneSetBuildQuality(HdMoonshine* c, int prefer_fast_trace) { LOCK(c); c->fast_builds = prefer_fast_trace == 0; }   // takes effect at the next (re)build
+// One wave spins for ~0.2 ms and reads both of the chip's counters around the spin: s_memtime counts shader-engine clocks, s_memrealtime the constant 100 MHz
+// reference.  Their ratio is the shader clock WHILE whatever else runs on the GPU runs (the probe has a stream of its own and takes one wave slot).
+__global__ void k_clock_probe(unsigned long long* out, uint32_t spins) {
+    const unsigned long long c0 = __builtin_readcyclecounter(), r0 = __builtin_amdgcn_s_memrealtime();
+    float x = (float)threadIdx.x;
+    for (uint32_t i = 0; i < spins; i++) { x = __builtin_fmaf(x, 1.0000001f, 1e-9f); asm volatile("" : "+v"(x)); }
+    const unsigned long long c1 = __builtin_readcyclecounter(), r1 = __builtin_amdgcn_s_memrealtime();
+    if (threadIdx.x == 0) { out[0] = c1 - c0; out[1] = r1 - r0; out[2] = (unsigned long long)x; }
+}
+double MsneProbeClockGhz(int device) {
+    struct Probe { hipStream_t s = nullptr; unsigned long long* d = nullptr; };
+    static std::mutex mu; static std::map<int, Probe> probes;
+    std::lock_guard<std::mutex> g(mu);
+    if (hipSetDevice(device) != hipSuccess) return -1.0;
+    Probe& p = probes[device];
+    if (!p.s && (hipStreamCreateWithFlags(&p.s, hipStreamNonBlocking) != hipSuccess || hipMalloc(&p.d, 32) != hipSuccess)) { p.s = nullptr; return -1.0; }
+    hipLaunchKernelGGL(k_clock_probe, dim3(1), dim3(64), 0, p.s, p.d, 60000u);
+    unsigned long long h[3] = { 0, 0, 0 };
+    if (hipMemcpyAsync(h, p.d, 24, hipMemcpyDeviceToHost, p.s) != hipSuccess || hipStreamSynchronize(p.s) != hipSuccess || h[1] == 0) return -1.0;
+    return (double)h[0] / (double)h[1] * 0.1;
+}
 void MsneGetAccelStats(HdMoonshine* c, uint64_t out[2]) { LOCK(c); out[0] = c->n_rebuilds; out[1] = c->n_tlas_updates; }   // acceleration-structure rebuilds, in-place TLAS updates
 uint64_t MsneGetTexelPoolBytes(HdMoonshine* c) {   // bytes of texels resident in HBM (after the next upload: what has been created so far)
     LOCK(c);

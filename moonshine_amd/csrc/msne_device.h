@@ -2,7 +2,13 @@
 #pragma once
 #include "msne_math.h"
 
+#include <cstdlib>
+
 namespace msne {
+
+// $MSNE_DEBUG_POISON (anything but "0"): every device allocation and the builder's scratch start as 0xCD garbage, as recycled device memory does in a long-lived
+// process — a value read before it is written shows.  The tests run that way (tests/conftest.py) and run a subset without it ("0"): fresh memory, no extra syncs.
+inline bool debug_poison() { const char* e = getenv("MSNE_DEBUG_POISON"); return e && !(e[0] == '0' && e[1] == 0); }
 
 // ---- acceleration structure ----
 // 8-wide quantized node, 80 B = 5 x 16 B.  Child boxes: lo = origin + qlo * 2^(e-127) per axis.

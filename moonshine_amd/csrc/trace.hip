@@ -248,6 +248,12 @@ __device__ __forceinline__ bool step_tri(Lane& L, const SceneView& sc, unsigned 
     if (STATS) nt++;
     float t, u, v;
     const bool hit = tri_intersect(L.o, L.rk, F3(u2f(a.x), u2f(a.y), u2f(a.z)), F3(u2f(a.w), u2f(b.x), u2f(b.y)), F3(u2f(b.z), u2f(b.w), u2f(c.x)), t, u, v);
+#if defined(TRACE_TRI_DUP)   // measurement only (profiles/r05_tri_density.txt): the triangle test issued twice — what one more pass of the body costs
+    { f3 o2 = L.o; asm volatile("" : "+v"(o2.x), "+v"(o2.y), "+v"(o2.z));
+      float t2, u2, v2;
+      const bool h2 = tri_intersect(o2, L.rk, F3(u2f(a.x), u2f(a.y), u2f(a.z)), F3(u2f(a.w), u2f(b.x), u2f(b.y)), F3(u2f(b.z), u2f(b.w), u2f(c.x)), t2, u2, v2);
+      if (h2 != hit) { t = t2; u = u2; v = v2; } }   // (never: the same inputs)
+#endif
     const uint32_t inst = (!INSTANCED || L.cur_inst == WORLD_INSTANCE) ? c.w : L.cur_inst;   // world BLAS (the only one of a scene without a TLAS level): the triangle record names its instance
     if (ANY_HIT) {
         const bool done = hit && t < L.best.t;

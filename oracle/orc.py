@@ -94,6 +94,7 @@ def lib():
         L.OrcCreateInstance.restype = i64; L.OrcCreateInstance.argtypes = [vp, Mat3x4, C.POINTER(Geometry), C.c_size_t, C.c_bool]
         L.OrcSetInstanceTransform.argtypes = [vp, u32, Mat3x4]
         L.OrcSetInstanceVisibility.argtypes = [vp, u32, C.c_bool]
+        L.OrcSetGeometryMaterial.restype = C.c_int; L.OrcSetGeometryMaterial.argtypes = [vp, u32, u32, u32]
         L.OrcSetPipeline.argtypes = [vp, C.POINTER(MsnePipelineOpts)]
         L.OrcSetBackground.argtypes = [vp, vp, Extent2D]
         L.OrcCreateSensor.restype = i64; L.OrcCreateSensor.argtypes = [vp, Extent2D]
@@ -205,6 +206,10 @@ class Context:
 
     def set_instance_visibility(self, h, v):
         self.L.OrcSetInstanceVisibility(self.h, h, v)
+
+    def set_geometry_material(self, instance, geometry_index, material):
+        if self.L.OrcSetGeometryMaterial(self.h, instance, geometry_index, material) != 0:
+            raise RuntimeError("OrcSetGeometryMaterial: unknown instance, geometry or material")
 
     def set_pipeline(self, samples_per_run=1, max_bounces=4, env_samples_per_bounce=1, mesh_samples_per_bounce=1,
                      flip_image=True, indexed_attributes=True, two_component_normal_texture=True):

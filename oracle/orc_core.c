@@ -417,6 +417,14 @@ int64_t OrcCreateInstance(OrcContext *c, Mat3x4 t, const Geometry *geos, size_t 
 }
 void OrcSetInstanceTransform(OrcContext *c, uint32_t h, Mat3x4 t) { memcpy(&c->instances[h].transform, &t, sizeof(m34)); c->accel_dirty = 1; clear_all_sensors(c); }
 void OrcSetInstanceVisibility(OrcContext *c, uint32_t h, bool v) { c->instances[h].visible = v; c->accel_dirty = 1; clear_all_sensors(c); }
+/* Accel.recordUpdateSingleMaterial (Accel.zig:609-628): one field of the flat geometry table (index = the instance's custom index + geometry_index, online/main.zig:225);
+ * the acceleration structure and the alias table do not depend on it; sensors are left alone (the caller clears: online/main.zig:231) */
+int OrcSetGeometryMaterial(OrcContext *c, uint32_t h, uint32_t geometry_index, uint32_t material) {
+    if (h >= c->instance_count || geometry_index >= c->instances[h].geo_count) return -1;
+    if (material >= c->material_count) return -2;
+    c->geometries[c->instances[h].geo_offset + geometry_index].material = material;
+    return 0;
+}
 int OrcSetPipeline(OrcContext *c, const MsnePipelineOpts *o) { c->opts = *o; clear_all_sensors(c); return 0; }
 int64_t OrcCreateSensor(OrcContext *c, Extent2D e) {
     c->sensors = (orc_sensor *)realloc(c->sensors, sizeof(orc_sensor) * (c->sensor_count + 1));

@@ -21,6 +21,42 @@ def test_library_exports_every_declared_symbol(gpu_api):
         assert hasattr(L, name), name
 
 
+# diagnostics (header part 3) a renderer front end never calls: the Zig binding leaves them out
+_ZIG_LEAVES_OUT = {"MsneSetProfiling", "MsneGetAccelStats", "MsneGetTexelPoolBytes", "MsneSetBuildQuality", "MsneGetTraversalCounters", "MsneGetTraversalLaneUse",
+                   "MsneGetBounceCounters", "MsneTraceRays", "MsneShadeProbe", "MsneGetEnvSize", "MsneReadEnv", "MsneGetAliasTable", "MsneReadBvh", "MsneProbeClockGhz"}
+
+
+def _split_args(a):
+    out, depth, cur = [], 0, ""
+    for ch in a:
+        if ch in "([{": depth += 1
+        if ch in ")]}": depth -= 1
+        if ch == "," and depth == 0:
+            out.append(cur); cur = ""
+        else:
+            cur += ch
+    if cur.strip() and cur.strip() != "void":
+        out.append(cur)
+    return out
+
+
+def test_zig_binding_declares_the_headers_entry_points():
+    """moonshine_amd/host/zig/amd.zig (the file INTEGRATION.md section 2 hands a maintainer of the reference; no Zig toolchain in this image, so it is NOT compiled here):
+    every entry point of parts 1 and 2 of the header is declared `pub extern fn` with the header's number of arguments, and nothing is declared that the header lacks"""
+    hdr = re.sub(r"/\*.*?\*/", "", open(os.path.join(ROOT, "include", "moonshine_amd.h")).read(), flags=re.S)
+    c_decl = {m.group(1): len(_split_args(m.group(2))) for m in re.finditer(r"\b((?:HdMoonshine|Msne)[A-Za-z0-9]+)\s*\(([^;{]*)\)\s*;", hdr) if not m.group(1).endswith("Fn")}
+    zig = re.sub(r"//[^\n]*", "", open(os.path.join(ROOT, "moonshine_amd", "host", "zig", "amd.zig")).read())
+    z_decl = {m.group(1): len(_split_args(m.group(2))) for m in re.finditer(r"pub extern fn (\w+)\(([^;]*)\)\s*[^;]*;", zig)}
+    assert set(z_decl) <= set(c_decl), set(z_decl) - set(c_decl)
+    assert set(c_decl) - set(z_decl) == _ZIG_LEAVES_OUT, (set(c_decl) - set(z_decl)) ^ _ZIG_LEAVES_OUT
+    for name, n in z_decl.items():
+        assert c_decl[name] == n, (name, c_decl[name], n)
+    for f in ("offline.zig", "furnace_test.zig"):   # what they call exists in the binding
+        src = open(os.path.join(ROOT, "moonshine_amd", "host", "zig", f)).read()
+        for name in set(re.findall(r"amd\.((?:HdMoonshine|Msne)\w+)\(", src)):
+            assert name in z_decl, (f, name)
+
+
 def test_struct_layouts_match_reference_header(gpu_api):
     a = gpu_api
     assert C.sizeof(a.F32x2) == 8 and C.sizeof(a.F32x3) == 12 and C.sizeof(a.F32x4) == 16

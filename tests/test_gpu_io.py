@@ -102,11 +102,8 @@ def test_glb_import_rules_against_a_second_source_on_the_gpu(tmp_path, gpu_api, 
 
 
 def _glb_fuzz_seeds():
-    spec = os.environ.get("MSNE_FUZZ_SEEDS")
-    if not spec:
-        return list(range(8))
-    a, _, b = spec.partition("-")
-    return list(range(int(a), int(b or a) + 1))
+    from seeds import seeds
+    return seeds(list(range(8)), rotating=192)
 
 
 @pytest.mark.parametrize("seed", _glb_fuzz_seeds())

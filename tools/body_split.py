@@ -71,7 +71,7 @@ def print_static(st):
 
 
 if __name__ == "__main__":
-    st = static_split()
+    st = static_split([x for x in sys.argv[1:] if x.startswith("-D")])
     print_static(st)
     if "--static" in sys.argv:
         sys.exit(0)
