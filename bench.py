@@ -86,20 +86,36 @@ def valu_calibration():
     return json.load(open(f)) if os.path.exists(f) else None
 
 
+def gpu_count_without_hip():
+    """GPUs this process may use, counted WITHOUT bringing up a HIP / HSA runtime in it (the parent of the ranks must not hold one): the visibility masks if set,
+    else the KFD topology (a node with SIMDs is a GPU)."""
+    for var in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        v = os.environ.get(var)
+        if v is not None:
+            return len([x for x in v.split(",") if x.strip() != ""])
+    n = 0
+    try:
+        top = "/sys/class/kfd/kfd/topology/nodes"
+        for node in os.listdir(top):
+            for line in open(os.path.join(top, node, "properties")):
+                if line.startswith("simd_count") and int(line.split()[1]) > 0:
+                    n += 1
+    except OSError:
+        pass
+    return n
+
+
 def launch_ranks(a):
     """`python bench.py --gpus N` without a launcher: start the N ranks as CHILD processes (torch.distributed.run, rendezvous on 127.0.0.1) and relay rank 0's
-    line.  Nothing in this process has touched the GPU yet (torch.cuda.device_count() does not initialise it) and this process is never replaced by another.
-    With fewer GPUs than ranks (a one-GPU box) the ranks share devices and gather through host memory (gloo) — labelled as such in the line."""
-    import socket
+    line.  This process never touches the GPU (the devices are counted from the visibility masks / the KFD topology, not through HIP) and is never replaced by
+    another.  With fewer GPUs than ranks (a one-GPU box) the ranks share devices and gather through host memory (gloo) — labelled as such in the line."""
     import subprocess
-    ndev = torch.cuda.device_count()
+    ndev = gpu_count_without_hip()
     env = dict(os.environ)
     if ndev < a.gpus and "MSNE_BENCH_BACKEND" not in env:
         env["MSNE_BENCH_BACKEND"] = "gloo"
-    with socket.socket() as s:
-        s.bind(("127.0.0.1", 0))
-        port = s.getsockname()[1]
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(a.gpus), "--master-addr", "127.0.0.1", "--master-port", str(port),
+    # --standalone: torch.distributed.run picks and HOLDS a free rendezvous port itself (no bind-then-close race on a busy node)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--standalone", "--local-addr", "127.0.0.1", "--nnodes=1", "--nproc-per-node", str(a.gpus),
            os.path.abspath(__file__)] + sys.argv[1:]
     p = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True)
     for line in p.stdout:
@@ -319,6 +335,7 @@ def main():
     rays = closest + shadow
     dt = statistics.median(times)
 
+    observed_backend = dist.get_backend() if world > 1 else "none"
     if rank == 0 and a.dump_film:
         if world == 1:
             ctx.render(sensor, lens, launches=0, readback=True)     # the gather already unpacked the film on rank 0 when world > 1
@@ -402,7 +419,9 @@ def main():
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": workload_name(a),
                        "sharding": "16x16 image tiles, tile t -> rank t mod %d, one gather of the packed film (one process per GPU)" % world},
-            "launcher": "ranks", "transport": "none" if world == 1 else ("rccl" if backend == "nccl" else backend), "ranks_seen": ranks_seen, "devices_seen": devices_seen,
+            "launcher": "ranks", "transport": "none" if world == 1 else ("rccl" if observed_backend == "nccl" else observed_backend), "ranks_seen": ranks_seen, "devices_seen": devices_seen,
+            # what torch.distributed says it ran the gather on (not the environment variable), and whether every rank had a GPU of its own
+            "transport_observed": None if world == 1 else {"backend": observed_backend, "one_gpu_per_rank": devices_seen == world},
             "repeats": R, "repeat_values": rates, "spread": (max(rates) - min(rates)) / statistics.median(rates),
             "msamples_per_s": samples / dt / 1e6,
             "rays": {"closest": closest, "shadow": shadow, "per_sample": rays / max(samples, 1.0)},

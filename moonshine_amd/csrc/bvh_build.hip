@@ -475,7 +475,7 @@ __global__ void k_collapse(const CollapseWork* work, uint32_t nwork, CollapseWor
     nodes[widx] = nd;
 }
 
-__global__ void k_emit_tris(const BlasGeo* geos, uint32_t ngeo, const uint32_t* item_src, uint32_t item_begin, uint32_t n, TriRec* tris, TriAttr* attrs) {
+__global__ void k_emit_tris(const BlasGeo* geos, uint32_t ngeo, const uint32_t* item_src, uint32_t item_begin, uint32_t n, TriRec* tris, TriRot* rots, TriAttr* attrs) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const uint32_t src = item_src[item_begin + i];
@@ -489,6 +489,14 @@ __global__ void k_emit_tris(const BlasGeo* geos, uint32_t ngeo, const uint32_t* 
     r.v2x = P[3 * (size_t)i2]; r.v2y = P[3 * (size_t)i2 + 1]; r.v2z = P[3 * (size_t)i2 + 2];
     r.geo = ge.geo; r.prim = p; r.pad = ge.inst;
     tris[item_begin + i] = r;
+    {   // the traversal's copy: every vertex as x y z x y (msne_device.h TriRot)
+        TriRot q;
+        q.v[0] = r.v0x; q.v[1] = r.v0y; q.v[2] = r.v0z; q.v[3] = r.v0x; q.v[4] = r.v0y;
+        q.v[5] = r.v1x; q.v[6] = r.v1y; q.v[7] = r.v1z; q.v[8] = r.v1x; q.v[9] = r.v1y;
+        q.v[10] = r.v2x; q.v[11] = r.v2y; q.v[12] = r.v2z; q.v[13] = r.v2x; q.v[14] = r.v2y;
+        q.inst = ge.inst;
+        rots[item_begin + i] = q;
+    }
     if (attrs && (ge.normals || ge.texcoords)) {   // world.hlsl:127-149: attribute indices and the texcoords a mesh without any gets
         const uint32_t a0 = ge.indexed ? i0 : 3 * p, a1 = ge.indexed ? i1 : 3 * p + 1, a2 = ge.indexed ? i2 : 3 * p + 2;
         TriAttr t;
@@ -548,15 +556,18 @@ struct BuildScratch {
     uint32_t *seg = nullptr, *csa = nullptr, *csb = nullptr;                   // batched builds: segment of every primitive / cluster (ping-pong)
     void* arena = nullptr; size_t arena_bytes = 0;                             // the top-down stages' working set (bvh_sweep.h), kept between builds
     bool fast_builds = false;                                                  // MsneSetBuildQuality(ctx, 0): PLOC to the roots, no sweep (an editing session's rebuilds)
+    void* refit = nullptr; size_t refit_bytes = 0;                             // bvh_refit_tlas's buffers (TLAS-sized, grown on demand, kept for the context's lifetime: an
+                                                                               // in-place update then allocates and frees nothing — hipFree synchronises the whole device)
+    void release_arena() { if (arena) (void)hipFree(arena); arena = nullptr; arena_bytes = 0; }
     void release() {
         if (arena) (void)hipFree(arena);
         arena = nullptr; arena_bytes = 0;
         void* p[] = { boxes, sorted, ibox, keys, keys2, idx, idx2, ghist, bounds, left, right, count, cost, split, wa, wb, next_count,
                       cba, cbb, cra, crb, nn, pflags, bsum, totals, bbase, seg, csa, csb };
         for (void* q : p) if (q) (void)hipFree(q);
-        const bool keep = fast_builds;
+        const bool keep = fast_builds; void* const rf = refit; const size_t rb = refit_bytes;
         *this = BuildScratch();
-        fast_builds = keep;
+        fast_builds = keep; refit = rf; refit_bytes = rb;
     }
     bool reserve(uint32_t n) {
         if (n <= cap) return true;
@@ -589,7 +600,9 @@ struct BuildScratch {
 // The scratch belongs to ONE context (allocated on its device, used on its stream under its mutex): contexts that rebuild
 // concurrently from different threads, or live on different GPUs, share nothing.
 BuildScratch* bvh_scratch_create() { return new (std::nothrow) BuildScratch(); }
-void bvh_scratch_destroy(BuildScratch* s) { if (s) { s->release(); delete s; } }
+void bvh_scratch_destroy(BuildScratch* s) { if (s) { s->release(); if (s->refit) (void)hipFree(s->refit); delete s; } }
+void bvh_scratch_release_arena(BuildScratch* s) { if (s) s->release_arena(); }
+size_t bvh_scratch_arena_bytes(const BuildScratch* s) { return s ? s->arena_bytes : 0; }
 void bvh_scratch_release(BuildScratch* s) { if (s) s->release(); }
 size_t bvh_scratch_capacity(const BuildScratch* s) { return s ? s->cap : 0; }
 void bvh_scratch_set_fast(BuildScratch* s, bool fast) { if (s) s->fast_builds = fast; }
@@ -975,7 +988,7 @@ static bool build_from_boxes(BuildScratch& S, hipStream_t s, uint32_t n, uint32_
 // over the whole batch, job j owns triangles [job_first[j], job_first[j + 1]).  A scene of thousands of small meshes costs one build, not thousands
 // (2 000 meshes of 320 triangles: 1.65 s one by one).
 bool bvh_build_blas_batch(BuildScratch* scratch, hipStream_t s, const std::vector<BlasGeo>& geos, const std::vector<uint32_t>& job_first, Node8* nodes, uint32_t* node_counter, uint32_t node_capacity,
-                          TriRec* tris, TriAttr* attrs, uint32_t* tri_counter, uint32_t* item_src, uint32_t* roots_out, float* root_boxes /* 6 per job */) {
+                          TriRec* tris, TriRot* rots, TriAttr* attrs, uint32_t* tri_counter, uint32_t* item_src, uint32_t* roots_out, float* root_boxes /* 6 per job */) {
     const uint32_t njobs = (uint32_t)job_first.size() - 1u, ntris = job_first.back();
     if (njobs == 0 || ntris == 0) return true;
     if (!scratch) return false;
@@ -990,7 +1003,7 @@ bool bvh_build_blas_batch(BuildScratch* scratch, hipStream_t s, const std::vecto
     HIPCHK(hipMemcpyAsync(&item_begin, tri_counter, 4, hipMemcpyDeviceToHost, s));
     std::vector<Box> rb(njobs);
     if (!build_from_boxes(g_scratch, s, ntris, njobs, job_first.data(), nodes, node_counter, node_capacity, tri_counter, item_src, roots_out, rb.data())) return false;
-    hipLaunchKernelGGL(k_emit_tris, dim3((ntris + 255) / 256), dim3(256), 0, s, dgeos, (uint32_t)geos.size(), item_src, item_begin, ntris, tris, attrs);
+    hipLaunchKernelGGL(k_emit_tris, dim3((ntris + 255) / 256), dim3(256), 0, s, dgeos, (uint32_t)geos.size(), item_src, item_begin, ntris, tris, rots, attrs);
     HIPCHK(hipStreamSynchronize(s));
     for (uint32_t j = 0; j < njobs; j++) for (int k = 0; k < 3; k++) { root_boxes[6 * j + k] = rb[j].lo[k]; root_boxes[6 * j + 3 + k] = rb[j].hi[k]; }
     return true;
@@ -1222,17 +1235,23 @@ void bvh_tlas_links(hipStream_t s, const Node8* nodes, uint32_t node_begin, uint
 }
 
 // insts / meshes describe the n_edits edited instances (their NEW transforms), edit_items their TLAS leaf items; n_nodes / n_items: the TLAS's nodes and leaf items
-bool bvh_refit_tlas(hipStream_t s, const TlasInst* insts, const TlasMesh* meshes, uint32_t nmeshes, const uint32_t* edit_items, uint32_t n_edits,
+bool bvh_refit_tlas(BuildScratch* scratch, hipStream_t s, const TlasInst* insts, const TlasMesh* meshes, uint32_t nmeshes, const uint32_t* edit_items, uint32_t n_edits,
                     Node8* nodes, uint32_t node_begin, uint32_t n_nodes, uint32_t item_begin, uint32_t n_items, const uint2* node_parent, const uint2* item_parent) {
     if (n_edits == 0) return true;
-    TlasInst* dinst = nullptr; TlasMesh* dmesh = nullptr; uint32_t* ditems = nullptr; Box* dboxes = nullptr; char* state = nullptr;
-    struct Free { TlasInst*& a; TlasMesh*& b; uint32_t*& c; Box*& d; char*& e; ~Free() { (void)hipFree(a); (void)hipFree(b); (void)hipFree(c); (void)hipFree(d); (void)hipFree(e); } } fr{ dinst, dmesh, ditems, dboxes, state };
-    HIPCHK(hipMalloc(&dinst, (size_t)n_edits * sizeof(TlasInst)));
-    HIPCHK(hipMalloc(&dboxes, (size_t)n_edits * sizeof(Box)));
-    HIPCHK(hipMalloc(&dmesh, (size_t)std::max(nmeshes, 1u) * sizeof(TlasMesh)));
-    HIPCHK(hipMalloc(&ditems, (size_t)n_edits * 4));
-    const size_t zeroed = ((size_t)3 * n_nodes + n_items) * 4, total = zeroed + ((size_t)n_nodes + n_items) * sizeof(Box);
-    HIPCHK(hipMalloc(&state, total));
+    // one buffer of the scratch, carved (256-B aligned pieces) and grown on demand
+    auto up = [](size_t b) { return (b + 255) & ~(size_t)255; };
+    const size_t zeroed = ((size_t)3 * n_nodes + n_items) * 4, state_bytes = zeroed + ((size_t)n_nodes + n_items) * sizeof(Box);
+    const size_t o_inst = 0, o_boxes = o_inst + up((size_t)n_edits * sizeof(TlasInst)), o_mesh = o_boxes + up((size_t)n_edits * sizeof(Box)),
+                 o_items = o_mesh + up((size_t)std::max(nmeshes, 1u) * sizeof(TlasMesh)), o_state = o_items + up((size_t)n_edits * 4), total = o_state + up(state_bytes);
+    if (total > scratch->refit_bytes) {
+        if (scratch->refit) (void)hipFree(scratch->refit);
+        scratch->refit = nullptr; scratch->refit_bytes = 0;
+        HIPCHK(hipMalloc(&scratch->refit, total + total / 2));
+        scratch->refit_bytes = total + total / 2;
+    }
+    char* const base = (char*)scratch->refit;
+    TlasInst* dinst = (TlasInst*)(base + o_inst); Box* dboxes = (Box*)(base + o_boxes); TlasMesh* dmesh = (TlasMesh*)(base + o_mesh); uint32_t* ditems = (uint32_t*)(base + o_items);
+    char* state = base + o_state;
     HIPCHK(hipMemsetAsync(state, 0, zeroed, s));
     RefitState R;
     R.dirty = (uint32_t*)state; R.pending = R.dirty + n_nodes; R.claimed = R.pending + n_nodes; R.item_edited = R.claimed + n_nodes;

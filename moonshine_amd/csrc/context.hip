@@ -42,13 +42,15 @@ void bvh_scratch_set_fast(BuildScratch*, bool);
 void bvh_scratch_destroy(BuildScratch*);
 void bvh_scratch_release(BuildScratch*);
 size_t bvh_scratch_capacity(const BuildScratch*);
-bool bvh_build_blas_batch(BuildScratch*, hipStream_t, const std::vector<BlasGeo>&, const std::vector<uint32_t>&, Node8*, uint32_t*, uint32_t, TriRec*, TriAttr*, uint32_t*, uint32_t*, uint32_t*, float*);
+bool bvh_build_blas_batch(BuildScratch*, hipStream_t, const std::vector<BlasGeo>&, const std::vector<uint32_t>&, Node8*, uint32_t*, uint32_t, TriRec*, TriRot*, TriAttr*, uint32_t*, uint32_t*, uint32_t*, float*);
 struct TlasInst { float T[12]; float blas_box[6]; uint32_t mesh_begin, mesh_end, exact, pad; };
 struct TlasMesh { const float* positions; uint32_t count, pad; };
 bool bvh_build_tlas(BuildScratch*, hipStream_t, const TlasInst*, const uint32_t*, uint32_t, const TlasMesh*, uint32_t, Node8*, uint32_t*, uint32_t, uint32_t*, uint32_t*, uint32_t*, uint32_t*);
 void bvh_tlas_links(hipStream_t, const Node8*, uint32_t node_begin, uint32_t node_end, uint32_t item_begin, uint2* node_parent, uint2* item_parent, uint32_t root);
 void bvh_tlas_leaves(hipStream_t, const uint32_t* items, const InstanceRec* instances, uint32_t n, TlasLeaf* out);
-bool bvh_refit_tlas(hipStream_t, const TlasInst*, const TlasMesh*, uint32_t, const uint32_t* edit_items, uint32_t n_edits, Node8*, uint32_t node_begin, uint32_t n_nodes, uint32_t item_begin, uint32_t n_items, const uint2*, const uint2*);
+void bvh_scratch_release_arena(BuildScratch*);
+size_t bvh_scratch_arena_bytes(const BuildScratch*);
+bool bvh_refit_tlas(BuildScratch*, hipStream_t, const TlasInst*, const TlasMesh*, uint32_t, const uint32_t* edit_items, uint32_t n_edits, Node8*, uint32_t node_begin, uint32_t n_nodes, uint32_t item_begin, uint32_t n_items, const uint2*, const uint2*);
 }  // namespace msne
 
 using namespace msne;
@@ -130,7 +132,7 @@ struct HdMoonshine {
     DevBuf<InstanceRec> d_instances;
     DevBuf<AliasEntry> d_alias;
     DevBuf<LightTri> d_light_tris; bool lights_dirty = true; uint32_t lights_indexed = 0;   // gathered light triangles (rebuilt with the alias table / attribute mode)
-    DevBuf<Node8> d_nodes; DevBuf<TriRec> d_tris; DevBuf<TriAttr> d_tri_attrs; DevBuf<uint32_t> d_tlas_items, d_item_src; DevBuf<TlasLeaf> d_tlas_leaves;
+    DevBuf<Node8> d_nodes; DevBuf<TriRec> d_tris; DevBuf<TriRot> d_tri_rot; DevBuf<TriAttr> d_tri_attrs; DevBuf<uint32_t> d_tlas_items, d_item_src; DevBuf<TlasLeaf> d_tlas_leaves;
     bool blas_indexed = true;                             // the attribute mode the TriAttr records of the cached BLASes were gathered with
     DevBuf<uint32_t> d_build_counters;    // [0] node count, [1] tri count, [2] tlas item count
     uint32_t blas_nodes_end = 0, blas_tris_end = 0;
@@ -411,10 +413,12 @@ bool HdMoonshine::rebuild_accel() {
     const size_t need_tris = (size_t)blas_tris_end + new_tris;
     const size_t need_nodes = (size_t)blas_nodes_end + new_tris + 2 * N + 64;
     if (need_tris > d_tris.n || !d_tris.p) {
-        DevBuf<TriRec> nt; if (!nt.alloc(need_tris + need_tris / 4 + 16)) { fail("out of device memory (triangles)"); return false; }
+        DevBuf<TriRec> nt; DevBuf<TriRot> nr;
+        if (!nt.alloc(need_tris + need_tris / 4 + 16) || !nr.alloc(need_tris + need_tris / 4 + 16)) { fail("out of device memory (triangles)"); return false; }
         if (blas_tris_end) CHECK_HIP(this, hipMemcpyAsync(nt.p, d_tris.p, (size_t)blas_tris_end * sizeof(TriRec), hipMemcpyDeviceToDevice, stream));
+        if (blas_tris_end) CHECK_HIP(this, hipMemcpyAsync(nr.p, d_tri_rot.p, (size_t)blas_tris_end * sizeof(TriRot), hipMemcpyDeviceToDevice, stream));
         CHECK_HIP(this, hipStreamSynchronize(stream));
-        std::swap(nt.p, d_tris.p); std::swap(nt.n, d_tris.n);
+        std::swap(nt.p, d_tris.p); std::swap(nt.n, d_tris.n); std::swap(nr.p, d_tri_rot.p); std::swap(nr.n, d_tri_rot.n);
     }
     // TriAttr records ride in the same slots as the TriRecs, allocated once any referenced mesh carries normals or texcoords
     bool any_attrs = false;
@@ -458,7 +462,7 @@ bool HdMoonshine::rebuild_accel() {
         const size_t njobs = job_key.size();
         if (njobs) {
             std::vector<uint32_t> roots(njobs); std::vector<float> boxes(6 * njobs);
-            if (!bvh_build_blas_batch(build_scratch, stream, bg, job_first, d_nodes.p, d_build_counters.p, (uint32_t)d_nodes.n, d_tris.p, d_tri_attrs.p, d_build_counters.p + 1, d_item_src.p,
+            if (!bvh_build_blas_batch(build_scratch, stream, bg, job_first, d_nodes.p, d_build_counters.p, (uint32_t)d_nodes.n, d_tris.p, d_tri_rot.p, d_tri_attrs.p, d_build_counters.p + 1, d_item_src.p,
                                       roots.data(), boxes.data())) { fail("BLAS build failed (details on stderr)"); return false; }
             for (size_t j = 0; j < njobs; j++) {
                 BlasInfo info{}; info.root = roots[j]; info.tris = job_first[j + 1] - job_first[j];
@@ -562,6 +566,7 @@ bool HdMoonshine::rebuild_accel() {
     // ~200 B of scratch per primitive: a scene-sized scratch is given back, a TLAS-sized one (interactive instance edits, up to a million instances) is kept
     lap("alias table");
     if (bvh_scratch_capacity(build_scratch) > (1u << 20)) bvh_scratch_release(build_scratch);
+    else if (bvh_scratch_arena_bytes(build_scratch) > (64u << 20)) bvh_scratch_release_arena(build_scratch);   // (the sweep's working set — ~120 B per position — of a BLAS build just under that size: S1 would keep 120 MB per context for its lifetime)
     lap("scratch release");
     if (timing) fprintf(stderr, "moonshine_amd rebuild (%zu instances):%s\n", N, t_report.c_str());
     accel_dirty = false; transform_edits.clear(); n_rebuilds++; refits_since_rebuild = 0;
@@ -594,7 +599,8 @@ bool HdMoonshine::refit_tlas() {
         coord_radius = std::max(coord_radius, coord_reach(instances[h].transform, bi->second.box));
     }
     if (transform_edits.size() > 64) CHECK_HIP(this, hipMemcpyAsync(d_instances.p, h_irec.data(), h_irec.size() * sizeof(InstanceRec), hipMemcpyHostToDevice, stream));   // many edits: the whole table in one copy
-    if (!bvh_refit_tlas(stream, tinst.data(), tmesh.data(), (uint32_t)tmesh.size(), items.data(), (uint32_t)items.size(), d_nodes.p, tlas_node_begin, tlas_node_end - tlas_node_begin, tlas_item_begin, n_tlas_items,
+    if (!build_scratch && !(build_scratch = bvh_scratch_create())) { fail("out of host memory"); return false; }
+    if (!bvh_refit_tlas(build_scratch, stream, tinst.data(), tmesh.data(), (uint32_t)tmesh.size(), items.data(), (uint32_t)items.size(), d_nodes.p, tlas_node_begin, tlas_node_end - tlas_node_begin, tlas_item_begin, n_tlas_items,
                         d_tlas_node_parent.p, d_tlas_item_parent.p)) return false;
     bvh_tlas_leaves(stream, d_tlas_items.p, d_instances.p, n_tlas_items, d_tlas_leaves.p);   // (the edited instances' matrices; all of them rewritten: microseconds)
     transform_edits.clear(); n_tlas_updates++; refits_since_rebuild++;
@@ -634,7 +640,7 @@ bool HdMoonshine::ensure_scene() {
 
 SceneView HdMoonshine::scene_view() const {
     SceneView v{};
-    v.nodes = d_nodes.p; v.tris = d_tris.p; v.tri_attrs = d_tri_attrs.p; v.tlas_items = d_tlas_items.p; v.tlas_leaves = d_tlas_leaves.p; v.instances = d_instances.p; v.geometries = d_geometries.p;
+    v.nodes = d_nodes.p; v.tris = d_tris.p; v.tri_rot = d_tri_rot.p; v.tri_attrs = d_tri_attrs.p; v.tlas_items = d_tlas_items.p; v.tlas_leaves = d_tlas_leaves.p; v.instances = d_instances.p; v.geometries = d_geometries.p;
     v.meshes = d_meshes.p; v.materials = d_materials.p; v.textures = d_texdesc.p; v.texels = d_texels.p; v.srgb_lut = d_srgb.p; v.alias = d_alias.p;
     if (!h_alias.empty()) { v.alias_count = h_alias[0].alias; v.alias_sum = h_alias[0].select; }
     v.light_tris = d_light_tris.p;

@@ -130,7 +130,10 @@ __device__ __forceinline__ f3 estimate_direct_mis(const Frame& frame, const LSam
 #define SHADE_WPS_CONST 4    // 128 registers, 8 spilled: S1 k_shade 26.7 -> 23.0 ms per 64-step batch (5904 -> 6197 Mrays/s), S2 39.0 -> 33.0 (3579 -> 3707); at 3 waves (141 registers) 26.1 / 38.2
 #endif
 constexpr uint32_t shade_spec_wps(int spec, bool tex) { return spec == 1 ? 4u : (tex ? (uint32_t)SHADE_WPS : (uint32_t)SHADE_WPS_CONST); }   // (the workgroup's 39 KB of LDS allow four waves per SIMD at most)
-template <int SPEC, bool TEX>
+// TRUNC (measurement only, profiles/r05_shade_td.txt): 1 = the kernel ends after the path-state loads and their LDS staging, 2 = after the hit / geometry / material chain and
+// the sort, 3 = after the hit's attributes, frames and material parameters are fetched, 4 = after the queue slots are reserved (one atomic per workgroup, on the counters'
+// padding), 5 = after the light samples, 6 = everything but the stores (nothing is ever written); launched in front of the real kernel under $MSNE_SHADE_TRUNC
+template <int SPEC, bool TEX, int TRUNC = 0>
 __global__ __launch_bounds__(SHADE_BLOCK, shade_spec_wps(SPEC, TEX)) void k_shade(SceneView sc, PipelineOpts opts, PathState cur, HitBuf hits, PathState nxt, ShadowQueue shq,
                                                          const float4* c_prev /* light-sample contributions of the previous bounce */,
                                                          float4* lbuf, BounceCounters* cnt /* [0]: this bounce, [1]: the next */, uint32_t first_pass /* the queue is k_raygen's */) {
@@ -155,6 +158,7 @@ __global__ __launch_bounds__(SHADE_BLOCK, shade_spec_wps(SPEC, TEX)) void k_shad
     // thread that shades the path after the sort picks it up there, instead of gathering 16-B pieces from a permuted index
     __shared__ float4 s_ro[SHADE_BLOCK], s_rd[SHADE_BLOCK], s_tp[SHADE_BLOCK], s_lr[SHADE_BLOCK];
     __shared__ uint2 s_sq[SHADE_BLOCK];
+    uint32_t acc = 0;   // TRUNC: what the truncated kernel folds its loads into
     for (uint32_t base_i = blockIdx.x * SHADE_BLOCK; base_i < n_pad; base_i += gridDim.x * SHADE_BLOCK) {
         uint32_t cat = CAT_NONE;
         {
@@ -166,7 +170,8 @@ __global__ __launch_bounds__(SHADE_BLOCK, shade_spec_wps(SPEC, TEX)) void k_shad
                 if (first_pass) { s_tp[threadIdx.x] = make_float4(1.0f, 1.0f, 1.0f, 0.0f); s_lr[threadIdx.x] = make_float4(0.0f, 0.0f, 0.0f, rd_own.w); s_sq[threadIdx.x] = make_uint2(i0, 0u); }
                 else { s_tp[threadIdx.x] = nt_load(&cur.tp[i0]); s_lr[threadIdx.x] = nt_load(&cur.lr[i0]); s_sq[threadIdx.x] = nt_load(&cur.sq[i0]); }
                 const uint32_t fl = f2u(ro_own.w);
-                if (!(fl & (PATH_FLAG_MASKED | PATH_FLAG_DEAD))) {
+                if (TRUNC == 1) acc ^= fl ^ f2u(rd_own.x);
+                if (TRUNC != 1 && !(fl & (PATH_FLAG_MASKED | PATH_FLAG_DEAD))) {
                     if (fl & PATH_FLAG_ZOMBIE) cat = 0u;
                     else {
                         const uint4 hr = nt_load(&hits.rec[i0]);
@@ -188,6 +193,7 @@ __global__ __launch_bounds__(SHADE_BLOCK, shade_spec_wps(SPEC, TEX)) void k_shad
                 if (SPEC == 3 && cat != 2u + MAT_LAMBERT) cat = CAT_NONE;
                 if (SPEC == 4 && cat != 2u + MAT_PBR) cat = CAT_NONE;
             }
+            if (TRUNC == 1) continue;
             uint32_t rank = 0;
 #pragma unroll
             for (uint32_t c = 0; c < NCAT; c++) {
@@ -207,6 +213,7 @@ __global__ __launch_bounds__(SHADE_BLOCK, shade_spec_wps(SPEC, TEX)) void k_shad
         }
         const bool live = threadIdx.x < s_cat[NCAT * (SHADE_BLOCK / 64)];
         const uint32_t src = live ? s_perm[threadIdx.x] : 0u;   // the thread that classified this path
+        if (TRUNC == 2) { acc ^= src; continue; }
         // ---- phase A: what the hit means for the path (pending light samples, miss epilogue, emission, termination) ----
         bool alive = false, nee = false, delta = false;
         f3 rayO = F3(0, 0, 0), rayD = F3(0, 0, 1), throughput = F3(0, 0, 0), L = F3(0, 0, 0), woSs = F3(0, 0, 1);
@@ -275,6 +282,8 @@ __global__ __launch_bounds__(SHADE_BLOCK, shade_spec_wps(SPEC, TEX)) void k_shad
                     material = material_load_desc<TEX>(sc, mrec, t_color, t_metal, t_rough, attrs.texcoord);
                 }
 
+                if (TRUNC == 3) acc ^= f2u(attrs.position.x) ^ f2u(attrs.texcoord.x) ^ f2u(attrs.frame.n.x) ^ f2u(attrs.triangleFrame.n.y) ^ f2u(textureFrame.n.z) ^ f2u(emissiveLight.x) ^ f2u(material.color.x) ^ f2u(material.alpha) ^ f2u(material.metalness);
+                if (TRUNC != 3) {
                 const f3 woWs = neg(rayD);
                 const bool frontfacing = dot(attrs.triangleFrame.n, woWs) > 0.0f;
                 if ((frontfacing && dot(woWs, textureFrame.n) > 0.0f) || (!frontfacing && -dot(woWs, textureFrame.n) > 0.0f)) shadingFrame = textureFrame;
@@ -299,9 +308,12 @@ __global__ __launch_bounds__(SHADE_BLOCK, shade_spec_wps(SPEC, TEX)) void k_shad
                     else throughput = divs(throughput, pSurvive);
                 }
                 if (!done) { alive = true; delta = SPEC == 2 ? true : (SPEC >= 3 ? false : material_is_delta(material)); nee = !delta && n_nee != 0u; }
+                }
             }
-            if (done) nt_store(&lbuf[slot], make_float4(L.x, L.y, L.z, 0.0f));
+            if (TRUNC != 0) acc ^= f2u(L.x) ^ f2u(L.y) ^ f2u(L.z);
+            else if (done) nt_store(&lbuf[slot], make_float4(L.x, L.y, L.z, 0.0f));
         }
+        if (TRUNC == 3) continue;
         // ---- phase B: queue slots.  One 64-bit atomic per WORKGROUP reserves both ranges (low word: one next-path entry per
         // surviving path, high word: n_nee shadow-ray entries per path that samples lights) — per-wave atomics on one counter
         // cap the kernel at ~88 waves/us (MI355X_MICROARCH.md "dequeue").  Reserving before the samples exist means they are
@@ -314,7 +326,8 @@ __global__ __launch_bounds__(SHADE_BLOCK, shade_spec_wps(SPEC, TEX)) void k_shad
             for (int k = 0; k < SHADE_BLOCK / 64; k++) tot += s_cnt[k];
             const uint32_t np = (uint32_t)(tot >> 32);   // paths of this workgroup that sample lights: sample k of all of them is stored together
             s_stride = np;                               // (keeps env rays with env rays and light rays with light rays in the shadow queue)
-            s_base = tot ? atomicAdd(reinterpret_cast<unsigned long long*>(&cnt[1].n_paths), (tot & 0xffffffffull) | ((unsigned long long)(np * n_nee) << 32)) : 0ull;
+            // (a truncated instantiation reserves from the counters' padding: the same atomic traffic, nothing the real kernel reads)
+            s_base = tot ? atomicAdd(reinterpret_cast<unsigned long long*>(TRUNC ? &cnt[1].pad[0] : &cnt[1].n_paths), (tot & 0xffffffffull) | ((unsigned long long)(np * n_nee) << 32)) : 0ull;
         }
         __syncthreads();
         unsigned long long base = s_base;
@@ -323,6 +336,10 @@ __global__ __launch_bounds__(SHADE_BLOCK, shade_spec_wps(SPEC, TEX)) void k_shad
         __syncthreads();   // s_cnt / s_base / s_stride are rewritten by the next iteration
         const uint32_t j = (uint32_t)base + (uint32_t)__popcll(ma & lt);
         const uint32_t q = (uint32_t)(base >> 32) + (uint32_t)__popcll(mn & lt);   // sample k of this path: entry q + k * stride
+        if (TRUNC == 4) { acc ^= j ^ q ^ stride; continue; }
+        // (TRUNC 5 / 6: the stores below become folds into acc)
+        auto st4 = [&](float4* p_, float4 v_) { if (TRUNC == 0) nt_store(p_, v_); else acc ^= f2u(v_.x) ^ f2u(v_.y) ^ f2u(v_.z) ^ f2u(v_.w) ^ (uint32_t)(uintptr_t)p_; };
+        auto st2 = [&](uint2* p_, uint2 v_) { if (TRUNC == 0) nt_store(p_, v_); else acc ^= v_.x ^ v_.y ^ (uint32_t)(uintptr_t)p_; };
         // ---- phase C: light samples (integrator.hlsl:137-151) and the next direction (:153-165) ----
         if (SPEC != 1 && alive) {
             uint32_t valid = 0;
@@ -335,10 +352,10 @@ __global__ __launch_bounds__(SHADE_BLOCK, shade_spec_wps(SPEC, TEX)) void k_shad
                         const f3 so = offset_along_normal(attrs.position, face_forward(attrs.triangleFrame.n, ls.dirWs));
                         const f3 e = estimate_direct_mis(shadingFrame, ls, material, woSs, env_n);
                         const f3 cc = divs(mul(throughput, e), (float)env_n);
-                        nt_store(&shq.o[e_], make_float4(so.x, so.y, so.z, INFINITY_F)); nt_store(&shq.d[e_], make_float4(ls.dirWs.x, ls.dirWs.y, ls.dirWs.z, 0.0f));
-                        nt_store(&shq.c[e_], make_float4(cc.x, cc.y, cc.z, 0.0f));
+                        st4(&shq.o[e_], make_float4(so.x, so.y, so.z, INFINITY_F)); st4(&shq.d[e_], make_float4(ls.dirWs.x, ls.dirWs.y, ls.dirWs.z, 0.0f));
+                        st4(&shq.c[e_], make_float4(cc.x, cc.y, cc.z, 0.0f));
                         valid++;
-                    } else { nt_store(&shq.o[e_], make_float4(0.0f, 0.0f, 0.0f, -1.0f)); nt_store(&shq.c[e_], make_float4(0.0f, 0.0f, 0.0f, 0.0f)); }
+                    } else { st4(&shq.o[e_], make_float4(0.0f, 0.0f, 0.0f, -1.0f)); st4(&shq.c[e_], make_float4(0.0f, 0.0f, 0.0f, 0.0f)); }
                 }
                 for (uint32_t k = 0; k < mesh_n; k++) {  // integrator.hlsl:147-150 + MeshLights::sample light.hlsl:130-158
                     f2 rand; rand.x = rng_float(rng); rand.y = rng_float(rng);
@@ -378,22 +395,23 @@ __global__ __launch_bounds__(SHADE_BLOCK, shade_spec_wps(SPEC, TEX)) void k_shad
                             const float st_ = length(sub(offL, offS)); const f3 sd = normalize(sub(offL, offS));
                             const f3 e = estimate_direct_mis(shadingFrame, ls, material, woSs, mesh_n);
                             const f3 cc = divs(mul(throughput, e), (float)mesh_n);
-                            nt_store(&shq.o[e_], make_float4(offS.x, offS.y, offS.z, st_)); nt_store(&shq.d[e_], make_float4(sd.x, sd.y, sd.z, 0.0f));
-                            nt_store(&shq.c[e_], make_float4(cc.x, cc.y, cc.z, 0.0f));
+                            st4(&shq.o[e_], make_float4(offS.x, offS.y, offS.z, st_)); st4(&shq.d[e_], make_float4(sd.x, sd.y, sd.z, 0.0f));
+                            st4(&shq.c[e_], make_float4(cc.x, cc.y, cc.z, 0.0f));
                             ok = true; valid++;
                         }
                     }
-                    if (!ok) { nt_store(&shq.o[e_], make_float4(0.0f, 0.0f, 0.0f, -1.0f)); nt_store(&shq.c[e_], make_float4(0.0f, 0.0f, 0.0f, 0.0f)); }
+                    if (!ok) { st4(&shq.o[e_], make_float4(0.0f, 0.0f, 0.0f, -1.0f)); st4(&shq.c[e_], make_float4(0.0f, 0.0f, 0.0f, 0.0f)); }
                 }
             }
+            if (TRUNC == 5) { acc ^= valid ^ rng; continue; }
             // next direction, integrator.hlsl:153-165
             f2 sq; sq.x = rng_float(rng); sq.y = rng_float(rng);
             const MSample sample = material_sample(material, woSs, sq);
             if (sample.pdf == 0.0f) {
                 // the path ends here; with light samples in flight it is finalised one pass later (after their shadow rays)
-                atomicAdd(&cnt[1].zombies, 1u);
-                if (valid) { nt_store(&nxt.ro[j], make_float4(0.0f, 0.0f, 0.0f, u2f(PATH_FLAG_ZOMBIE | PATH_FLAG_NEE | (stride << PATH_STRIDE_SHIFT)))); nt_store(&nxt.lr[j], make_float4(L.x, L.y, L.z, 0.0f)); nt_store(&nxt.sq[j], make_uint2(slot, q)); }
-                else { nt_store(&nxt.ro[j], make_float4(0.0f, 0.0f, 0.0f, u2f(PATH_FLAG_ZOMBIE | PATH_FLAG_DEAD))); nt_store(&lbuf[slot], make_float4(L.x, L.y, L.z, 0.0f)); }
+                if (TRUNC == 0) atomicAdd(&cnt[1].zombies, 1u);
+                if (valid) { st4(&nxt.ro[j], make_float4(0.0f, 0.0f, 0.0f, u2f(PATH_FLAG_ZOMBIE | PATH_FLAG_NEE | (stride << PATH_STRIDE_SHIFT)))); st4(&nxt.lr[j], make_float4(L.x, L.y, L.z, 0.0f)); st2(&nxt.sq[j], make_uint2(slot, q)); }
+                else { st4(&nxt.ro[j], make_float4(0.0f, 0.0f, 0.0f, u2f(PATH_FLAG_ZOMBIE | PATH_FLAG_DEAD))); st4(&lbuf[slot], make_float4(L.x, L.y, L.z, 0.0f)); }
             } else {
                 const f3 nd = frame_frame_to_world(shadingFrame, sample.dirFs);
                 const f3 no = offset_along_normal(attrs.position, face_forward(attrs.triangleFrame.n, nd));
@@ -401,11 +419,12 @@ __global__ __launch_bounds__(SHADE_BLOCK, shade_spec_wps(SPEC, TEX)) void k_shad
                 const float ac = absf(sample.dirFs.z);
                 const f3 tp = mul(throughput, F3(f.x * ac / sample.pdf, f.y * ac / sample.pdf, f.z * ac / sample.pdf));
                 const uint32_t nf = ((bounceCount + 1u) & 0xFFFFu) | (delta ? PATH_FLAG_DELTA : 0u) | (nee ? (PATH_FLAG_NEE | (stride << PATH_STRIDE_SHIFT)) : 0u);
-                nt_store(&nxt.ro[j], make_float4(no.x, no.y, no.z, u2f(nf))); nt_store(&nxt.rd[j], make_float4(nd.x, nd.y, nd.z, 0.0f));
-                nt_store(&nxt.tp[j], make_float4(tp.x, tp.y, tp.z, sample.pdf)); nt_store(&nxt.lr[j], make_float4(L.x, L.y, L.z, u2f(rng))); nt_store(&nxt.sq[j], make_uint2(slot, q));
+                st4(&nxt.ro[j], make_float4(no.x, no.y, no.z, u2f(nf))); st4(&nxt.rd[j], make_float4(nd.x, nd.y, nd.z, 0.0f));
+                st4(&nxt.tp[j], make_float4(tp.x, tp.y, tp.z, sample.pdf)); st4(&nxt.lr[j], make_float4(L.x, L.y, L.z, u2f(rng))); st2(&nxt.sq[j], make_uint2(slot, q));
             }
         }
     }
+    if (TRUNC != 0 && acc == 0x9e3779b9u && n == 0xffffffffu) lbuf[0] = make_float4(u2f(acc), 0.0f, 0.0f, 0.0f);   // (never: keeps the truncated kernel's loads alive)
 }
 
 // statistics of a finished batch: rays traced and camera paths started, from its per-bounce counters
@@ -538,6 +557,13 @@ void launch_raygen(hipStream_t s, int grid, const ShardView& sh, const CameraCon
 void launch_shade(hipStream_t s, int grid, const SceneView& sc, const PipelineOpts& o, const PathState& cur, const HitBuf& hits, const PathState& nxt, const ShadowQueue& q, const float4* c_prev, float4* lbuf, BounceCounters* cnt, bool first_pass, bool textured) {
     static const bool specialised = [] { const char* e = getenv("MSNE_SHADE_SPEC"); return e && atoi(e) != 0; }();
     const uint32_t fp = first_pass ? 1u : 0u;
+    static const bool trunc = [] { const char* e = getenv("MSNE_SHADE_TRUNC"); return e && atoi(e) != 0; }();
+    if (trunc && !first_pass) {   // measurement: the truncated kernels on the same queues, in front of the real one
+#define MSNE_TRUNC_LAUNCH(T) do { if (textured) hipLaunchKernelGGL((k_shade<0, true, T>), dim3(grid), dim3(SHADE_BLOCK), 0, s, sc, o, cur, hits, nxt, q, c_prev, lbuf, cnt, fp); \
+                                  else hipLaunchKernelGGL((k_shade<0, false, T>), dim3(grid), dim3(SHADE_BLOCK), 0, s, sc, o, cur, hits, nxt, q, c_prev, lbuf, cnt, fp); } while (0)
+        MSNE_TRUNC_LAUNCH(1); MSNE_TRUNC_LAUNCH(2); MSNE_TRUNC_LAUNCH(3); MSNE_TRUNC_LAUNCH(4); MSNE_TRUNC_LAUNCH(5); MSNE_TRUNC_LAUNCH(6);
+#undef MSNE_TRUNC_LAUNCH
+    }
     if (!specialised) {
         if (textured) hipLaunchKernelGGL((k_shade<0, true>), dim3(grid), dim3(SHADE_BLOCK), 0, s, sc, o, cur, hits, nxt, q, c_prev, lbuf, cnt, fp);
         else hipLaunchKernelGGL((k_shade<0, false>), dim3(grid), dim3(SHADE_BLOCK), 0, s, sc, o, cur, hits, nxt, q, c_prev, lbuf, cnt, fp);

@@ -35,6 +35,15 @@ struct alignas(16) TriRec {
 };
 static_assert(sizeof(TriRec) == 48, "TriRec must be 48 bytes");
 
+// The same three vertices once more, for the traversal kernels only (same slot of a parallel pool): every vertex as x y z x y, so that the three dwords at offset r
+// are the vertex's coordinates rotated by r — (v[r], v[r + 1], v[r + 2]) for r = the ray's dominant axis kz.  The watertight test permutes every vertex by the ray's
+// dominant axis; with this record the permutation is the ADDRESS of three 12-B loads instead of 18 v_cndmask + 6 v_cmp per test (a quarter of the test's issue
+// cycles).  `inst` repeats TriRec::pad.  64 B, never straddles a 128-B line.  (Measured against the alternative without a second pool — the 48-B record stored by axis,
+// {x0 x1 x2}{y0 y1 y2}{z0 z1 z2}, its three blocks loaded in rotated order: three 64-bit address computations per test instead of one cost more than the selects had
+// on S1 (-1.1 % against +1.2 % for this record); profiles/r05_tri_density.txt.)
+struct alignas(16) TriRot { float v[15]; uint32_t inst; };
+static_assert(sizeof(TriRot) == 64, "TriRot must be 64 bytes");
+
 // What MeshAttributes::lookupAndInterpolate (world.hlsl:114-158) reads beyond the positions, for the triangle in the SAME slot of the
 // triangle pool: the three normals and texcoords the pipeline's attribute mode selects (by vertex index for glTF, by corner for Hydra),
 // gathered once at build time.  A hit then needs one 64-B record instead of the chain geometry -> mesh -> indices -> 6 scattered attributes.
@@ -128,6 +137,7 @@ static_assert(sizeof(TlasLeaf) == 64, "TlasLeaf must be 64 bytes");
 struct SceneView {
     const Node8* nodes;
     const TriRec* tris;
+    const TriRot* tri_rot;            // parallel to tris (same slot): what the traversal kernels read
     const TriAttr* tri_attrs;         // parallel to tris (same slot); nullptr when no mesh of the scene has normals or texcoords
     const uint32_t* tlas_items;       // instance index per TLAS leaf item
     const TlasLeaf* tlas_leaves;      // parallel to tlas_items: what entering that instance takes

@@ -19,8 +19,10 @@
 //  * entering an instance (reload the world-space direction, transform, shear constants) is a "space body" that a wave runs when
 //    SPACE_MIN_LANES lanes wait for it or nothing else can be done; the lane puts the world-space half of its ray (origin, reciprocal
 //    direction, octant: 7 registers) aside and takes it back inline when its stack is back at the height of the entry (Lane::ret_sp: no sentinel
-//    entry, no second pop) — leaving costs no body and no wait.  The two-level instantiations run 5 waves per SIMD (96 registers) for that; scenes without a TLAS level run an
-//    instantiation without any of it at 6 waves per SIMD (80 registers).
+//    entry, no second pop) — leaving costs no body and no wait.  Both instantiations run 6 waves per SIMD (80 registers; the two-level one spills 13 of them and is still
+//    3 % faster than at 5 waves: TRACE_WPS_TLAS below); scenes without a TLAS level run an instantiation without any of the space bookkeeping;
+//  * a triangle is tested from a 64-B record that holds every vertex as x y z x y (msne_device.h TriRot): the watertight test's permutation of the vertices by the ray's dominant
+//    axis is the address of three 12-B loads, not 18 selects per test (profiles/r05_tri_density.txt).
 // Box tests use fmaf and a relative slack (they only gate which triangles are tested); the triangle test is
 // the watertight Woop–Benthin–Wald test evaluated op-for-op like the test oracle, and equal-t ties resolve
 // to the smallest (instance, geometry, primitive), so results do not depend on BVH shape or visit order.
@@ -33,7 +35,13 @@ constexpr int TRACE_BLOCK = 256;
 #define TRACE_WPS 6          // resident waves per SIMD the trace kernels are register-allocated for (= blocks of 256 per CU)
 #endif
 #ifndef TRACE_WPS_TLAS
-#define TRACE_WPS_TLAS 6     // two-level scenes: the world-space half of the ray a lane keeps while inside an instance costs 13 spilled registers at 80 — and 6 waves per SIMD are still 3 % faster than 5 at 96 registers without spills (S2 3597 / 3481 Mrays/s, profiles/r04_s2_variants.txt; round 3 measured the opposite before the leaf records took the InstanceRec hop out of the space body)
+#define TRACE_WPS_TLAS 6     // two-level scenes: the world-space half of the ray a lane keeps while inside an instance costs 13 spilled registers at 80 — and 6 waves per SIMD are still 3 % faster than 5 at 96 registers without spills (S2 3597 / 3481 Mrays/s, profiles/r04_s2_lane_use.txt "6 instead of 5 waves per SIMD"; round 3 measured the opposite before the leaf records took the InstanceRec hop out of the space body; 7 and 8 waves per SIMD — 72 / 64 registers, LDS stacks of 10 / 9 entries — lose 2-3 % / 12-20 %: profiles/r05_tri_density.txt).  With both at 6 the grid rescaling in the launch wrappers is the identity
+#endif
+#ifndef TRACE_TRI_MIN_LANES
+#define TRACE_TRI_MIN_LANES 1
+#endif
+#ifndef TRACE_KEEP_RO_TLAS
+#define TRACE_KEEP_RO_TLAS 0   // two-level scenes: the rotated origin of the triangle test lives in registers (1) or is rotated again at every test (0)
 #endif
 #ifndef TRACE_SPACE_MIN_LANES
 #define TRACE_SPACE_MIN_LANES 16   // lanes that must wait for a change of space (instance entry / exit) before the wave runs that body
@@ -46,37 +54,47 @@ constexpr int STACK_LDS = TRACE_STACK_LDS;   // group entries per lane kept in L
 constexpr int STACK_SPILL = 128 - STACK_LDS; // further entries per lane in HBM (2 words each)
 constexpr uint32_t GRP_NODE = 0u, GRP_INST = 1u << 16, GRP_KIND_MASK = 3u << 16;
 
-struct RayK { int kx, ky, kz; float Sx, Sy, Sz; };
+// The ray's half of the watertight test.  kz = the dominant axis of the direction.  Woop et al. (and the test oracle) take kx = kz + 1, ky = kz + 2 (mod 3) and swap the two
+// when d[kz] < 0.  Here the permutation is always the ROTATION by kz — the triangle records serve it by address (msne_device.h TriRot) — and the swap is applied where it
+// matters: with P / Q = the sheared coordinates along kz + 1 / kz + 2, the oracle's (x, y) are (P, Q) without the swap and (Q, P) with it, so its U = Cx*By - Cy*Bx is
+// p - q or q - p of the SAME two products (multiplication commutes exactly), likewise V and W: one select of the operand order per edge function reproduces the oracle's
+// bits, signed zeros included (p - q and q - p are exact negations of each other unless the result is zero, and zero results are what edge and vertex hits are made of).
+// S1 = d[kz + 1] / d[kz], S2 = d[kz + 2] / d[kz] (the oracle's Sx, Sy in one order or the other), Sz = 1 / d[kz]; ro = the origin rotated like the vertices.
+struct RayK { uint32_t kz; float S1, S2, Sz; f3 ro; };
 
-__device__ __forceinline__ float idx3(f3 v, int i) { return i == 0 ? v.x : (i == 1 ? v.y : v.z); }
+__device__ __forceinline__ float idx3(f3 v, uint32_t i) { return i == 0 ? v.x : (i == 1 ? v.y : v.z); }
+__device__ __forceinline__ f3 rot3(f3 v, uint32_t kz) {   // (v[kz], v[kz + 1], v[kz + 2])
+    return F3(kz == 0 ? v.x : (kz == 1 ? v.y : v.z), kz == 0 ? v.y : (kz == 1 ? v.z : v.x), kz == 0 ? v.z : (kz == 1 ? v.x : v.y));
+}
 
-__device__ __forceinline__ RayK rayk_make(f3 d) {
+__device__ __forceinline__ RayK rayk_make(f3 o, f3 d) {
     RayK k;
     k.kz = 0;
     if (absf(d.y) > absf(d.x)) k.kz = 1;
     if (absf(d.z) > absf(idx3(d, k.kz))) k.kz = 2;
-    k.kx = k.kz + 1; if (k.kx == 3) k.kx = 0;
-    k.ky = k.kx + 1; if (k.ky == 3) k.ky = 0;
-    if (idx3(d, k.kz) < 0.0f) { int t = k.kx; k.kx = k.ky; k.ky = t; }
-    float dz = idx3(d, k.kz);
-    k.Sx = idx3(d, k.kx) / dz; k.Sy = idx3(d, k.ky) / dz; k.Sz = 1.0f / dz;
+    const f3 dr = rot3(d, k.kz);   // (d[kz], d[kz + 1], d[kz + 2])
+    k.S1 = dr.y / dr.x; k.S2 = dr.z / dr.x; k.Sz = 1.0f / dr.x;
+    k.ro = rot3(o, k.kz);
     return k;
 }
 
-// watertight ray/triangle test (Woop, Benthin, Wald 2013), no culling; (u,v) = weights of vertices 1,2.
+// watertight ray/triangle test (Woop, Benthin, Wald 2013), no culling; (u,v) = weights of vertices 1,2.  The vertices arrive rotated like the ray: (v[kz], v[kz + 1], v[kz + 2]).
 // Written without early-outs (one predicate at the end) so a wave does not fragment into exec-mask branches;
-// the arithmetic is exactly the test oracle's.
-__device__ __forceinline__ bool tri_intersect(f3 o, const RayK& k, f3 v0, f3 v1, f3 v2, float& t, float& u, float& v) {
-    const f3 A = sub(v0, o), B = sub(v1, o), C = sub(v2, o);
-    const float Akz = idx3(A, k.kz), Bkz = idx3(B, k.kz), Ckz = idx3(C, k.kz);
-    const float Ax = idx3(A, k.kx) - k.Sx * Akz, Ay = idx3(A, k.ky) - k.Sy * Akz;
-    const float Bx = idx3(B, k.kx) - k.Sx * Bkz, By = idx3(B, k.ky) - k.Sy * Bkz;
-    const float Cx = idx3(C, k.kx) - k.Sx * Ckz, Cy = idx3(C, k.ky) - k.Sy * Ckz;
-    float U = Cx * By - Cy * Bx, V = Ax * Cy - Ay * Cx, W = Bx * Ay - By * Ax;
+// the arithmetic is the test oracle's, operation for operation (see RayK for the swap).
+__device__ __forceinline__ bool tri_intersect(const RayK& k, f3 r0, f3 r1, f3 r2, float& t, float& u, float& v) {
+    const float Akz = r0.x - k.ro.x, Ak1 = r0.y - k.ro.y, Ak2 = r0.z - k.ro.z;
+    const float Bkz = r1.x - k.ro.x, Bk1 = r1.y - k.ro.y, Bk2 = r1.z - k.ro.z;
+    const float Ckz = r2.x - k.ro.x, Ck1 = r2.y - k.ro.y, Ck2 = r2.z - k.ro.z;
+    const float AP = Ak1 - k.S1 * Akz, AQ = Ak2 - k.S2 * Akz;
+    const float BP = Bk1 - k.S1 * Bkz, BQ = Bk2 - k.S2 * Bkz;
+    const float CP = Ck1 - k.S1 * Ckz, CQ = Ck2 - k.S2 * Ckz;
+    const bool swp = k.Sz < 0.0f;   // d[kz] < 0: the oracle's (x, y) = (Q, P)
+    const float pu = CP * BQ, qu = CQ * BP, pv = AP * CQ, qv = AQ * CP, pw = BP * AQ, qw = BQ * AP;
+    float U = swp ? qu - pu : pu - qu, V = swp ? qv - pv : pv - qv, W = swp ? qw - pw : pw - qw;
     if (__builtin_expect(U == 0.0f || V == 0.0f || W == 0.0f, 0)) {
-        double CxBy = (double)Cx * (double)By, CyBx = (double)Cy * (double)Bx; U = (float)(CxBy - CyBx);
-        double AxCy = (double)Ax * (double)Cy, AyCx = (double)Ay * (double)Cx; V = (float)(AxCy - AyCx);
-        double BxAy = (double)Bx * (double)Ay, ByAx = (double)By * (double)Ax; W = (float)(BxAy - ByAx);
+        const double dpu = (double)CP * (double)BQ, dqu = (double)CQ * (double)BP; U = (float)(swp ? dqu - dpu : dpu - dqu);
+        const double dpv = (double)AP * (double)CQ, dqv = (double)AQ * (double)CP; V = (float)(swp ? dqv - dpv : dpv - dqv);
+        const double dpw = (double)BP * (double)AQ, dqw = (double)BQ * (double)AP; W = (float)(swp ? dqw - dpw : dpw - dqw);
     }
     const bool mixed = (U < 0.0f || V < 0.0f || W < 0.0f) && (U > 0.0f || V > 0.0f || W > 0.0f);
     const float det = U + V + W;
@@ -150,7 +168,7 @@ __device__ __forceinline__ void lane_set_space(Lane& L, f3 o, f3 d, float coord_
     L.o = o;
     L.id = F3(safe_inv(d.x), safe_inv(d.y), safe_inv(d.z));
     L.slk = cull_slack(L, coord_slack);
-    L.rk = rayk_make(d);
+    L.rk = rayk_make(o, d);
     L.octbase = ((L.id.x < 0.0f ? 1u : 0u) | (L.id.y < 0.0f ? 2u : 0u) | (L.id.z < 0.0f ? 4u : 0u)) << 8;
 }
 
@@ -196,6 +214,9 @@ __device__ __forceinline__ void step_node(Lane& L, const SceneView& sc, const St
     const float bx = (nox - L.o.x) * L.id.x, by = (noy - L.o.y) * L.id.y, bz = (noz - L.o.z) * L.id.z;
     // byte planes: qlo[0] = w2.xy, qlo[1] = w2.zw, qlo[2] = w3.xy, qhi[0] = w3.zw, qhi[1] = w4.xy, qhi[2] = w4.zw.
     // a = scale * id has the sign of id, so the entry plane of an axis is qlo when id >= 0 and qhi otherwise
+    // (the choice made by ADDRESS instead — a 128-B node on a 128-B boundary with every axis' planes as {lo, hi, lo}, three 16-B loads at offset 0 or 8 by the ray's
+    // direction signs: 7 VALU fewer per visit and one cache line per node instead of 1.5 — was built and measured: S1 -9 %, S2 -4 %, the node pool's footprint
+    // (+60 %) costs far more than the selects: profiles/r05_tri_density.txt)
     const bool sx = L.id.x < 0.0f, sy = L.id.y < 0.0f, sz = L.id.z < 0.0f;
     const uint32_t nx[2] = { sx ? w3.z : w2.x, sx ? w3.w : w2.y }, fx[2] = { sx ? w2.x : w3.z, sx ? w2.y : w3.w };
     const uint32_t ny[2] = { sy ? w4.x : w2.z, sy ? w4.y : w2.w }, fy[2] = { sy ? w2.z : w4.x, sy ? w2.w : w4.y };
@@ -243,18 +264,25 @@ __device__ __forceinline__ bool step_tri(Lane& L, const SceneView& sc, unsigned 
     const uint32_t idx = L.ta0 + __popc((L.ta1 >> 8) & (low - 1u));
     L.ta1 &= ~low;
     if (!(L.ta1 & 0xffu)) { L.ta0 = L.tb0; L.ta1 = L.tb1; L.tb1 = 0u; }
-    const uint4* tp = reinterpret_cast<const uint4*>(sc.tris + idx);
-    const uint4 a = tp[0], b = tp[1], c = tp[2];
+    // three 12-B loads whose ADDRESS carries the rotation by the ray's dominant axis (msne_device.h TriRot), and the instance of a world-BLAS triangle from the same 64-B record
+    const float* tp = reinterpret_cast<const float*>(sc.tri_rot + idx) + L.rk.kz;
+    typedef float f3v __attribute__((ext_vector_type(3)));
+    f3v a, b, c;
+    __builtin_memcpy(&a, tp, 12); __builtin_memcpy(&b, tp + 5, 12); __builtin_memcpy(&c, tp + 10, 12);
+    uint32_t winst = WORLD_INSTANCE;   // (an any-hit ray of a scene without a TLAS level only needs "hit")
+    if (INSTANCED ? L.cur_inst == WORLD_INSTANCE : !ANY_HIT) winst = sc.tri_rot[idx].inst;   // (inside an instance of its own the lane knows the instance: no load)
     if (STATS) nt++;
     float t, u, v;
-    const bool hit = tri_intersect(L.o, L.rk, F3(u2f(a.x), u2f(a.y), u2f(a.z)), F3(u2f(a.w), u2f(b.x), u2f(b.y)), F3(u2f(b.z), u2f(b.w), u2f(c.x)), t, u, v);
+    RayK rk = L.rk;
+    if (INSTANCED && !TRACE_KEEP_RO_TLAS) rk.ro = rot3(L.o, L.rk.kz);   // (two-level scenes: three registers fewer across the loop for six selects per test)
+    const bool hit = tri_intersect(rk, F3(a.x, a.y, a.z), F3(b.x, b.y, b.z), F3(c.x, c.y, c.z), t, u, v);
 #if defined(TRACE_TRI_DUP)   // measurement only (profiles/r05_tri_density.txt): the triangle test issued twice — what one more pass of the body costs
-    { f3 o2 = L.o; asm volatile("" : "+v"(o2.x), "+v"(o2.y), "+v"(o2.z));
+    { RayK k2 = rk; asm volatile("" : "+v"(k2.ro.x), "+v"(k2.ro.y), "+v"(k2.ro.z));
       float t2, u2, v2;
-      const bool h2 = tri_intersect(o2, L.rk, F3(u2f(a.x), u2f(a.y), u2f(a.z)), F3(u2f(a.w), u2f(b.x), u2f(b.y)), F3(u2f(b.z), u2f(b.w), u2f(c.x)), t2, u2, v2);
+      const bool h2 = tri_intersect(k2, F3(a.x, a.y, a.z), F3(b.x, b.y, b.z), F3(c.x, c.y, c.z), t2, u2, v2);
       if (h2 != hit) { t = t2; u = u2; v = v2; } }   // (never: the same inputs)
 #endif
-    const uint32_t inst = (!INSTANCED || L.cur_inst == WORLD_INSTANCE) ? c.w : L.cur_inst;   // world BLAS (the only one of a scene without a TLAS level): the triangle record names its instance
+    const uint32_t inst = (!INSTANCED || L.cur_inst == WORLD_INSTANCE) ? winst : L.cur_inst;   // world BLAS (the only one of a scene without a TLAS level): the triangle record names its instance
     if (ANY_HIT) {
         const bool done = hit && t < L.best.t;
         L.best.inst = done ? inst : L.best.inst;
@@ -262,9 +290,9 @@ __device__ __forceinline__ bool step_tri(Lane& L, const SceneView& sc, unsigned 
     }
     bool closer = hit && t < L.best.t;
     if (__builtin_expect(hit && t == L.best.t && L.best.inst != MAX_UINT, 0)) {   // exact tie: smallest (instance, geometry, primitive) wins
-        const TriRec* bt = sc.tris + L.best.tri;
-        const uint32_t bgeo = bt->geo, bprim = bt->prim;
-        closer = inst < L.best.inst || (inst == L.best.inst && (c.y < bgeo || (c.y == bgeo && c.z < bprim)));
+        const TriRec* bt = sc.tris + L.best.tri; const TriRec* ct = sc.tris + idx;
+        const uint32_t bgeo = bt->geo, bprim = bt->prim, cgeo = ct->geo, cprim = ct->prim;
+        closer = inst < L.best.inst || (inst == L.best.inst && (cgeo < bgeo || (cgeo == bgeo && cprim < bprim)));
     }
     L.best.t = closer ? t : L.best.t; L.best.u = closer ? u : L.best.u; L.best.v = closer ? v : L.best.v;
     L.best.inst = closer ? inst : L.best.inst; L.best.tri = closer ? idx : L.best.tri;
@@ -432,8 +460,8 @@ __device__ __forceinline__ void trace_wave_loop(const SceneView& sc, uint32_t n,
                 const uint32_t dl = nth_set_bit(donors, rth < npair ? rth : 0u);   // the donor this lane would take from
                 const float ox = __shfl(L.o.x, dl), oy = __shfl(L.o.y, dl), oz = __shfl(L.o.z, dl);
                 const float ix = __shfl(L.id.x, dl), iy = __shfl(L.id.y, dl), iz = __shfl(L.id.z, dl);
-                const int kx = __shfl(L.rk.kx, dl), ky = __shfl(L.rk.ky, dl), kz = __shfl(L.rk.kz, dl);
-                const float sx = __shfl(L.rk.Sx, dl), sy = __shfl(L.rk.Sy, dl), sz = __shfl(L.rk.Sz, dl);
+                const uint32_t kz = (uint32_t)__shfl((int)L.rk.kz, dl);
+                const float sx = __shfl(L.rk.S1, dl), sy = __shfl(L.rk.S2, dl), sz = __shfl(L.rk.Sz, dl);
                 // the donor's best hit so far goes along whole: a piece that meets the same distance again (coincident triangles) must break the tie against it
                 const float bt = __shfl(L.best.t, dl), bu = __shfl(L.best.u, dl), bv = __shfl(L.best.v, dl);
                 const uint32_t binst = (uint32_t)__shfl((int)L.best.inst, dl), btri = (uint32_t)__shfl((int)L.best.tri, dl);
@@ -449,7 +477,7 @@ __device__ __forceinline__ void trace_wave_loop(const SceneView& sc, uint32_t n,
                         L.g0 = dsp[(size_t)(2 * (dsb - STACK_LDS)) * S.spill_stride]; L.g1 = dsp[(size_t)(2 * (dsb - STACK_LDS) + 1) * S.spill_stride];
                     }
                     L.o = F3(ox, oy, oz); L.id = F3(ix, iy, iz); L.slk = cull_slack(L, sc.coord_slack);
-                    L.rk.kx = kx; L.rk.ky = ky; L.rk.kz = kz; L.rk.Sx = sx; L.rk.Sy = sy; L.rk.Sz = sz;
+                    L.rk.kz = kz; L.rk.S1 = sx; L.rk.S2 = sy; L.rk.Sz = sz; L.rk.ro = rot3(L.o, kz);
                     L.best.inst = binst; L.best.tri = btri; L.best.t = bt; L.best.u = ANY_HIT ? bt + L.slk : bu; L.best.v = bv;
                     L.octbase = ob; L.cur_inst = ci; L.ret_sp = -1; my = dmy;
                     L.sp = 0; L.sb = 0; L.ta1 = 0; L.tb1 = 0; L.own = downer;
@@ -475,7 +503,10 @@ __device__ __forceinline__ void trace_wave_loop(const SceneView& sc, uint32_t n,
         const bool has_g = active && (L.g1 & 0xffu);
         const bool want_n = has_g && (!INSTANCED || (L.g1 & GRP_KIND_MASK) == GRP_NODE) && !(L.tb1 & 0xffu);
         const bool want_s = INSTANCED && has_g && (L.g1 & GRP_KIND_MASK) == GRP_INST;   // enters an instance: the ray changes space
-        const bool do_n = __ballot(want_n) != 0ull, do_t = __ballot(want_t) != 0ull;
+        const unsigned long long mt = __ballot(want_t);
+        const bool do_n = __ballot(want_n) != 0ull;
+        // (TRACE_TRI_MIN_LANES > 1, measurement only: the triangle body waits until that many lanes want it or no lane can visit a node — profiles/r05_tri_density.txt)
+        const bool do_t = TRACE_TRI_MIN_LANES <= 1 ? mt != 0ull : (mt != 0ull && ((uint32_t)__popcll(mt) >= (uint32_t)TRACE_TRI_MIN_LANES || !do_n));
         // Changing space costs ~250 instructions (reload the world-space ray, transform, three IEEE divisions for the shear constants)
         // and few lanes need it in any one iteration: entering and leaving share one body, and it runs when enough lanes wait for
         // it or nothing else can be done.

@@ -103,7 +103,7 @@ def test_glb_import_rules_against_a_second_source_on_the_gpu(tmp_path, gpu_api, 
 
 def _glb_fuzz_seeds():
     from seeds import seeds
-    return seeds(list(range(8)), rotating=192)
+    return seeds(list(range(8)), rotating=400)
 
 
 @pytest.mark.parametrize("seed", _glb_fuzz_seeds())

@@ -1308,12 +1308,12 @@ _FAILED_ONCE = [1688, 2297, 7724, 18344, 19491]   # the five of 0 .. 20 000 that
 
 
 def _fuzz_seeds():
-    """sixteen fixed seeds, the five that once failed, and 180 rotating ones"""
-    return _seed_range(list(range(16)) + _FAILED_ONCE, rotating=180)
+    """sixteen fixed seeds, the five that once failed, and 400 rotating ones"""
+    return _seed_range(list(range(16)) + _FAILED_ONCE, rotating=400)
 
 
 def _fuzz_seeds_edits():
-    return _seed_range(list(range(16)) + _FAILED_ONCE, rotating=180)
+    return _seed_range(list(range(16)) + _FAILED_ONCE, rotating=400)
 
 
 @pytest.mark.parametrize("seed", _fuzz_seeds())
@@ -1337,7 +1337,7 @@ def test_random_scenes_match_oracle(orc, gpu_api, seed):
 
 
 def _fuzz_seeds_big():
-    return _seed_range(list(range(4)), rotating=36)
+    return _seed_range(list(range(4)), rotating=60)
 
 
 @pytest.mark.parametrize("seed", _fuzz_seeds_big())
@@ -1359,7 +1359,7 @@ def test_random_big_scenes_match_oracle(orc, gpu_api, seed):
 
 
 def _fuzz_seeds_hydra():
-    return _seed_range(list(range(8)), rotating=52)
+    return _seed_range(list(range(8)), rotating=100)
 
 
 @pytest.mark.parametrize("seed", _fuzz_seeds_hydra())
@@ -1713,7 +1713,7 @@ def test_group_render_equals_single_context(gpu_api, members):
 
 
 def _fuzz_seeds_group():
-    return _seed_range(list(range(12)), rotating=28)
+    return _seed_range(list(range(12)), rotating=60)
 
 
 @pytest.mark.parametrize("seed", _fuzz_seeds_group())
