@@ -683,8 +683,8 @@ bool HdMoonshine::ensure_wavefront(size_t npaths, size_t slots, int npipes) {
     for (int k = 0; k < npipes; k++) {
         Pipe& pp = pipes[k];
         if (!pp.s0 && (hipStreamCreateWithFlags(&pp.s0, hipStreamNonBlocking) != hipSuccess || hipStreamCreateWithFlags(&pp.s1, hipStreamNonBlocking) != hipSuccess)) { fail("cannot create HIP streams"); return false; }
-        if (npaths > pp.cap) {
-            const size_t c = (npaths + 255) & ~(size_t)255;
+        if (((npaths + 255) & ~(size_t)255) + (size_t)QUEUE_SUBS * 256 > pp.cap) {
+            const size_t c = ((npaths + 255) & ~(size_t)255) + (size_t)QUEUE_SUBS * 256;   // (a queue's extent rounds up to a whole round of sub-queue tiles: msne_device.h)
             pp.cap = 0;
             if (!pp.paths[0].ensure(c) || !pp.paths[1].ensure(c) || !pp.hit_u.alloc(4 * c)) { fail("out of device memory (wavefront state)"); return false; }
             pp.cap = c; pp.shq_samples = 0;
@@ -820,9 +820,11 @@ bool HdMoonshine::render(uint32_t sensor, uint32_t lens, uint32_t launches, bool
             if (!shadow_done) { fail("hipEventCreate failed"); return false; }
             CHECK_HIP(this, hipEventRecord(shadow_done, sh_stream));
             if (b >= 15 && (b & 3) == 3) {   // long tails (max_bounces = 1024 offline): poll the queue length every 4 bounces
-                uint32_t n_next = 0;
-                CHECK_HIP(this, hipMemcpyAsync(&n_next, &cnt[b + 1].n_paths, 4, hipMemcpyDeviceToHost, pp.s0));
+                BounceCounters next;
+                CHECK_HIP(this, hipMemcpyAsync(&next, &cnt[b + 1], sizeof next, hipMemcpyDeviceToHost, pp.s0));
                 CHECK_HIP(this, hipStreamSynchronize(pp.s0));
+                uint32_t n_next = 0;
+                for (uint32_t k = 0; k < QUEUE_SUBS; k++) n_next += next.sub[k].n_paths;
                 if (n_next == 0) break;
             }
         }
@@ -1236,7 +1238,11 @@ int MsneGetBounceCounters(HdMoonshine* c, uint32_t* out, uint32_t max_bounces) {
     const uint32_t n = (uint32_t)std::min<size_t>(max_bounces, c->pipes[0].counters.n);
     std::vector<BounceCounters> h(n);
     if (hipMemcpy(h.data(), c->pipes[0].counters.p, n * sizeof(BounceCounters), hipMemcpyDeviceToHost) != hipSuccess) return -1;
-    for (uint32_t b = 0; b < n; b++) { out[4 * b] = h[b].n_paths; out[4 * b + 1] = h[b].zombies; out[4 * b + 2] = h[b].n_shadow_in; out[4 * b + 3] = h[b].n_shadow_traced; }
+    for (uint32_t b = 0; b < n; b++) {   // a queue's entries = the sum over its sub-queues (the holes between them are nobody's entries)
+        uint32_t np = 0, nsh = 0;
+        for (uint32_t k = 0; k < QUEUE_SUBS; k++) { np += h[b].sub[k].n_paths; nsh += h[b].sub[k].n_shadow; }
+        out[4 * b] = np; out[4 * b + 1] = h[b].zombies; out[4 * b + 2] = nsh; out[4 * b + 3] = h[b].n_shadow_traced;
+    }
     return (int)n;
 }
 // batch probe of the device shading functions (material / light / mapping code of k_shade), see k_shade_probe

@@ -39,7 +39,8 @@ __device__ __forceinline__ bool shard_pixel(const ShardView& sh, uint32_t p, uin
 
 __global__ __launch_bounds__(SHADE_BLOCK) void k_raygen(ShardView sh, CameraConsts cam, PipelineOpts opts, uint32_t sample_base, uint32_t s_count,
                                                           PathState st, BounceCounters* cnt) {
-    if (blockIdx.x == 0 && threadIdx.x == 0) { cnt->n_paths = s_count * sh.pixels; cnt->zombies = s_count * (sh.pixels - sh.valid_pixels); }   // bounce 0's queue
+    if (blockIdx.x == 0 && threadIdx.x < QUEUE_SUBS) cnt->sub[threadIdx.x].n_paths = queue_dense_len(s_count * sh.pixels, threadIdx.x);   // bounce 0's queue: dense (msne_device.h)
+    if (blockIdx.x == 0 && threadIdx.x == 0) cnt->zombies = s_count * (sh.pixels - sh.valid_pixels);
     // queue index = slot (no compaction, no atomics: one device-scope counter would cap this kernel at ~88 waves/us);
     // the few slots of edge tiles that fall outside the image are flagged and dropped by the first k_shade
     const uint32_t total = s_count * sh.pixels;
@@ -137,7 +138,8 @@ template <int SPEC, bool TEX, int TRUNC = 0>
 __global__ __launch_bounds__(SHADE_BLOCK, shade_spec_wps(SPEC, TEX)) void k_shade(SceneView sc, PipelineOpts opts, PathState cur, HitBuf hits, PathState nxt, ShadowQueue shq,
                                                          const float4* c_prev /* light-sample contributions of the previous bounce */,
                                                          float4* lbuf, BounceCounters* cnt /* [0]: this bounce, [1]: the next */, uint32_t first_pass /* the queue is k_raygen's */) {
-    const uint32_t n = cnt[0].n_paths;
+    const QueueDims qd = queue_dims<false>(&cnt[0]);   // this bounce's path queue: its extent, and which of its entries hold a path (msne_device.h)
+    const uint32_t n = qd.extent;
     const uint32_t max_bounces = opts.max_bounces, env_n = opts.env_samples, mesh_n = opts.mesh_samples;
     const bool have_lights = !(sc.alias_count == 0 || sc.alias_sum == 0.0f);                  // MeshLights::sample returns pdf 0 without them (light.hlsl:131)
     const uint32_t n_nee = env_n + (have_lights ? mesh_n : 0u);                               // shadow-queue entries per path that samples lights
@@ -163,7 +165,7 @@ __global__ __launch_bounds__(SHADE_BLOCK, shade_spec_wps(SPEC, TEX)) void k_shad
         uint32_t cat = CAT_NONE;
         {
             const uint32_t i0 = base_i + threadIdx.x;
-            if (i0 < n) {
+            if (queue_live<false>(qd, i0)) {
                 const float4 ro_own = nt_load(&cur.ro[i0]);
                 const float4 rd_own = nt_load(&cur.rd[i0]);
                 s_ro[threadIdx.x] = ro_own; s_rd[threadIdx.x] = rd_own;
@@ -231,9 +233,9 @@ __global__ __launch_bounds__(SHADE_BLOCK, shade_spec_wps(SPEC, TEX)) void k_shad
             // light samples of the previous bounce, in the reference's order (env samples, then mesh samples): each was stored
             // unoccluded next to its shadow ray and zeroed by k_trace_shadow if the ray was blocked
             if (flags & PATH_FLAG_NEE) {
-                const uint32_t pq = sq2.y;
+                const uint32_t pq = sq2.y & 0x0fffffffu, pk = sq2.y >> 28;   // position in its sub-queue | sub-queue
                 const uint32_t ps = (flags >> PATH_STRIDE_SHIFT) & 0x1ffu;
-                for (uint32_t k = 0; k < n_nee; k++) { const float4 c = nt_load(&c_prev[pq + k * ps]); L = add(L, F3(c.x, c.y, c.z)); }
+                for (uint32_t k = 0; k < n_nee; k++) { const float4 c = nt_load(&c_prev[queue_slot(pq + k * ps, pk)]); L = add(L, F3(c.x, c.y, c.z)); }
             }
             bounceCount = flags & 0xFFFFu;
             const bool isLastMaterialDelta = (flags & PATH_FLAG_DELTA) != 0;
@@ -326,17 +328,23 @@ __global__ __launch_bounds__(SHADE_BLOCK, shade_spec_wps(SPEC, TEX)) void k_shad
             for (int k = 0; k < SHADE_BLOCK / 64; k++) tot += s_cnt[k];
             const uint32_t np = (uint32_t)(tot >> 32);   // paths of this workgroup that sample lights: sample k of all of them is stored together
             s_stride = np;                               // (keeps env rays with env rays and light rays with light rays in the shadow queue)
-            // (a truncated instantiation reserves from the counters' padding: the same atomic traffic, nothing the real kernel reads)
-            s_base = tot ? atomicAdd(reinterpret_cast<unsigned long long*>(TRUNC ? &cnt[1].pad[0] : &cnt[1].n_paths), (tot & 0xffffffffull) | ((unsigned long long)(np * n_nee) << 32)) : 0ull;
+            // the survivors of chunk c go to sub-queue c % QUEUE_SUBS of the next bounce's queues (msne_device.h): eight heads instead of one
+            QueueHead* const head = &cnt[1].sub[(base_i >> QUEUE_TILE_SHIFT) & (QUEUE_SUBS - 1u)];
+            if (TRUNC == 7) s_base = tot;   // (7 = 4 without the atomic: what the three barriers and the LDS traffic cost by themselves)
+            else if (TRUNC == 8) s_base = tot ? atomicAdd(&cnt[1].trunc_pad, tot) : 0ull;   // (8 = 4 with ONE head for everybody, as the kernel was before)
+            else
+            // (a truncated instantiation reserves from the head's padding: the same atomic traffic, nothing the real kernel reads)
+            s_base = tot ? atomicAdd(reinterpret_cast<unsigned long long*>(TRUNC ? &head->pad[0] : &head->n_paths), (tot & 0xffffffffull) | ((unsigned long long)(np * n_nee) << 32)) : 0ull;
         }
         __syncthreads();
         unsigned long long base = s_base;
         const uint32_t stride = s_stride;
         for (uint32_t k = 0; k < wave; k++) base += s_cnt[k];
         __syncthreads();   // s_cnt / s_base / s_stride are rewritten by the next iteration
-        const uint32_t j = (uint32_t)base + (uint32_t)__popcll(ma & lt);
-        const uint32_t q = (uint32_t)(base >> 32) + (uint32_t)__popcll(mn & lt);   // sample k of this path: entry q + k * stride
-        if (TRUNC == 4) { acc ^= j ^ q ^ stride; continue; }
+        const uint32_t kq = (base_i >> QUEUE_TILE_SHIFT) & (QUEUE_SUBS - 1u);
+        const uint32_t j = queue_slot((uint32_t)base + (uint32_t)__popcll(ma & lt), kq);
+        const uint32_t q = (uint32_t)(base >> 32) + (uint32_t)__popcll(mn & lt);   // sample k of this path: entry q + k * stride of sub-queue kq = queue slot queue_slot(q + k * stride, kq)
+        if (TRUNC == 4 || TRUNC == 7 || TRUNC == 8) { acc ^= j ^ q ^ stride; continue; }
         // (TRUNC 5 / 6: the stores below become folds into acc)
         auto st4 = [&](float4* p_, float4 v_) { if (TRUNC == 0) nt_store(p_, v_); else acc ^= f2u(v_.x) ^ f2u(v_.y) ^ f2u(v_.z) ^ f2u(v_.w) ^ (uint32_t)(uintptr_t)p_; };
         auto st2 = [&](uint2* p_, uint2 v_) { if (TRUNC == 0) nt_store(p_, v_); else acc ^= v_.x ^ v_.y ^ (uint32_t)(uintptr_t)p_; };
@@ -347,7 +355,7 @@ __global__ __launch_bounds__(SHADE_BLOCK, shade_spec_wps(SPEC, TEX)) void k_shad
                 for (uint32_t k = 0; k < env_n; k++) {   // integrator.hlsl:141-144
                     f2 rand; rand.x = rng_float(rng); rand.y = rng_float(rng);
                     const LSample ls = env_sample_unoccluded(sc.env, rand);
-                    const uint32_t e_ = q + k * stride;
+                    const uint32_t e_ = queue_slot(q + k * stride, kq);
                     if (ls.pdf > 0.0f) {
                         const f3 so = offset_along_normal(attrs.position, face_forward(attrs.triangleFrame.n, ls.dirWs));
                         const f3 e = estimate_direct_mis(shadingFrame, ls, material, woSs, env_n);
@@ -359,7 +367,7 @@ __global__ __launch_bounds__(SHADE_BLOCK, shade_spec_wps(SPEC, TEX)) void k_shad
                 }
                 for (uint32_t k = 0; k < mesh_n; k++) {  // integrator.hlsl:147-150 + MeshLights::sample light.hlsl:130-158
                     f2 rand; rand.x = rng_float(rng); rand.y = rng_float(rng);
-                    const uint32_t e_ = q + (env_n + k) * stride;
+                    const uint32_t e_ = queue_slot(q + (env_n + k) * stride, kq);
                     if (!have_lights) continue;
                     bool ok = false;
                     const uint32_t entryCount = sc.alias_count;
@@ -410,7 +418,7 @@ __global__ __launch_bounds__(SHADE_BLOCK, shade_spec_wps(SPEC, TEX)) void k_shad
             if (sample.pdf == 0.0f) {
                 // the path ends here; with light samples in flight it is finalised one pass later (after their shadow rays)
                 if (TRUNC == 0) atomicAdd(&cnt[1].zombies, 1u);
-                if (valid) { st4(&nxt.ro[j], make_float4(0.0f, 0.0f, 0.0f, u2f(PATH_FLAG_ZOMBIE | PATH_FLAG_NEE | (stride << PATH_STRIDE_SHIFT)))); st4(&nxt.lr[j], make_float4(L.x, L.y, L.z, 0.0f)); st2(&nxt.sq[j], make_uint2(slot, q)); }
+                if (valid) { st4(&nxt.ro[j], make_float4(0.0f, 0.0f, 0.0f, u2f(PATH_FLAG_ZOMBIE | PATH_FLAG_NEE | (stride << PATH_STRIDE_SHIFT)))); st4(&nxt.lr[j], make_float4(L.x, L.y, L.z, 0.0f)); st2(&nxt.sq[j], make_uint2(slot, q | (kq << 28))); }
                 else { st4(&nxt.ro[j], make_float4(0.0f, 0.0f, 0.0f, u2f(PATH_FLAG_ZOMBIE | PATH_FLAG_DEAD))); st4(&lbuf[slot], make_float4(L.x, L.y, L.z, 0.0f)); }
             } else {
                 const f3 nd = frame_frame_to_world(shadingFrame, sample.dirFs);
@@ -420,19 +428,19 @@ __global__ __launch_bounds__(SHADE_BLOCK, shade_spec_wps(SPEC, TEX)) void k_shad
                 const f3 tp = mul(throughput, F3(f.x * ac / sample.pdf, f.y * ac / sample.pdf, f.z * ac / sample.pdf));
                 const uint32_t nf = ((bounceCount + 1u) & 0xFFFFu) | (delta ? PATH_FLAG_DELTA : 0u) | (nee ? (PATH_FLAG_NEE | (stride << PATH_STRIDE_SHIFT)) : 0u);
                 st4(&nxt.ro[j], make_float4(no.x, no.y, no.z, u2f(nf))); st4(&nxt.rd[j], make_float4(nd.x, nd.y, nd.z, 0.0f));
-                st4(&nxt.tp[j], make_float4(tp.x, tp.y, tp.z, sample.pdf)); st4(&nxt.lr[j], make_float4(L.x, L.y, L.z, u2f(rng))); st2(&nxt.sq[j], make_uint2(slot, q));
+                st4(&nxt.tp[j], make_float4(tp.x, tp.y, tp.z, sample.pdf)); st4(&nxt.lr[j], make_float4(L.x, L.y, L.z, u2f(rng))); st2(&nxt.sq[j], make_uint2(slot, q | (kq << 28)));
             }
         }
     }
-    if (TRUNC != 0 && acc == 0x9e3779b9u && n == 0xffffffffu) lbuf[0] = make_float4(u2f(acc), 0.0f, 0.0f, 0.0f);   // (never: keeps the truncated kernel's loads alive)
+    if (TRUNC != 0 && acc == 0x9e3779b9u && cnt[0].head_closest == 0xffffffffu) lbuf[0] = make_float4(u2f(acc), 0.0f, 0.0f, 0.0f);   // (never — but only memory knows: keeps the truncated kernel's loads alive)
 }
 
 // statistics of a finished batch: rays traced and camera paths started, from its per-bounce counters
 __global__ void k_account(const BounceCounters* c, uint32_t n_bounces, Totals* t) {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
     unsigned long long closest = 0, shadow = 0;
-    for (uint32_t b = 0; b <= n_bounces; b++) { closest += c[b].n_paths - c[b].zombies; shadow += c[b].n_shadow_traced; }
-    t->closest_rays += closest; t->shadow_rays += shadow; t->samples += c[0].n_paths - c[0].zombies;
+    for (uint32_t b = 0; b <= n_bounces; b++) { closest += queue_total(&c[b], false) - c[b].zombies; shadow += c[b].n_shadow_traced; }
+    t->closest_rays += closest; t->shadow_rays += shadow; t->samples += queue_total(&c[0], false) - c[0].zombies;
 }
 
 // storeColor main.hlsl:43-51 over the `s_count` samples of this chunk (summed in sample order, main.hlsl:83-92)
@@ -561,7 +569,7 @@ void launch_shade(hipStream_t s, int grid, const SceneView& sc, const PipelineOp
     if (trunc && !first_pass) {   // measurement: the truncated kernels on the same queues, in front of the real one
 #define MSNE_TRUNC_LAUNCH(T) do { if (textured) hipLaunchKernelGGL((k_shade<0, true, T>), dim3(grid), dim3(SHADE_BLOCK), 0, s, sc, o, cur, hits, nxt, q, c_prev, lbuf, cnt, fp); \
                                   else hipLaunchKernelGGL((k_shade<0, false, T>), dim3(grid), dim3(SHADE_BLOCK), 0, s, sc, o, cur, hits, nxt, q, c_prev, lbuf, cnt, fp); } while (0)
-        MSNE_TRUNC_LAUNCH(1); MSNE_TRUNC_LAUNCH(2); MSNE_TRUNC_LAUNCH(3); MSNE_TRUNC_LAUNCH(4); MSNE_TRUNC_LAUNCH(5); MSNE_TRUNC_LAUNCH(6);
+        MSNE_TRUNC_LAUNCH(1); MSNE_TRUNC_LAUNCH(2); MSNE_TRUNC_LAUNCH(3); MSNE_TRUNC_LAUNCH(4); MSNE_TRUNC_LAUNCH(7); MSNE_TRUNC_LAUNCH(8); MSNE_TRUNC_LAUNCH(5); MSNE_TRUNC_LAUNCH(6);
 #undef MSNE_TRUNC_LAUNCH
     }
     if (!specialised) {

@@ -186,7 +186,7 @@ struct PathState {
     float4* rd;     // ray direction xyz | w unused
     float4* tp;     // throughput rgb | w = pdf of the last BSDF sample
     float4* lr;     // accumulated radiance rgb | w = rng state (bit pattern)
-    uint2* sq;      // x = sample slot (s_local * pixels + pixel_local), y = first of the path's light-sample entries in the shadow queue
+    uint2* sq;      // x = sample slot (s_local * pixels + pixel_local), y = first of the path's light-sample entries in the shadow queue: position in its sub-queue | sub-queue << 28
     // flags (in ro.w): bits 0..15 bounce count, bit 16 last material delta, bit 17 no ray (finalise only), bit 18 masked,
     // bit 19 light samples pending (env_samples + mesh_samples entries from sq.y, PATH_STRIDE apart), bit 20 dead
 };
@@ -213,16 +213,64 @@ struct ShadowQueue {
 
 // Queue counters of ONE bounce of a batch.  A batch owns an array of them indexed by bounce, zeroed when it starts, so
 // nothing has to be rotated or reset between the kernels of a bounce (no bookkeeping launches in the bounce loop):
-// k_trace_closest(b) and k_shade(b) consume [b]; k_shade(b) appends to [b + 1]; k_trace_shadow(b) consumes [b + 1].n_shadow_in.
-struct alignas(8) BounceCounters {
-    uint32_t n_paths, n_shadow_in;       // path-queue entries of this bounce | shadow rays made by the previous bounce's k_shade
-                                         // (adjacent: ONE 64-bit atomic per workgroup appends to both)
-    uint32_t zombies;                    // of n_paths: entries that only wait to be finalised (no ray)
+// k_trace_closest(b) and k_shade(b) consume [b]; k_shade(b) appends to [b + 1]; k_trace_shadow(b) consumes [b + 1]'s shadow half.
+//
+// The heads k_shade appends to sit on a cache line of their own (QueueHead): in the 32-byte record of rounds 1-4 they shared a line with the neighbouring bounces' counters
+// and with the dequeue heads the traversal kernels hammer — every workgroup of k_shade(b) reads the line it starts from while the atomics of the same kernel rewrite it.
+// Taking them apart is worth 3-4 % of k_shade (S1 23.0 -> 21.3 ms per 64-launch batch, S2 33.0 -> 31.9: profiles/r05_shade_td.txt).
+//
+// A queue may be cut into QUEUE_SUBS sub-queues interleaved in tiles of 256 entries: tile t of the queue belongs to sub-queue t % QUEUE_SUBS, entry p of sub-queue k sits at
+// queue_slot(p, k), and k_shade appends the survivors of its 256-path chunk c to sub-queue c % QUEUE_SUBS with ONE 64-bit atomic on THAT sub-queue's head.  The reason to want
+// it: one device-scope atomic word hands out ~88 reservations per microsecond on this part, and k_shade's first pass makes 162 k of them in 2.2 ms (74 per microsecond) — a
+// truncated k_shade that ends right after the reservation spends 4.1 of its 10.5 ms waiting for the one word, and none with eight (profiles/r05_shade_td.txt).  The price is holes
+// — the sub-queues end at different lengths, so the last tiles of the shorter ones hold no path; nobody writes or reads them: every consumer derives a queue's extent and which
+// entries are live from the heads (queue_dims / queue_live: one compare below the shortest sub-queue's last full tile, a lookup above it).  Chunk c of bounce b is tile c of its
+// queue, so sub-queue k of bounce b + 1 is fed by sub-queue k of bounce b alone and can never be longer: extents only shrink.  MEASURED, the whole kernel does not yet run into
+// the one-word ceiling: 1 / 4 / 8 / 16 heads give S1 6400 / 6380 / 6325 / 6333 and S2 3846 / 3842 / 3791 / 3805 Mrays/s — the mapping and the hole checks cost what the
+// heads save.  The shipped value is ONE sub-queue (a dense queue, as before); the general form stays, compiled as a variant and run by the tests
+// (test_sub_queues_render_the_same_film), for the day k_shade is fast enough to need it.
+#ifndef MSNE_QUEUE_SUBS
+#define MSNE_QUEUE_SUBS 1
+#endif
+constexpr uint32_t QUEUE_SUBS = MSNE_QUEUE_SUBS, QUEUE_TILE_SHIFT = 8u;   // (a power of two; 1 = one head per queue, as before round 5)
+struct alignas(128) QueueHead { uint32_t n_paths, n_shadow; uint32_t pad[30]; };   // (adjacent: ONE 64-bit atomic per workgroup appends to both)
+struct alignas(128) BounceCounters {
+    QueueHead sub[QUEUE_SUBS];           // path entries | shadow-queue entries of this bounce's queues, per sub-queue
+    uint32_t zombies;                    // of the path entries: entries that only wait to be finalised (no ray)
     uint32_t head_closest, head_shadow;  // dequeue heads of k_trace_closest(b) and k_trace_shadow(b - 1)
-    uint32_t n_shadow_traced;            // of n_shadow_in: entries that held a ray (a light sample with pdf 0 leaves its entry unused), counted by k_trace_shadow
-    uint32_t pad[2];
+    uint32_t n_shadow_traced;            // of the shadow entries: entries that held a ray (a light sample with pdf 0 leaves its entry unused), counted by k_trace_shadow
+    unsigned long long trunc_pad;        // (what the truncated measurement instantiations of k_shade reserve from: integrator.hip TRUNC)
+    uint32_t pad[26];
 };
-static_assert(sizeof(BounceCounters) == 32, "BounceCounters must be 32 bytes");
+static_assert(sizeof(BounceCounters) == 128 * (QUEUE_SUBS + 1), "BounceCounters layout");
+// the shape of one queue, as every consumer derives it from the heads (two registers; the rare entry above dense_end looks its sub-queue's length up in memory)
+struct QueueDims { uint32_t extent /* entries, holes included */, dense_end /* every entry below is live */; const BounceCounters* c; };
+template <bool SHADOW>
+__device__ __forceinline__ QueueDims queue_dims(const BounceCounters* c) {
+    QueueDims d; uint32_t tmin = 0xffffffffu, tmax = 0u;
+#pragma unroll
+    for (uint32_t k = 0; k < QUEUE_SUBS; k++) {
+        const uint32_t len = SHADOW ? c->sub[k].n_shadow : c->sub[k].n_paths;
+        const uint32_t full = len >> QUEUE_TILE_SHIFT, used = (len + 255u) >> QUEUE_TILE_SHIFT;
+        tmin = full < tmin ? full : tmin; tmax = used > tmax ? used : tmax;
+    }
+    d.extent = (tmax * QUEUE_SUBS) << QUEUE_TILE_SHIFT; d.dense_end = (tmin * QUEUE_SUBS) << QUEUE_TILE_SHIFT; d.c = c;
+    return d;
+}
+__device__ __forceinline__ uint32_t queue_total(const BounceCounters* c, bool shadow) { uint32_t n = 0; for (uint32_t k = 0; k < QUEUE_SUBS; k++) n += shadow ? c->sub[k].n_shadow : c->sub[k].n_paths; return n; }
+MSNE_HD uint32_t queue_slot(uint32_t p, uint32_t k) { return ((((p >> QUEUE_TILE_SHIFT) * QUEUE_SUBS) + k) << QUEUE_TILE_SHIFT) | (p & 255u); }
+template <bool SHADOW>
+__device__ __forceinline__ bool queue_live(const QueueDims& d, uint32_t i) {
+    if (i < d.dense_end) return true;
+    if (i >= d.extent) return false;
+    const uint32_t tile = i >> QUEUE_TILE_SHIFT, k = tile & (QUEUE_SUBS - 1u), p = ((tile / QUEUE_SUBS) << QUEUE_TILE_SHIFT) | (i & 255u);
+    return p < (SHADOW ? d.c->sub[k].n_shadow : d.c->sub[k].n_paths);
+}
+// the lengths of the sub-queues of a DENSE queue of n entries (k_raygen's: queue index = sample slot)
+MSNE_HD uint32_t queue_dense_len(uint32_t n, uint32_t k) {
+    const uint32_t T = n >> QUEUE_TILE_SHIFT, r = n & 255u;
+    return ((T / QUEUE_SUBS + (k < T % QUEUE_SUBS ? 1u : 0u)) << QUEUE_TILE_SHIFT) + (k == T % QUEUE_SUBS ? r : 0u);
+}
 struct Totals { unsigned long long closest_rays, shadow_rays, samples, pad; };   // since the last MsneResetStats
 
 struct PipelineOpts {   // pipeline.zig:319-327

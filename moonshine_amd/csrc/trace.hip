@@ -578,10 +578,12 @@ template <bool STATS, bool INSTANCED>
 __global__ __launch_bounds__(TRACE_BLOCK, INSTANCED ? TRACE_WPS_TLAS : TRACE_WPS) void k_trace_closest(SceneView sc, PathState st, HitBuf hits, BounceCounters* cnt,
                                                                 uint32_t* spill, uint32_t* overflow, unsigned long long* stat_out, uint32_t refill) {
     TRACE_LDS_DECL;
-    const uint32_t n = cnt->n_paths;
+    const QueueDims qd = queue_dims<false>(cnt);   // the bounce's path queue: eight interleaved sub-queues, holes in the last tiles of the shorter ones (msne_device.h)
+    const uint32_t n = qd.extent;
     unsigned long long nv = 0, nt = 0;
     trace_wave_loop<false, STATS, INSTANCED>(sc, n, &cnt->head_closest, lds_stack, lds_lut, spill, overflow, refill,
         [&](uint32_t i, f3& o, f3& d, float& tmax) -> bool {
+            if (!queue_live<false>(qd, i)) return false;
             const float4 ro = nt_load(&st.ro[i]);
             if (f2u(ro.w) & PATH_FLAG_ZOMBIE) return false;
             const float4 rd = INSTANCED ? st.rd[i] : nt_load(&st.rd[i]);   // (two-level scenes read the direction again at every instance they enter: it stays cached)
@@ -599,13 +601,15 @@ template <bool STATS, bool INSTANCED>
 __global__ __launch_bounds__(TRACE_BLOCK, INSTANCED ? TRACE_WPS_TLAS : TRACE_WPS) void k_trace_shadow(SceneView sc, ShadowQueue q, BounceCounters* cnt,
                                                                uint32_t* spill, uint32_t* overflow, unsigned long long* stat_out, uint32_t refill) {
     TRACE_LDS_DECL;
-    const uint32_t n = cnt->n_shadow_in;
+    const QueueDims qs = queue_dims<true>(cnt);   // the shadow queue the previous k_shade filled
+    const uint32_t n = qs.extent;
     unsigned long long nv = 0, nt = 0;
     trace_wave_loop<true, STATS, INSTANCED>(sc, n, &cnt->head_shadow, lds_stack, lds_lut, spill, overflow, refill,
         [&](uint32_t i, f3& o, f3& d, float& tmax) -> bool {
-            const float4 qo = nt_load(&q.o[i]), qd = INSTANCED ? q.d[i] : nt_load(&q.d[i]);
+            if (!queue_live<true>(qs, i)) return false;
+            const float4 qo = nt_load(&q.o[i]), qdir = INSTANCED ? q.d[i] : nt_load(&q.d[i]);
             if (qo.w < 0.0f) return false;   // unused entry
-            o = F3(qo.x, qo.y, qo.z); d = F3(qd.x, qd.y, qd.z); tmax = qo.w;
+            o = F3(qo.x, qo.y, qo.z); d = F3(qdir.x, qdir.y, qdir.z); tmax = qo.w;
             return true;
         },
         [&](uint32_t i) -> f3 { const float4 qd = q.d[i]; return F3(qd.x, qd.y, qd.z); },

@@ -986,6 +986,22 @@ def test_traversal_stack_spill_path(tmp_path):
 
 
 @pytest.mark.gpu
+def test_sub_queues_render_the_same_film(tmp_path):
+    """csrc/msne_device.h QUEUE_SUBS: a path queue may be eight interleaved sub-queues with a head each (holes in the last tiles of the shorter ones, which every consumer
+    derives from the heads).  The shipped library runs with one; a second library built with eight renders a subset of this file — randomized scenes (several tiles of
+    paths, every pipeline), edits, the sharded film, progressive batches — against the oracle in a process of its own"""
+    from moonshine_amd import build as b
+    lib = b.build(variant="q8", extra_flags=["-DMSNE_QUEUE_SUBS=8"])
+    env = dict(os.environ, MSNE_LIB=lib, MSNE_FUZZ_SEEDS="0-15")
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-m", "gpu", "-x", "-q", "-p", "no:cacheprovider", "-k",
+                        "test_random_scenes_match_oracle or test_random_big_scenes_match_oracle or test_random_edits_match_oracle or test_sharded_film_equals_unsharded or test_progressive_equals_batched "
+                        "or test_s1_small or test_instanced_s2_small or test_several_light_samples_per_bounce or test_launch_larger_than_inflight_budget or test_furnace"],
+                       env=env, capture_output=True, text=True, timeout=1200)
+    tail = (r.stdout or "")[-1500:] + (r.stderr or "")[-500:]
+    assert r.returncode == 0 and " passed" in tail and "failed" not in tail, tail
+
+
+@pytest.mark.gpu
 def test_fine_morton_codes(tmp_path):
     """the builder switches from 10 to 21 bits per axis (63-bit codes, eight sort passes) above 4 M primitives — no test scene is that large, so a second
     process forces the fine codes ($MSNE_MORTON_BITS=21) on S1 and the instanced S2 (single and segmented builds, TLAS): films and ray counts like the oracle's"""

@@ -37,7 +37,7 @@ for f in glob.glob(os.path.join(G + "_trace", "**", "*kernel_trace.csv"), recurs
         k = name_of(r["Kernel_Name"])
         if k:
             trace[k][0] += 1; trace[k][1] += int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
-order = ["k_shade<TRUNC %d>" % i for i in range(1, 7)] + ["k_shade (full)"]
+order = ["k_shade<TRUNC %d>" % i for i in (1, 2, 3, 7, 4, 5, 6)] + ["k_shade (full)"]
 print("# %s — k_shade cut after each of its stages (tools/shade_td.py %s %s; S1, the driver's 20 steps; the first pass of a batch — camera rays, no state to load — is not truncated)" % (open(G + "_cmd.txt").read().strip(), tag, scene))
 print("# kernel trace (no counters): dispatches, total ms, mean us per dispatch, and what each stage adds")
 prev = 0.0
