@@ -170,8 +170,20 @@ __global__ __launch_bounds__(SHADE_BLOCK, shade_spec_wps(SPEC, TEX)) void k_shad
                 const float4 rd_own = nt_load(&cur.rd[i0]);
                 s_ro[threadIdx.x] = ro_own; s_rd[threadIdx.x] = rd_own;
                 if (first_pass) { s_tp[threadIdx.x] = make_float4(1.0f, 1.0f, 1.0f, 0.0f); s_lr[threadIdx.x] = make_float4(0.0f, 0.0f, 0.0f, rd_own.w); s_sq[threadIdx.x] = make_uint2(i0, 0u); }
-                else { s_tp[threadIdx.x] = nt_load(&cur.tp[i0]); s_lr[threadIdx.x] = nt_load(&cur.lr[i0]); s_sq[threadIdx.x] = nt_load(&cur.sq[i0]); }
                 const uint32_t fl = f2u(ro_own.w);
+                if (!first_pass) {
+                    s_tp[threadIdx.x] = nt_load(&cur.tp[i0]);
+                    float4 lr_own = nt_load(&cur.lr[i0]); const uint2 sq_own = nt_load(&cur.sq[i0]);
+                    // light samples of the previous bounce, in the reference's order (env samples, then mesh samples): each was stored unoccluded next to its shadow ray
+                    // and zeroed by k_trace_shadow if the ray was blocked.  Added HERE, by the thread that owns the queue entry, as soon as the entry's flags and sample
+                    // position are in: the fetches run next to the hit / geometry / material chain below instead of after the sort
+                    if (fl & PATH_FLAG_NEE) {
+                        const uint32_t pq = sq_own.y & 0x0fffffffu, pk = sq_own.y >> 28;   // position in its sub-queue | sub-queue
+                        const uint32_t ps = (fl >> PATH_STRIDE_SHIFT) & 0x1ffu;
+                        for (uint32_t k = 0; k < n_nee; k++) { const float4 c = nt_load(&c_prev[queue_slot(pq + k * ps, pk)]); lr_own.x = lr_own.x + c.x; lr_own.y = lr_own.y + c.y; lr_own.z = lr_own.z + c.z; }
+                    }
+                    s_lr[threadIdx.x] = lr_own; s_sq[threadIdx.x] = sq_own;
+                }
                 if (TRUNC == 1) acc ^= fl ^ f2u(rd_own.x);
                 if (TRUNC != 1 && !(fl & (PATH_FLAG_MASKED | PATH_FLAG_DEAD))) {
                     if (fl & PATH_FLAG_ZOMBIE) cat = 0u;
@@ -230,13 +242,7 @@ __global__ __launch_bounds__(SHADE_BLOCK, shade_spec_wps(SPEC, TEX)) void k_shad
             const float4 tp4 = s_tp[src], lr4 = s_lr[src]; const uint2 sq2 = s_sq[src];
             throughput = F3(tp4.x, tp4.y, tp4.z); L = F3(lr4.x, lr4.y, lr4.z);
             lastPdf = tp4.w; rng = f2u(lr4.w); slot = sq2.x; flags = f2u(ro4.w);
-            // light samples of the previous bounce, in the reference's order (env samples, then mesh samples): each was stored
-            // unoccluded next to its shadow ray and zeroed by k_trace_shadow if the ray was blocked
-            if (flags & PATH_FLAG_NEE) {
-                const uint32_t pq = sq2.y & 0x0fffffffu, pk = sq2.y >> 28;   // position in its sub-queue | sub-queue
-                const uint32_t ps = (flags >> PATH_STRIDE_SHIFT) & 0x1ffu;
-                for (uint32_t k = 0; k < n_nee; k++) { const float4 c = nt_load(&c_prev[queue_slot(pq + k * ps, pk)]); L = add(L, F3(c.x, c.y, c.z)); }
-            }
+            // (the previous bounce's light samples are already in L: added when the entry was staged)
             bounceCount = flags & 0xFFFFu;
             const bool isLastMaterialDelta = (flags & PATH_FLAG_DELTA) != 0;
             bool done = (flags & PATH_FLAG_ZOMBIE) != 0;

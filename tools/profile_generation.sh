@@ -12,6 +12,10 @@ timeout 300 python3 bench.py --steps 20 --warmup 4 > $O/${TAG}_bench_n1_k20.json
 timeout 300 python3 bench.py --steps 64 --warmup 4 > $O/${TAG}_bench_n1_k64.json 2> /dev/null < /dev/null
 timeout 300 python3 bench.py --scene s2 --steps 64 --warmup 4 --no-cpu-baseline > $O/${TAG}_bench_s2_k64.json 2> /dev/null < /dev/null
 timeout 300 python3 bench.py --env sky --steps 64 --warmup 4 --no-cpu-baseline > $O/${TAG}_bench_s1_sky_k64.json 2> /dev/null < /dev/null
+timeout 300 python3 bench.py --scene s2 --steps 20 --warmup 4 --no-cpu-baseline > $O/${TAG}_bench_s2_k20.json 2> /dev/null < /dev/null
+timeout 300 python3 bench.py --env sky --steps 20 --warmup 4 --no-cpu-baseline > $O/${TAG}_bench_s1_sky_k20.json 2> /dev/null < /dev/null
+# a render is seconds of launches, the timed region a burst: the same batch back to back for 12 s (rate per 1-s window, shader clock probed while it runs)
+(for a in "--steps 20" "--steps 64" "--scene s2 --steps 64"; do timeout 300 python3 bench.py $a --warmup 4 --no-cpu-baseline --sustain-seconds 12 2>/dev/null < /dev/null | python3 -c "import sys,json; d=json.loads(sys.stdin.read()); print('bench.py $a --sustain-seconds 12: burst %.1f Mrays/s (median of %d repeats) | sustained %s' % (d['value'], d['repeats'], json.dumps(d['sustained'])))"; done) > $O/${TAG}_sustained.txt
 (timeout 600 python3 tools/scene_rates.py 2>&1 < /dev/null | grep Mrays; timeout 300 python3 tools/standin_rates.py 2>&1 < /dev/null | grep "^run") > $O/${TAG}_scene_rates.txt
 (for i in 1 2 3 4 5 6; do timeout 200 python3 bench.py --steps 20 --warmup 4 --no-cpu-baseline 2>/dev/null < /dev/null | python3 -c "import sys,json; d=json.loads(sys.stdin.read()); print('run $i: %.1f Mrays/s, repeats %s' % (d['value'], ' '.join('%.0f' % v for v in d['repeat_values'])))"; done) > $O/${TAG}_soak.txt
 export MSNE_BUILD_TIMING=1
