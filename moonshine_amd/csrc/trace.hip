@@ -306,6 +306,9 @@ __device__ __forceinline__ bool step_tri(Lane& L, const SceneView& sc, unsigned 
 // queue head, and (3) a chunk is 64..256 rays that the wave's lanes consume one by one as they go idle.
 // Small chunks handed out IN ORDER also keep all resident waves inside one window of ~1.5 M consecutive rays of the
 // (screen-ordered) queue, so they share BVH nodes in L2: a big static share per wave was measured 1.4-2x slower.
+// (An XCD-aware hand-out — the queue cut into eight contiguous ranges, the waves of XCD b % 8 draining range x from a head of its own, a dry range's waves moving to the
+// fullest one — was built and measured in round 5: S1 -2 %, 20-launch batches -3.5 %, S2 -5 %.  One window of the whole queue shared by all eight L2s beats eight windows
+// with an eighth of the screen each: profiles/r05_tri_density.txt section 6.)
 struct WaveQueue {
     uint32_t n, chunk, pos, end, nwaves_chunk;
     uint32_t* head;
