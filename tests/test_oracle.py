@@ -240,3 +240,31 @@ def test_sample_count_and_clear_rules(orc):
     assert c.sample_count(s) == 0
     c.render(s, l)
     assert np.all(c.sensor_data(s)[..., 3] == 1.0)
+
+
+def test_geometry_material_reassignment(orc):
+    """Accel.recordUpdateSingleMaterial (Accel.zig:609-628) on the oracle: one field of the flat geometry table — the film changes from the next render on, the alias table
+    (areas only, Accel.zig:503-519) and the sample count do not, an edit back restores the first film bit for bit, unknown handles are refused"""
+    c = orc.Context(threads=usable_cores())
+    black = c.solid_texture(0.0, 0.0, 0.0); flat = c.solid_texture(0.5, 0.5)
+    red = c.create_material(scenes.LAMBERT, flat, black, color=c.solid_texture(0.8, 0.1, 0.1))
+    mirror = c.create_material(scenes.PERFECT_MIRROR, flat, black)
+    glow = c.create_material(scenes.LAMBERT, flat, c.solid_texture(4.0, 4.0, 4.0), color=black)
+    P, I = scenes.icosphere(2); sphere = c.create_mesh(P, I)
+    Pq, Iq = scenes.quad((-1, -1, 2.5), (1, -1, 2.5), (1, 1, 2.5), (-1, 1, 2.5)); lamp = c.create_mesh(Pq, Iq)
+    inst = c.create_instance([(sphere, red, False)], transform=np.eye(3, 4, dtype=np.float32))
+    c.create_instance([(lamp, glow, True)], transform=np.eye(3, 4, dtype=np.float32))
+    c.set_background(np.array([0.2, 0.2, 0.3, 1.0], np.float32), 1, 1)
+    s = c.create_sensor(24, 16); l = c.create_lens(c.make_lens((0.0, -5.0, 0.5), (0.0, 1.0, 0.0), (0, 0, 1), 0.7))
+    c.set_pipeline(samples_per_run=4, max_bounces=4, env_samples_per_bounce=1, mesh_samples_per_bounce=1)
+    c.render(s, l, launches=2); first = c.sensor_data(s).copy(); alias = np.asarray(c.alias_table()).copy()
+    c.set_geometry_material(inst, 0, mirror)
+    assert c.sample_count(s) == 8                                  # the caller clears (online/main.zig:231), the call does not
+    c.clear_sensor(s); c.render(s, l, launches=2); second = c.sensor_data(s).copy()
+    assert not np.array_equal(first[..., :3], second[..., :3])
+    assert np.array_equal(np.asarray(c.alias_table()).view(np.uint8), alias.view(np.uint8))
+    c.set_geometry_material(inst, 0, red); c.clear_sensor(s); c.render(s, l, launches=2)
+    assert np.array_equal(c.sensor_data(s).view(np.uint32), first.view(np.uint32))
+    for bad in ((7, 0, red), (inst, 1, red), (inst, 0, 99)):
+        with pytest.raises(RuntimeError):
+            c.set_geometry_material(*bad)
