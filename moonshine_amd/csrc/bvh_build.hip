@@ -1016,8 +1016,10 @@ bool bvh_build_blas_batch(BuildScratch* scratch, hipStream_t s, const std::vecto
 struct TlasInst { float T[12]; float blas_box[6]; uint32_t mesh_begin, mesh_end, exact, pad; };   // mesh_begin..mesh_end index TlasMesh
 struct TlasMesh { const float* positions; uint32_t count, pad; };
 
-__global__ __launch_bounds__(256) void k_instance_boxes(const TlasInst* insts, const TlasMesh* meshes, uint32_t n, Box* boxes) {
-    __shared__ float s_lo[3][256 / 64], s_hi[3][256 / 64];
+// One workgroup per instance: the box of its transformed vertices (the TLAS leaf box) and — sphere_ids != nullptr — its world-space bounding sphere into
+// spheres[sphere_ids[i]]: centre = the box's, radius = the farthest transformed vertex (msne_device.h TlasLeaf; the traversal inflates it).
+__global__ __launch_bounds__(256) void k_instance_boxes(const TlasInst* insts, const TlasMesh* meshes, uint32_t n, Box* boxes, const uint32_t* sphere_ids, float4* spheres) {
+    __shared__ float s_lo[3][256 / 64], s_hi[3][256 / 64], s_r2[256 / 64];
     const uint32_t i = blockIdx.x;
     if (i >= n) return;
     const TlasInst in = insts[i];
@@ -1040,13 +1042,37 @@ __global__ __launch_bounds__(256) void k_instance_boxes(const TlasInst* insts, c
         if ((threadIdx.x & 63) == 0) { s_lo[k][threadIdx.x >> 6] = lo[k]; s_hi[k][threadIdx.x >> 6] = hi[k]; }
     }
     __syncthreads();
-    if (threadIdx.x != 0) return;
-    for (int k = 0; k < 3; k++) for (int w = 0; w < 256 / 64; w++) { lo[k] = fminf(lo[k], s_lo[k][w]); hi[k] = fmaxf(hi[k], s_hi[k][w]); }
-    if (lo[0] > hi[0]) for (int k = 0; k < 8; k++) {   // no vertex seen: the transformed corners of the BLAS root box
+    for (int k = 0; k < 3; k++) { lo[k] = s_lo[k][0]; hi[k] = s_hi[k][0]; for (int w = 1; w < 256 / 64; w++) { lo[k] = fminf(lo[k], s_lo[k][w]); hi[k] = fmaxf(hi[k], s_hi[k][w]); } }
+    const bool seen = !(lo[0] > hi[0]);
+    if (!seen) for (int k = 0; k < 8; k++) {   // no vertex seen: the transformed corners of the BLAS root box
         const f3 q = m34_mul_point(T, F3((k & 1) ? in.blas_box[3] : in.blas_box[0], (k & 2) ? in.blas_box[4] : in.blas_box[1], (k & 4) ? in.blas_box[5] : in.blas_box[2]));
         lo[0] = fminf(lo[0], q.x); lo[1] = fminf(lo[1], q.y); lo[2] = fminf(lo[2], q.z);
         hi[0] = fmaxf(hi[0], q.x); hi[1] = fmaxf(hi[1], q.y); hi[2] = fmaxf(hi[2], q.z);
     }
+    if (sphere_ids) {   // the farthest vertex from the box's centre (second pass over the same vertices)
+        const f3 c = F3(0.5f * lo[0] + 0.5f * hi[0], 0.5f * lo[1] + 0.5f * hi[1], 0.5f * lo[2] + 0.5f * hi[2]);
+        float r2 = 0.0f;
+        if (seen) {
+            for (uint32_t m = in.mesh_begin; m < in.mesh_end; m++) {
+                const TlasMesh me = meshes[m];
+                for (uint32_t v = threadIdx.x; v < me.count; v += 256) {
+                    const f3 q = m34_mul_point(T, F3(me.positions[3 * (size_t)v], me.positions[3 * (size_t)v + 1], me.positions[3 * (size_t)v + 2]));
+                    if (!(q.x == q.x && q.y == q.y && q.z == q.z)) continue;
+                    const f3 e = sub(q, c);
+                    r2 = fmaxf(r2, dot(e, e));
+                }
+            }
+        } else { const f3 e = sub(F3(hi[0], hi[1], hi[2]), c); r2 = dot(e, e); }   // the box's own circumscribed sphere
+        for (int o = 32; o >= 1; o >>= 1) r2 = fmaxf(r2, __shfl_xor(r2, o));
+        if ((threadIdx.x & 63) == 0) s_r2[threadIdx.x >> 6] = r2;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            for (int w = 0; w < 256 / 64; w++) r2 = fmaxf(r2, s_r2[w]);
+            if (!(r2 >= 0.0f) || !(r2 < 3e38f) || !(c.x == c.x && c.y == c.y && c.z == c.z)) r2 = 3e38f;   // (not finite: a sphere nothing is outside of)
+            spheres[sphere_ids[i]] = make_float4(c.x, c.y, c.z, r2 < 1e37f ? sqrtf(r2) : 1e18f);   // (radius; 1e18: its square is still finite)
+        }
+    }
+    if (threadIdx.x != 0) return;
     float pad = 1e-30f;
     for (int k = 0; k < 3; k++) pad += 1e-6f * (fabsf(hi[k] - lo[k]) + fabsf(hi[k]) + fabsf(lo[k]));
     Box b;
@@ -1056,7 +1082,8 @@ __global__ __launch_bounds__(256) void k_instance_boxes(const TlasInst* insts, c
 
 // insts / meshes: host arrays describing the n visible instances (ids: instance index per entry)
 bool bvh_build_tlas(BuildScratch* scratch, hipStream_t s, const TlasInst* insts, const uint32_t* host_ids, uint32_t n, const TlasMesh* meshes, uint32_t nmeshes,
-                    Node8* nodes, uint32_t* node_counter, uint32_t node_capacity, uint32_t* tlas_items, uint32_t* item_counter, uint32_t* item_src, uint32_t* root_out) {
+                    Node8* nodes, uint32_t* node_counter, uint32_t node_capacity, uint32_t* tlas_items, uint32_t* item_counter, uint32_t* item_src, uint32_t* root_out,
+                    float4* spheres /* per INSTANCE (indexed by host_ids[i]): its world-space bounding sphere */) {
     if (n == 0) { *root_out = MAX_UINT; return true; }
     if (!scratch) return false;
     BuildScratch& g_scratch = *scratch;
@@ -1068,7 +1095,7 @@ bool bvh_build_tlas(BuildScratch* scratch, hipStream_t s, const TlasInst* insts,
     HIPCHK(hipMemcpyAsync(dinst, insts, (size_t)n * sizeof(TlasInst), hipMemcpyHostToDevice, s));
     if (nmeshes) HIPCHK(hipMemcpyAsync(dmesh, meshes, (size_t)nmeshes * sizeof(TlasMesh), hipMemcpyHostToDevice, s));
     HIPCHK(hipMemcpyAsync(dids, host_ids, (size_t)n * 4, hipMemcpyHostToDevice, s));
-    hipLaunchKernelGGL(k_instance_boxes, dim3(n), dim3(256), 0, s, dinst, dmesh, n, g_scratch.boxes);
+    hipLaunchKernelGGL(k_instance_boxes, dim3(n), dim3(256), 0, s, dinst, dmesh, n, g_scratch.boxes, dids, spheres);
     uint32_t item_begin = 0;
     HIPCHK(hipMemcpyAsync(&item_begin, item_counter, 4, hipMemcpyDeviceToHost, s));
     Box rb;
@@ -1214,7 +1241,7 @@ __global__ void k_tlas_refit_apply(Node8* nodes, RefitState R, uint32_t node_beg
 }
 
 // the traversal's record of every TLAS leaf (msne_device.h TlasLeaf), from the instance records: after a TLAS build and after every in-place update
-__global__ void k_tlas_leaves(const uint32_t* items, const InstanceRec* instances, uint32_t n, TlasLeaf* out) {
+__global__ void k_tlas_leaves(const uint32_t* items, const InstanceRec* instances, const float4* spheres, uint32_t n, TlasLeaf* out) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const uint32_t ii = items[i];
@@ -1224,10 +1251,12 @@ __global__ void k_tlas_leaves(const uint32_t* items, const InstanceRec* instance
     l.root = (r.flags & INST_FLAG_VISIBLE) ? r.blas_root : MAX_UINT;
     l.inst = (r.flags & INST_FLAG_WORLD) ? WORLD_INSTANCE : ii;
     l.flags = r.flags; l.pad = 0u;
+    const float4 sp = spheres[ii];
+    l.sx = sp.x; l.sy = sp.y; l.sz = sp.z; l.sr = sp.w;
     out[i] = l;
 }
-void bvh_tlas_leaves(hipStream_t s, const uint32_t* items, const InstanceRec* instances, uint32_t n, TlasLeaf* out) {
-    if (n) hipLaunchKernelGGL(k_tlas_leaves, dim3((n + 255) / 256), dim3(256), 0, s, items, instances, n, out);
+void bvh_tlas_leaves(hipStream_t s, const uint32_t* items, const InstanceRec* instances, const float4* spheres, uint32_t n, TlasLeaf* out) {
+    if (n) hipLaunchKernelGGL(k_tlas_leaves, dim3((n + 255) / 256), dim3(256), 0, s, items, instances, spheres, n, out);
 }
 
 void bvh_tlas_links(hipStream_t s, const Node8* nodes, uint32_t node_begin, uint32_t node_end, uint32_t item_begin, uint2* node_parent, uint2* item_parent, uint32_t root) {
@@ -1236,13 +1265,14 @@ void bvh_tlas_links(hipStream_t s, const Node8* nodes, uint32_t node_begin, uint
 
 // insts / meshes describe the n_edits edited instances (their NEW transforms), edit_items their TLAS leaf items; n_nodes / n_items: the TLAS's nodes and leaf items
 bool bvh_refit_tlas(BuildScratch* scratch, hipStream_t s, const TlasInst* insts, const TlasMesh* meshes, uint32_t nmeshes, const uint32_t* edit_items, uint32_t n_edits,
-                    Node8* nodes, uint32_t node_begin, uint32_t n_nodes, uint32_t item_begin, uint32_t n_items, const uint2* node_parent, const uint2* item_parent) {
+                    Node8* nodes, uint32_t node_begin, uint32_t n_nodes, uint32_t item_begin, uint32_t n_items, const uint2* node_parent, const uint2* item_parent,
+                    const uint32_t* edit_ids /* the edited instances, in the order of insts */, float4* spheres /* per instance */) {
     if (n_edits == 0) return true;
     // one buffer of the scratch, carved (256-B aligned pieces) and grown on demand
     auto up = [](size_t b) { return (b + 255) & ~(size_t)255; };
     const size_t zeroed = ((size_t)3 * n_nodes + n_items) * 4, state_bytes = zeroed + ((size_t)n_nodes + n_items) * sizeof(Box);
     const size_t o_inst = 0, o_boxes = o_inst + up((size_t)n_edits * sizeof(TlasInst)), o_mesh = o_boxes + up((size_t)n_edits * sizeof(Box)),
-                 o_items = o_mesh + up((size_t)std::max(nmeshes, 1u) * sizeof(TlasMesh)), o_state = o_items + up((size_t)n_edits * 4), total = o_state + up(state_bytes);
+                 o_items = o_mesh + up((size_t)std::max(nmeshes, 1u) * sizeof(TlasMesh)), o_ids = o_items + up((size_t)n_edits * 4), o_state = o_ids + up((size_t)n_edits * 4), total = o_state + up(state_bytes);
     if (total > scratch->refit_bytes) {
         if (scratch->refit) (void)hipFree(scratch->refit);
         scratch->refit = nullptr; scratch->refit_bytes = 0;
@@ -1251,6 +1281,7 @@ bool bvh_refit_tlas(BuildScratch* scratch, hipStream_t s, const TlasInst* insts,
     }
     char* const base = (char*)scratch->refit;
     TlasInst* dinst = (TlasInst*)(base + o_inst); Box* dboxes = (Box*)(base + o_boxes); TlasMesh* dmesh = (TlasMesh*)(base + o_mesh); uint32_t* ditems = (uint32_t*)(base + o_items);
+    uint32_t* dids = (uint32_t*)(base + o_ids);
     char* state = base + o_state;
     HIPCHK(hipMemsetAsync(state, 0, zeroed, s));
     RefitState R;
@@ -1259,7 +1290,8 @@ bool bvh_refit_tlas(BuildScratch* scratch, hipStream_t s, const TlasInst* insts,
     HIPCHK(hipMemcpyAsync(dinst, insts, (size_t)n_edits * sizeof(TlasInst), hipMemcpyHostToDevice, s));
     if (nmeshes) HIPCHK(hipMemcpyAsync(dmesh, meshes, (size_t)nmeshes * sizeof(TlasMesh), hipMemcpyHostToDevice, s));
     HIPCHK(hipMemcpyAsync(ditems, edit_items, (size_t)n_edits * 4, hipMemcpyHostToDevice, s));
-    hipLaunchKernelGGL(k_instance_boxes, dim3(n_edits), dim3(256), 0, s, dinst, dmesh, n_edits, dboxes);
+    HIPCHK(hipMemcpyAsync(dids, edit_ids, (size_t)n_edits * 4, hipMemcpyHostToDevice, s));
+    hipLaunchKernelGGL(k_instance_boxes, dim3(n_edits), dim3(256), 0, s, dinst, dmesh, n_edits, dboxes, dids, spheres);
     hipLaunchKernelGGL(k_tlas_refit_mark, dim3((n_edits + 63) / 64), dim3(64), 0, s, R, node_begin, item_begin, node_parent, item_parent, ditems, dboxes, n_edits);
     hipLaunchKernelGGL(k_tlas_refit_apply, dim3((n_edits + 63) / 64), dim3(64), 0, s, nodes, R, node_begin, item_begin, node_parent, item_parent, ditems, n_edits);
     HIPCHK(hipStreamSynchronize(s));

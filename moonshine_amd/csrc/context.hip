@@ -45,12 +45,12 @@ size_t bvh_scratch_capacity(const BuildScratch*);
 bool bvh_build_blas_batch(BuildScratch*, hipStream_t, const std::vector<BlasGeo>&, const std::vector<uint32_t>&, Node8*, uint32_t*, uint32_t, TriRec*, TriRot*, TriAttr*, uint32_t*, uint32_t*, uint32_t*, float*);
 struct TlasInst { float T[12]; float blas_box[6]; uint32_t mesh_begin, mesh_end, exact, pad; };
 struct TlasMesh { const float* positions; uint32_t count, pad; };
-bool bvh_build_tlas(BuildScratch*, hipStream_t, const TlasInst*, const uint32_t*, uint32_t, const TlasMesh*, uint32_t, Node8*, uint32_t*, uint32_t, uint32_t*, uint32_t*, uint32_t*, uint32_t*);
+bool bvh_build_tlas(BuildScratch*, hipStream_t, const TlasInst*, const uint32_t*, uint32_t, const TlasMesh*, uint32_t, Node8*, uint32_t*, uint32_t, uint32_t*, uint32_t*, uint32_t*, uint32_t*, float4*);
 void bvh_tlas_links(hipStream_t, const Node8*, uint32_t node_begin, uint32_t node_end, uint32_t item_begin, uint2* node_parent, uint2* item_parent, uint32_t root);
-void bvh_tlas_leaves(hipStream_t, const uint32_t* items, const InstanceRec* instances, uint32_t n, TlasLeaf* out);
+void bvh_tlas_leaves(hipStream_t, const uint32_t* items, const InstanceRec* instances, const float4* spheres, uint32_t n, TlasLeaf* out);
 void bvh_scratch_release_arena(BuildScratch*);
 size_t bvh_scratch_arena_bytes(const BuildScratch*);
-bool bvh_refit_tlas(BuildScratch*, hipStream_t, const TlasInst*, const TlasMesh*, uint32_t, const uint32_t* edit_items, uint32_t n_edits, Node8*, uint32_t node_begin, uint32_t n_nodes, uint32_t item_begin, uint32_t n_items, const uint2*, const uint2*);
+bool bvh_refit_tlas(BuildScratch*, hipStream_t, const TlasInst*, const TlasMesh*, uint32_t, const uint32_t* edit_items, uint32_t n_edits, Node8*, uint32_t node_begin, uint32_t n_nodes, uint32_t item_begin, uint32_t n_items, const uint2*, const uint2*, const uint32_t* edit_ids, float4* spheres);
 }  // namespace msne
 
 using namespace msne;
@@ -132,7 +132,7 @@ struct HdMoonshine {
     DevBuf<InstanceRec> d_instances;
     DevBuf<AliasEntry> d_alias;
     DevBuf<LightTri> d_light_tris; bool lights_dirty = true; uint32_t lights_indexed = 0;   // gathered light triangles (rebuilt with the alias table / attribute mode)
-    DevBuf<Node8> d_nodes; DevBuf<TriRec> d_tris; DevBuf<TriRot> d_tri_rot; DevBuf<TriAttr> d_tri_attrs; DevBuf<uint32_t> d_tlas_items, d_item_src; DevBuf<TlasLeaf> d_tlas_leaves;
+    DevBuf<Node8> d_nodes; DevBuf<TriRec> d_tris; DevBuf<TriRot> d_tri_rot; DevBuf<TriAttr> d_tri_attrs; DevBuf<uint32_t> d_tlas_items, d_item_src; DevBuf<TlasLeaf> d_tlas_leaves; DevBuf<float4> d_inst_spheres;   // per instance (+ the world pseudo-instance): world-space bounding sphere
     bool blas_indexed = true;                             // the attribute mode the TriAttr records of the cached BLASes were gathered with
     DevBuf<uint32_t> d_build_counters;    // [0] node count, [1] tri count, [2] tlas item count
     uint32_t blas_nodes_end = 0, blas_tris_end = 0;
@@ -435,7 +435,7 @@ bool HdMoonshine::rebuild_accel() {
         CHECK_HIP(this, hipStreamSynchronize(stream));
         std::swap(nn.p, d_nodes.p); std::swap(nn.n, d_nodes.n);
     }
-    if (!d_item_src.ensure(std::max(d_tris.n, N + 2)) || !d_tlas_items.ensure(N + 2) || !d_tlas_leaves.ensure(N + 2)) { fail("out of device memory (items)"); return false; }
+    if (!d_item_src.ensure(std::max(d_tris.n, N + 2)) || !d_tlas_items.ensure(N + 2) || !d_tlas_leaves.ensure(N + 2) || !d_inst_spheres.ensure(N + 2)) { fail("out of device memory (items)"); return false; }
     // counters: node count resumes after the BLAS region (the previous TLAS is discarded)
     { uint32_t c[4] = { blas_nodes_end, blas_tris_end, 0u, 0u }; CHECK_HIP(this, hipMemcpyAsync(d_build_counters.p, c, 16, hipMemcpyHostToDevice, stream)); CHECK_HIP(this, hipStreamSynchronize(stream)); }
     lap("pools");
@@ -521,7 +521,7 @@ bool HdMoonshine::rebuild_accel() {
     if (ids.size() == 1 && ids[0] == (uint32_t)N) {
         tlas_root = irec[N].blas_root; root_in_blas = 1;     // nothing but static geometry: traversal starts inside the world BLAS
         const uint32_t zero = 0; CHECK_HIP(this, hipMemcpyAsync(d_build_counters.p + 2, &zero, 4, hipMemcpyHostToDevice, stream));
-    } else if (!bvh_build_tlas(build_scratch, stream, tinst.data(), ids.data(), (uint32_t)ids.size(), tmesh.data(), (uint32_t)tmesh.size(), d_nodes.p, d_build_counters.p, (uint32_t)d_nodes.n, d_tlas_items.p, d_build_counters.p + 2, d_item_src.p, &tlas_root)) { fail("TLAS build failed (details on stderr)"); return false; }
+    } else if (!bvh_build_tlas(build_scratch, stream, tinst.data(), ids.data(), (uint32_t)ids.size(), tmesh.data(), (uint32_t)tmesh.size(), d_nodes.p, d_build_counters.p, (uint32_t)d_nodes.n, d_tlas_items.p, d_build_counters.p + 2, d_item_src.p, &tlas_root, d_inst_spheres.p)) { fail("TLAS build failed (details on stderr)"); return false; }
 
     // what an in-place update of this TLAS needs later: parent links of its nodes and leaf items, the leaf item of every instance, the records as uploaded
     h_irec = irec; built_in_world = in_world; item_of_instance.assign(N + 1, MAX_UINT);
@@ -535,7 +535,7 @@ bool HdMoonshine::rebuild_accel() {
         for (size_t it = 0; it < h_items.size(); it++) if (h_items[it] <= N) item_of_instance[h_items[it]] = (uint32_t)it;
         if (!d_tlas_node_parent.ensure(tlas_node_end - tlas_node_begin + 1) || !d_tlas_item_parent.ensure(ids.size() + 1)) { fail("out of device memory (TLAS links)"); return false; }
         bvh_tlas_links(stream, d_nodes.p, tlas_node_begin, tlas_node_end, tlas_item_begin, d_tlas_node_parent.p, d_tlas_item_parent.p, tlas_root);
-        bvh_tlas_leaves(stream, d_tlas_items.p, d_instances.p, (uint32_t)ids.size(), d_tlas_leaves.p);
+        bvh_tlas_leaves(stream, d_tlas_items.p, d_instances.p, d_inst_spheres.p, (uint32_t)ids.size(), d_tlas_leaves.p);
         n_tlas_items = (uint32_t)ids.size();
     }
     if (timing) (void)hipStreamSynchronize(stream);
@@ -601,8 +601,8 @@ bool HdMoonshine::refit_tlas() {
     if (transform_edits.size() > 64) CHECK_HIP(this, hipMemcpyAsync(d_instances.p, h_irec.data(), h_irec.size() * sizeof(InstanceRec), hipMemcpyHostToDevice, stream));   // many edits: the whole table in one copy
     if (!build_scratch && !(build_scratch = bvh_scratch_create())) { fail("out of host memory"); return false; }
     if (!bvh_refit_tlas(build_scratch, stream, tinst.data(), tmesh.data(), (uint32_t)tmesh.size(), items.data(), (uint32_t)items.size(), d_nodes.p, tlas_node_begin, tlas_node_end - tlas_node_begin, tlas_item_begin, n_tlas_items,
-                        d_tlas_node_parent.p, d_tlas_item_parent.p)) return false;
-    bvh_tlas_leaves(stream, d_tlas_items.p, d_instances.p, n_tlas_items, d_tlas_leaves.p);   // (the edited instances' matrices; all of them rewritten: microseconds)
+                        d_tlas_node_parent.p, d_tlas_item_parent.p, transform_edits.data(), d_inst_spheres.p)) return false;
+    bvh_tlas_leaves(stream, d_tlas_items.p, d_instances.p, d_inst_spheres.p, n_tlas_items, d_tlas_leaves.p);   // (the edited instances' matrices; all of them rewritten: microseconds)
     transform_edits.clear(); n_tlas_updates++; refits_since_rebuild++;
     return true;
 }

@@ -518,14 +518,25 @@ __device__ __forceinline__ void trace_wave_loop(const SceneView& sc, uint32_t n,
         if (STATS && do_s) cyc[2] += __popcll(ms);   // lanes that change space (slot 2 of the profile: the vote itself is timed with the node section)
         if (INSTANCED && do_s && want_s) {   // entering an instance (leaving needs no body: the world-space half of the lane's ray was put aside)
             const uint32_t item = group_take(L, S, lut);   // TLAS leaf (one instance of the group; the rest of the group goes back on the stack)
-            // the leaf's own 64-B record (matrix, BLAS root, instance) and the ray's direction: five independent loads, one round trip
+            // the leaf's own 80-B record (matrix, BLAS root, instance, bounding sphere) and the ray's direction: six independent loads, one round trip
             const float4* mp = reinterpret_cast<const float4*>(sc.tlas_leaves + item);
-            const float4 r0 = mp[0], r1 = mp[1], r2 = mp[2];
+            const float4 r0 = mp[0], r1 = mp[1], r2 = mp[2], sph = mp[4];
             const uint4 lw = reinterpret_cast<const uint4*>(mp)[3];
-            const uint32_t root = lw.x, new_inst = lw.y, flags = lw.z;
+            const uint32_t new_inst = lw.y, flags = lw.z;
+            uint32_t root = lw.x;
+            f3 o = L.o, d = load_dir(my);   // at TLAS level the lane's origin IS the world-space one; the world-space direction is not kept in registers
+            {   // The instance's world-space bounding sphere (msne_device.h TlasLeaf), before the change of space and the visit of the BLAS root are paid for: a ray whose
+                // line misses the sphere, or that starts outside it and points away, cannot meet any of the instance's triangles.  Only ever a cull: the sphere is taken
+                // 0.2 % larger than the farthest vertex, plus four times the absolute slack the tmax cull uses (the rounding of centre - origin is an absolute error of the
+                // size of the coordinates, not of the radius), and the discriminant gets a tolerance ten times its rounding error: a near miss is an entry.
+                const f3 oc = F3(sph.x - o.x, sph.y - o.y, sph.z - o.z);
+                const float rr = __builtin_fmaf(sph.w, 1.002f, 4.0f * __builtin_fmaf(fmaxf(fmaxf(absf(o.x), absf(o.y)), absf(o.z)), 1.5e-6f, sc.coord_slack));
+                const float oc2 = dot(oc, oc), dd = dot(d, d), b = dot(oc, d), r2s = rr * rr;
+                const float disc = b * b - dd * (oc2 - r2s);
+                if (oc2 > r2s && (b <= 0.0f || disc < -1e-5f * (b * b + dd * oc2))) root = MAX_UINT;
+            }
             if (root != MAX_UINT) {
                 const bool ident = (flags & INST_FLAG_IDENTITY) != 0u;
-                f3 o = L.o, d = load_dir(my);   // at TLAS level the lane's origin IS the world-space one; the world-space direction is not kept in registers
                 L.wo = L.o; L.wid = L.id; L.woct = L.octbase;
                 L.ret_sp = L.sp;   // (the rest of the instance group is already on the stack: group_take above)
                 if (!ident) {   // t is preserved: d is not renormalised.  (Identity: M·(o,1) = o and M·d = d exactly — only the shear constants are recomputed)
