@@ -14,6 +14,9 @@ had to share a GPU: host memory), "copy" (group members sharing a GPU: device-to
 Timed region: EXACTLY `steps` steps, bracketed by barrier + synchronize on both sides, max over ranks.  The region is
 repeated `--repeats` times (default 5, SURVEY.md §8(d): "median of >= 5 runs") on a cleared sensor; `value` is the median
 repeat, every repeat is listed in `repeat_values`.
+After the headline (N = 1, S1, constant environment): `other_configs` = the same K-step batch on BASELINE.json's other single-GPU configurations — S2 (configs[4]: 10.24 M
+instanced triangles) and S1 under the image environment — each in a context of its own, median of 3 (`--no-other-configs` skips them; never the headline `value`);
+`--sustain-seconds S`: the batch back to back for >= S seconds (`sustained`: rate per 1-s window, shader clock probed while it runs).
 """
 import argparse
 import json
@@ -40,6 +43,31 @@ def build_scene(ctx, a):
     if a.scene == "s2":
         return scenes.s2(ctx, extent=(a.width, a.height))
     return scenes.s1(ctx, extent=(a.width, a.height), env=a.env)
+
+
+def other_config(a, dev, scene, env):
+    """BASELINE.json's other single-GPU configuration(s) in the same record (never the headline `value`): the same K-step batch on another scene, median of 3 repeats,
+    in a context of its own after the headline measurement is over.  configs[4] = S2, the 10 M-triangle instanced traversal stress."""
+    b = argparse.Namespace(scene=scene, env=env, width=a.width, height=a.height, steps=a.steps)
+    c = api.Context(device=dev)
+    sensor, lens = build_scene(c, b)
+    c.set_pipeline(samples_per_run=1, max_bounces=8, env_samples_per_bounce=1, mesh_samples_per_bounce=1)
+    c.render(sensor, lens, launches=0, readback=False)
+    c.set_profiling(kernel_events=False, traversal_counters=False)
+    c.reserve(sensor, max(a.steps, a.warmup))
+    if a.warmup:
+        c.render(sensor, lens, launches=a.warmup, readback=False)
+    c.reset_stats()
+    ts = []
+    for _ in range(3):
+        c.clear_sensor(sensor); torch.cuda.synchronize()
+        t0 = time.perf_counter(); c.render(sensor, lens, launches=a.steps, readback=False); torch.cuda.synchronize()
+        ts.append(time.perf_counter() - t0)
+    st = c.stats(); dt = statistics.median(ts)
+    rays = (st["closest_rays"] + st["shadow_rays"]) / 3.0
+    c.close()
+    return {"workload": workload_name(b), "value": rays / dt / 1e6, "unit": "Mrays/s", "ms_per_step": dt / a.steps * 1e3, "steps": a.steps, "repeats": 3,
+            "msamples_per_s": st["samples"] / 3.0 / dt / 1e6}
 
 
 def cpu_baseline(a):
@@ -190,6 +218,7 @@ def main():
     ap.add_argument("--scene", default="s1", choices=["s1", "s2"])
     ap.add_argument("--env", default="constant", choices=["constant", "sky"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-other-configs", action="store_true", help="skip the secondary single-GPU configurations (S2, S1 under the sky) reported next to the headline")
     ap.add_argument("--sustain-seconds", type=float, default=0.0,
                     help="after the timed repeats: back-to-back K-step batches for at least this long, reported as `sustained` (rate per 1-s window, shader clock at both ends); 0 = off")
     ap.add_argument("--dump-film", default=None, help="rank 0 saves the assembled film of the last repeat here (.npy): parity tests of the gather path")
@@ -437,6 +466,9 @@ def main():
         }
         if sustained is not None:
             out["sustained"] = sustained     # this rank's batches (at N > 1 every rank runs the same loop, gather included)
+        if world == 1 and a.scene == "s1" and a.env == "constant" and not a.no_other_configs:
+            # the other single-GPU configurations of BASELINE.json, measured after the headline (a second or two): configs[4] (S2) and S1 under the image environment
+            out["other_configs"] = {"s2": other_config(a, dev, "s2", "constant"), "s1_sky": other_config(a, dev, "s1", "sky")}
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(a)
         print(json.dumps(out))
