@@ -87,8 +87,10 @@ if __name__ == "__main__":
         c.set_profiling(True, True)
         c.render(s, l, launches=spp, readback=False)
         stt = c.stats(); t = c.traversal_counters(); u = c.traversal_lane_use()
-        cfile = os.path.join(ROOT, "profiles", "r04_counters_%s.json" % {"s1": "s1", "sky": "s1_sky", "s2": "s2"}[name])   # SQ_INSTS_VALU per ray of the same kernels (round 4's PMC pass)
-        measured = json.load(open(cfile))["kernels"] if os.path.exists(cfile) else {}
+        import glob
+        cfiles = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_counters_%s.json" % {"s1": "s1", "sky": "s1_sky", "s2": "s2"}[name])))   # SQ_INSTS_VALU per ray of the same kernels: the newest committed PMC pass
+        cfile = cfiles[-1] if cfiles else ""
+        measured = json.load(open(cfile))["kernels"] if cfile and os.path.exists(cfile) else {}
         for k, rays, nv, nt in (("closest", stt["closest_rays"], t["closest_node_visits"], t["closest_tri_tests"]), ("shadow", stt["shadow_rays"], t["shadow_node_visits"], t["shadow_tri_tests"])):
             x = u[k]; it = max(x["iterations"], 1); prof = t[k + "_profile"]
             body = st["k_trace_%s%s" % (k, "_instanced" if name == "s2" else "")]
