@@ -241,6 +241,9 @@ __device__ __forceinline__ void step_node(Lane& L, const SceneView& sc, const St
         miss8 = __builtin_amdgcn_alignbit(miss8, f2u(__builtin_fmaf(f, 1.00001f, -n)), 31);   // (miss8 << 1) | sign
     }
     const uint32_t hits8 = ~miss8 & 0xffu;
+#if defined(TRACE_COUNT_EMPTY)   // measurement: node visits none of whose children the ray hits — all of them (1) or those made with a hit already found (2) — in the upper half of the visit counter
+    if (STATS && !(hits8 & (w0.w >> 24 | (w1.z & 0xffu))) && (TRACE_COUNT_EMPTY == 1 || (!ANY_HIT && L.best.inst != MAX_UINT))) nv += (1ull << 32);
+#endif
     // empty slots (inverted boxes) can pass the slack test when the node is tiny against its distance: imask / lmask drop them
     const uint32_t lmask = w1.z & 0xffu;
     const uint32_t ihits = hits8 & imask, lhits = hits8 & lmask;
