@@ -1013,7 +1013,7 @@ bool bvh_build_blas_batch(BuildScratch* scratch, hipStream_t s, const std::vecto
 // A TLAS leaf is the world box of the instance's TRANSFORMED VERTICES, not of the transformed corners of its BLAS root box (up to 1.7x
 // wider per axis under rotation; every false TLAS hit costs a change of space in the traversal).  One workgroup per instance reduces
 // min / max over the vertices of its meshes; an instance without a finite vertex, or flagged `exact = 0`, takes the corner box.
-struct TlasInst { float T[12]; float blas_box[6]; uint32_t mesh_begin, mesh_end, exact, pad; };   // mesh_begin..mesh_end index TlasMesh
+struct TlasInst { float T[12]; float blas_box[6]; uint32_t mesh_begin, mesh_end, exact; float cull_pad; /* context.hip instance_cull_pad */ };   // mesh_begin..mesh_end index TlasMesh
 struct TlasMesh { const float* positions; uint32_t count, pad; };
 
 // One workgroup per instance: the box of its transformed vertices (the TLAS leaf box) and — sphere_ids != nullptr — its world-space bounding sphere into
@@ -1069,14 +1069,19 @@ __global__ __launch_bounds__(256) void k_instance_boxes(const TlasInst* insts, c
         if (threadIdx.x == 0) {
             for (int w = 0; w < 256 / 64; w++) r2 = fmaxf(r2, s_r2[w]);
             if (!(r2 >= 0.0f) || !(r2 < 3e38f) || !(c.x == c.x && c.y == c.y && c.z == c.z)) r2 = 3e38f;   // (not finite: a sphere nothing is outside of)
-            spheres[sphere_ids[i]] = make_float4(c.x, c.y, c.z, r2 < 1e37f ? sqrtf(r2) : 1e18f);   // (radius; 1e18: its square is still finite)
+            const float rad = r2 < 1e37f ? sqrtf(r2) * 1.000001f + 1.7320509f * in.cull_pad : 1e18f;   // (the slack is a bound per coordinate: sqrt 3 of it along a diagonal)
+            spheres[sphere_ids[i]] = make_float4(c.x, c.y, c.z, rad < 1e18f ? rad : 1e18f);   // (radius; 1e18: its square is still finite)
         }
     }
     if (threadIdx.x != 0) return;
-    float pad = 1e-30f;
-    for (int k = 0; k < 3; k++) pad += 1e-6f * (fabsf(hi[k] - lo[k]) + fabsf(hi[k]) + fabsf(lo[k]));
+    // grown by what the world-space ray and the instance-space hit can differ by (context.hip instance_cull_pad), and by an ulp for the rounding of this very sum
     Box b;
-    for (int k = 0; k < 3; k++) { b.lo[k] = lo[k] - pad; b.hi[k] = hi[k] + pad; }
+    for (int k = 0; k < 3; k++) {
+        b.lo[k] = lo[k] - in.cull_pad; b.hi[k] = hi[k] + in.cull_pad;
+        b.lo[k] -= 1.2e-7f * fabsf(b.lo[k]) + 1e-30f; b.hi[k] += 1.2e-7f * fabsf(b.hi[k]) + 1e-30f;
+        if (!(b.lo[k] > -3e38f)) b.lo[k] = -3e38f;
+        if (!(b.hi[k] < 3e38f)) b.hi[k] = 3e38f;
+    }
     boxes[i] = b;
 }
 

@@ -43,7 +43,7 @@ void bvh_scratch_destroy(BuildScratch*);
 void bvh_scratch_release(BuildScratch*);
 size_t bvh_scratch_capacity(const BuildScratch*);
 bool bvh_build_blas_batch(BuildScratch*, hipStream_t, const std::vector<BlasGeo>&, const std::vector<uint32_t>&, Node8*, uint32_t*, uint32_t, TriRec*, TriRot*, TriAttr*, uint32_t*, uint32_t*, uint32_t*, float*);
-struct TlasInst { float T[12]; float blas_box[6]; uint32_t mesh_begin, mesh_end, exact, pad; };
+struct TlasInst { float T[12]; float blas_box[6]; uint32_t mesh_begin, mesh_end, exact; float cull_pad; };   // (bvh_build.hip)
 struct TlasMesh { const float* positions; uint32_t count, pad; };
 bool bvh_build_tlas(BuildScratch*, hipStream_t, const TlasInst*, const uint32_t*, uint32_t, const TlasMesh*, uint32_t, Node8*, uint32_t*, uint32_t, uint32_t*, uint32_t*, uint32_t*, uint32_t*, float4*);
 void bvh_tlas_links(hipStream_t, const Node8*, uint32_t node_begin, uint32_t node_end, uint32_t item_begin, uint2* node_parent, uint2* item_parent, uint32_t root);
@@ -337,6 +337,38 @@ static float coord_reach(const m34& T, const float box[6]) {
     return r < 3.0e38f ? r : 3.0e38f;   // (NaN or infinite: no culling against the best hit at all)
 }
 
+// How far a world-space ray can pass from an instance's world-space vertices and still hit one of its triangles: the hit is decided in instance space on
+// fl(W o + w) + s fl(W d) — W, w the ROUNDED inverse (m34_inverse_affine, f32) — and T (W p + w) + t is not p.  For a point p of the ray and its twin q in instance space
+//     |T q + t - p| <= |T W - I| |p| + |T w + t| + |T| g (|W| (2 |o| + |p|) + |w|),        g = four roundings of a dot product, doubled,
+// plus g (|T| |v| + |t|) for the rounding of the transformed vertices themselves; with |p| <= the instance's reach (+ the slack) and |o| <= origin_reach, in double.
+// Every world-space volume an instance is culled by (its TLAS leaf box and, through it, the boxes above; its bounding sphere) is grown by this much
+// (bvh_build.hip k_instance_boxes).  Well-conditioned transforms: a few ulps of the coordinates.  A shear between scales 1e6 apart, or an instance a few ulps of its own
+// coordinates wide: as large as the instance — nothing is culled there, which is the contract (the oracle's search without boxes, tests/test_oracle.py).  Ray origins
+// farther out than origin_reach (16 x the scene's largest coordinate) are outside what is baked: DESIGN.md section 2.
+static float instance_cull_pad(const m34& T, const float box[6], float origin_reach) {
+    if (is_identity(T)) return 0.0f;   // (the traversal does not transform at all: trace.hip `ident`)
+    const m34 W = m34_inverse_affine(T);
+    const double g = 8.0 / 16777216.0;
+    double reach = 0.0, fixed = 0.0, resid = 0.0, ampl = 0.0;
+    for (int i = 0; i < 3; i++) {
+        double r_row = 0.0, a_row = 0.0, tau = T.m[i][3], w_row = 0.0, world = fabs((double)T.m[i][3]);
+        for (int j = 0; j < 3; j++) {
+            double r = i == j ? -1.0 : 0.0, a = 0.0;
+            for (int k = 0; k < 3; k++) { r += (double)T.m[i][k] * W.m[k][j]; a += fabs((double)T.m[i][k]) * fabs((double)W.m[k][j]); }
+            r_row += fabs(r); a_row += a;
+            tau += (double)T.m[i][j] * W.m[j][3]; w_row += fabs((double)T.m[i][j]) * fabs((double)W.m[j][3]);
+            world += fabs((double)T.m[i][j]) * std::max(fabs((double)box[j]), fabs((double)box[j + 3]));
+        }
+        reach = std::max(reach, world); resid = std::max(resid, r_row); ampl = std::max(ampl, a_row);
+        fixed = std::max(fixed, fabs(tau) + g * w_row + g * world);
+    }
+    fixed += 2.0 * g * ampl * (double)origin_reach;
+    double e = fixed + (resid + g * ampl) * reach;
+    e = fixed + (resid + g * ampl) * (reach + e);
+    e = 1.5 * (fixed + (resid + g * ampl) * (reach + e));
+    return (e == e && e < 1e37) ? (float)e * 1.000001f : 3.0e38f;   // (not finite: boxes and a sphere that nothing misses)
+}
+
 bool HdMoonshine::rebuild_accel() {
     // $MSNE_BUILD_TIMING: host wall time of the phases of a rebuild on stderr
     static const bool timing = getenv("MSNE_BUILD_TIMING") != nullptr;
@@ -514,6 +546,7 @@ bool HdMoonshine::rebuild_accel() {
             add_box(ident, bi.box, (uint32_t)N, nullptr);
         }
     }
+    for (TlasInst& t : tinst) { m34 T; memcpy(&T, t.T, 48); t.cull_pad = instance_cull_pad(T, t.blas_box, 16.0f * coord_radius); }
     lap("instance records");
     if (!d_instances.alloc(irec.size())) { fail("out of device memory (instances)"); return false; }
     CHECK_HIP(this, hipMemcpyAsync(d_instances.p, irec.data(), irec.size() * sizeof(InstanceRec), hipMemcpyHostToDevice, stream));
@@ -598,6 +631,7 @@ bool HdMoonshine::refit_tlas() {
         tinst.push_back(t); items.push_back(item_of_instance[h]);
         coord_radius = std::max(coord_radius, coord_reach(instances[h].transform, bi->second.box));
     }
+    for (TlasInst& t : tinst) { m34 T; memcpy(&T, t.T, 48); t.cull_pad = instance_cull_pad(T, t.blas_box, 16.0f * coord_radius); }
     if (transform_edits.size() > 64) CHECK_HIP(this, hipMemcpyAsync(d_instances.p, h_irec.data(), h_irec.size() * sizeof(InstanceRec), hipMemcpyHostToDevice, stream));   // many edits: the whole table in one copy
     if (!build_scratch && !(build_scratch = bvh_scratch_create())) { fail("out of host memory"); return false; }
     if (!bvh_refit_tlas(build_scratch, stream, tinst.data(), tmesh.data(), (uint32_t)tmesh.size(), items.data(), (uint32_t)items.size(), d_nodes.p, tlas_node_begin, tlas_node_end - tlas_node_begin, tlas_item_begin, n_tlas_items,

@@ -211,7 +211,9 @@ __device__ __forceinline__ void step_node(Lane& L, const SceneView& sc, const St
     const float nox = u2f(w0.x), noy = u2f(w0.y), noz = u2f(w0.z);
     const uint32_t ex = w0.w & 0xff, ey = (w0.w >> 8) & 0xff, ez = (w0.w >> 16) & 0xff, imask = w0.w >> 24;
     const float ax = u2f(ex << 23) * L.id.x, ay = u2f(ey << 23) * L.id.y, az = u2f(ez << 23) * L.id.z;
-    const float bx = (nox - L.o.x) * L.id.x, by = (noy - L.o.y) * L.id.y, bz = (noz - L.o.z) * L.id.z;
+    // (+0 through the SAME instruction: the hit bit below is a sign bit, and a ray that starts exactly in the plane of a flat box against its direction has a plane
+    // distance of 0 * negative = -0, whose sign would read as a miss — the oracle's `tf >= 0` takes it: tests/test_gpu_parity.py::test_rays_at_the_hulls_..., seed 14)
+    const float bx = __builtin_fmaf(nox - L.o.x, L.id.x, 0.0f), by = __builtin_fmaf(noy - L.o.y, L.id.y, 0.0f), bz = __builtin_fmaf(noz - L.o.z, L.id.z, 0.0f);
     // byte planes: qlo[0] = w2.xy, qlo[1] = w2.zw, qlo[2] = w3.xy, qhi[0] = w3.zw, qhi[1] = w4.xy, qhi[2] = w4.zw.
     // a = scale * id has the sign of id, so the entry plane of an axis is qlo when id >= 0 and qhi otherwise
     // (the choice made by ADDRESS instead — a 128-B node on a 128-B boundary with every axis' planes as {lo, hi, lo}, three 16-B loads at offset 0 or 8 by the ray's
@@ -536,7 +538,9 @@ __device__ __forceinline__ void trace_wave_loop(const SceneView& sc, uint32_t n,
                 const float rr = __builtin_fmaf(sph.w, 1.002f, 4.0f * __builtin_fmaf(fmaxf(fmaxf(absf(o.x), absf(o.y)), absf(o.z)), 1.5e-6f, sc.coord_slack));
                 const float oc2 = dot(oc, oc), dd = dot(d, d), b = dot(oc, d), r2s = rr * rr;
                 const float disc = b * b - dd * (oc2 - r2s);
+#if !defined(TRACE_NO_SPHERE_CULL)
                 if (oc2 > r2s && (b <= 0.0f || disc < -1e-5f * (b * b + dd * oc2))) root = MAX_UINT;
+#endif
             }
             if (root != MAX_UINT) {
                 const bool ident = (flags & INST_FLAG_IDENTITY) != 0u;

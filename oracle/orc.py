@@ -95,6 +95,7 @@ def lib():
         L.OrcSetInstanceTransform.argtypes = [vp, u32, Mat3x4]
         L.OrcSetInstanceVisibility.argtypes = [vp, u32, C.c_bool]
         L.OrcSetGeometryMaterial.restype = C.c_int; L.OrcSetGeometryMaterial.argtypes = [vp, u32, u32, u32]
+        L.OrcSetExhaustiveSearch.restype = None; L.OrcSetExhaustiveSearch.argtypes = [vp, C.c_int]
         L.OrcSetPipeline.argtypes = [vp, C.POINTER(MsnePipelineOpts)]
         L.OrcSetBackground.argtypes = [vp, vp, Extent2D]
         L.OrcCreateSensor.restype = i64; L.OrcCreateSensor.argtypes = [vp, Extent2D]
@@ -206,6 +207,10 @@ class Context:
 
     def set_instance_visibility(self, h, v):
         self.L.OrcSetInstanceVisibility(self.h, h, v)
+
+    def set_exhaustive_search(self, level):
+        """0: the instances' and the triangles' boxes cull (what every other test runs); 1: every visible instance is entered; 2: and every one of its triangles tested"""
+        self.L.OrcSetExhaustiveSearch(self.h, int(level))
 
     def set_geometry_material(self, instance, geometry_index, material):
         if self.L.OrcSetGeometryMaterial(self.h, instance, geometry_index, material) != 0:

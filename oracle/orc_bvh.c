@@ -161,22 +161,53 @@ void orc_build_blas(OrcContext *c, orc_bvh *out, const uint32_t *mesh_ids, uint3
     free(order); free(tris); free(boxes);
 }
 
+/* How far (largest world-space coordinate difference) the world-space ray can pass from an instance's triangles and still hit one of them in instance space.
+ * The hit is decided on fl(W o + w) + s fl(W d) (W, w: the rounded inverse that world_to_instance holds), the culling on o + s d, and T (W p + w) + t is not p:
+ *     |T q + t - p| <= |T W - I| |p| + |T w + t| + |T| g (|W| (2 |o| + |p|) + |w|)          (g: four roundings of a dot product, doubled)
+ * for a point p of the ray and its instance-space twin q; the transformed corners of the root box carry g (|T| |v| + |t|) themselves.  Everything that does not
+ * depend on the ray goes into the instance's box (e0, with |p| <= the instance's reach + e0); the |o| term is per ray: far_ * max|o_a| (scene_traverse).
+ * An ill-conditioned transform (shear between scales 1e6 apart) or an instance a few ulps of its own coordinates wide makes these as large as the instance itself:
+ * then nothing is culled, which is the contract (OrcSetExhaustiveSearch is the same search with no boxes at all; tests hold the two against each other). */
+typedef struct { float e0, far_; } inst_slack;
+static inst_slack instance_cull_slack(const m34 *T, const m34 *W, v3 lo, v3 hi) {
+    const double g = 8.0 / 16777216.0;
+    const double a[3] = { fmax(fabs((double)lo.x), fabs((double)hi.x)), fmax(fabs((double)lo.y), fabs((double)hi.y)), fmax(fabs((double)lo.z), fabs((double)hi.z)) };
+    double reach = 0.0, e_fix = 0.0, r_row = 0.0, a_row = 0.0;
+    for (int i = 0; i < 3; i++) {
+        double rr = 0.0, ar = 0.0, tau = (double)T->m[i][3], b = 0.0, world = fabs((double)T->m[i][3]);
+        for (int j = 0; j < 3; j++) {
+            double r = (i == j) ? -1.0 : 0.0, aa = 0.0;
+            for (int k = 0; k < 3; k++) { r += (double)T->m[i][k] * (double)W->m[k][j]; aa += fabs((double)T->m[i][k]) * fabs((double)W->m[k][j]); }
+            rr += fabs(r); ar += aa;
+            tau += (double)T->m[i][j] * (double)W->m[j][3]; b += fabs((double)T->m[i][j]) * fabs((double)W->m[j][3]);
+            world += fabs((double)T->m[i][j]) * a[j];
+        }
+        reach = fmax(reach, world);
+        e_fix = fmax(e_fix, fabs(tau) + g * b + g * world);
+        r_row = fmax(r_row, rr); a_row = fmax(a_row, ar);
+    }
+    double e0 = e_fix + (r_row + g * a_row) * reach;
+    e0 = e_fix + (r_row + g * a_row) * (reach + e0);
+    e0 = 1.5 * (e_fix + (r_row + g * a_row) * (reach + e0));
+    inst_slack s;
+    s.e0 = (e0 == e0 && e0 < 1e37) ? (float)e0 * 1.000001f : 3.0e38f;
+    const double f = 1.5 * 2.0 * g * a_row;
+    s.far_ = (f == f && f < 1e37) ? (float)f * 1.000001f : 3.0e38f;
+    return s;
+}
+
 static aabb transform_aabb(const m34 *m, v3 lo, v3 hi) {
     aabb b = aabb_empty();
     for (int i = 0; i < 8; i++) {
         v3 p = V3((i & 1) ? hi.x : lo.x, (i & 2) ? hi.y : lo.y, (i & 4) ? hi.z : lo.z);
         aabb_grow(&b, m34_mul_point(m, p));
     }
-    /* pad: the transform above rounds; keep the box conservative */
-    v3 e = v3sub(b.hi, b.lo); float pad = 1e-6f * (fabsf(e.x) + fabsf(e.y) + fabsf(e.z)) + 1e-30f;
-    pad += 1e-6f * (fabsf(b.hi.x) + fabsf(b.hi.y) + fabsf(b.hi.z) + fabsf(b.lo.x) + fabsf(b.lo.y) + fabsf(b.lo.z));
-    b.lo = v3sub(b.lo, V3(pad, pad, pad)); b.hi = v3add(b.hi, V3(pad, pad, pad));
     return b;
 }
 
 void orc_build_tlas(OrcContext *c) {
     orc_bvh_free(&c->tlas);
-    uint32_t n = 0;
+    uint32_t n = 0; float far_ = 0.0f;
     aabb *boxes = (aabb *)malloc(sizeof(aabb) * (c->instance_count ? c->instance_count : 1));
     uint32_t *ids = (uint32_t *)malloc(sizeof(uint32_t) * (c->instance_count ? c->instance_count : 1));
     for (uint32_t i = 0; i < c->instance_count; i++) {
@@ -185,11 +216,16 @@ void orc_build_tlas(OrcContext *c) {
         const orc_bvh *b = &c->blases[in->blas];
         if (b->tri_count == 0) continue;
         boxes[n] = transform_aabb(&in->transform, b->lo, b->hi);
+        const inst_slack sl = instance_cull_slack(&in->transform, &in->world_to_instance, b->lo, b->hi);
+        boxes[n].lo = v3sub(boxes[n].lo, V3(sl.e0, sl.e0, sl.e0)); boxes[n].hi = v3add(boxes[n].hi, V3(sl.e0, sl.e0, sl.e0));
+        if (!(boxes[n].lo.x > -3e38f)) boxes[n].lo = V3(-3e38f, -3e38f, -3e38f);   /* (a slack that is not finite: a box nothing misses) */
+        if (!(boxes[n].hi.x < 3e38f)) boxes[n].hi = V3(3e38f, 3e38f, 3e38f);
+        far_ = orc_maxf(far_, sl.far_);
         ids[n++] = i;
     }
     uint32_t *order = bvh_build_boxes(&c->tlas, boxes, n, 1);
     c->tlas.inst = (uint32_t *)malloc(sizeof(uint32_t) * (n ? n : 1));
-    c->tlas.inst_count = n;
+    c->tlas.inst_count = n; c->tlas.cull_far = far_;
     for (uint32_t i = 0; i < n; i++) c->tlas.inst[i] = ids[order[i]];
     free(order); free(boxes); free(ids);
 }
@@ -264,16 +300,17 @@ static inline orc_rayb rayb_make(v3 o, v3 id) {
 }
 /* All eight boxes of a node at once (the best hit does not change between the box tests of one visit): bit i of the result = box i is hit, tnear[i] its entry
  * distance.  Every box goes through the expressions above one by one — the loop only lets the compiler use vector registers for them. */
-static inline unsigned box_hit8(const orc_wnode *n, const orc_rayb *r, float tmax, float tnear[8]) {
+static inline unsigned box_hit8(const orc_wnode *n, const orc_rayb *r, float tmax, float pad /* every box grown by this much on every side (TLAS: instance_cull_slack's per-ray part) */, float tnear[8]) {
     const float ox = r->o.x, oy = r->o.y, oz = r->o.z, ix = r->id.x, iy = r->id.y, iz = r->id.z;
     const float fx = r->domx ? 1.0f : 0.0f, fy = r->domy ? 1.0f : 0.0f, fz = r->domz ? 1.0f : 0.0f;   /* the dominant axis has the smallest |1/d|; among equals the larger distance */
+    const float px = pad * fabsf(ix), py = pad * fabsf(iy), pz = pad * fabsf(iz);
     int ok[8];
     for (int i = 0; i < 8; i++) {
-        float t1 = (n->lo[0][i] - ox) * ix, t2 = (n->hi[0][i] - ox) * ix; const float mx = orc_maxf(fabsf(t1), fabsf(t2)); float e = 1e-5f * mx;
+        float t1 = (n->lo[0][i] - ox) * ix, t2 = (n->hi[0][i] - ox) * ix; const float mx = orc_maxf(fabsf(t1), fabsf(t2)); float e = 1e-5f * mx + px;
         float tn = orc_minf(t1, t2) - e, tf = orc_maxf(t1, t2) + e;
-        t1 = (n->lo[1][i] - oy) * iy; t2 = (n->hi[1][i] - oy) * iy; const float my = orc_maxf(fabsf(t1), fabsf(t2)); e = 1e-5f * my;
+        t1 = (n->lo[1][i] - oy) * iy; t2 = (n->hi[1][i] - oy) * iy; const float my = orc_maxf(fabsf(t1), fabsf(t2)); e = 1e-5f * my + py;
         tn = orc_maxf(tn, orc_minf(t1, t2) - e); tf = orc_minf(tf, orc_maxf(t1, t2) + e);
-        t1 = (n->lo[2][i] - oz) * iz; t2 = (n->hi[2][i] - oz) * iz; const float mz = orc_maxf(fabsf(t1), fabsf(t2)); e = 1e-5f * mz;
+        t1 = (n->lo[2][i] - oz) * iz; t2 = (n->hi[2][i] - oz) * iz; const float mz = orc_maxf(fabsf(t1), fabsf(t2)); e = 1e-5f * mz + pz;
         tn = orc_maxf(tn, orc_minf(t1, t2) - e); tf = orc_minf(tf, orc_maxf(t1, t2) + e);
         tnear[i] = tn;
         float far_ = 0.0f;   /* (m >= 0: max(0, m) = m for a dominant axis, and an axis that is not dominant contributes 0) */
@@ -298,7 +335,7 @@ static int blas_traverse(const orc_bvh *b, v3 o, v3 d, uint32_t inst, orc_hit *b
         const orc_wnode *n = &b->nodes[stack[--sp]];
         cnt->node_visits++; if (any_hit) cnt->shadow_node_visits++;
         float tn[8], tb[8]; int idx[8]; int nh = 0;
-        const unsigned hm = box_hit8(n, &rb, best->t, tb);
+        const unsigned hm = box_hit8(n, &rb, best->t, 0.0f, tb);
         for (int i = 0; i < n->nchild; i++) {
             const float t = tb[i];
             if (hm >> i & 1u) {
@@ -335,18 +372,50 @@ static int blas_traverse(const orc_bvh *b, v3 o, v3 d, uint32_t inst, orc_hit *b
     return found;
 }
 
+/* The contract itself, with no acceleration structure in the way (OrcSetExhaustiveSearch): every active triangle of the BLAS against the instance-space ray, the same
+ * watertight test, the same order of preference.  What the box culls above and below must never change — tests hold the culled search against this one. */
+static int blas_exhaustive(const orc_bvh *b, v3 o, v3 d, uint32_t inst, orc_hit *best, int any_hit, orc_counters *cnt) {
+    const orc_rayk rk = rayk_make(d);
+    int found = 0;
+    for (uint32_t q = 0; q < b->tri_count; q++) {
+        const orc_tri *tr = &b->tris[q];
+        float t, u, v;
+        cnt->tri_tests++; if (any_hit) cnt->shadow_tri_tests++;
+        if (!tri_intersect(o, &rk, tr, &t, &u, &v)) continue;
+        if (any_hit) { if (t < best->t) return 1; continue; }
+        int closer = t < best->t;
+        if (!closer && t == best->t && best->inst != ORC_MAX_UINT)
+            closer = inst < best->inst || (inst == best->inst && (tr->geo < best->geo || (tr->geo == best->geo && tr->prim < best->prim)));
+        if (closer) { best->t = t; best->u = u; best->v = v; best->inst = inst; best->geo = tr->geo; best->prim = tr->prim; found = 1; }
+    }
+    return found;
+}
+static int scene_exhaustive(const OrcContext *c, v3 o, v3 d, orc_hit *best, int any_hit, orc_counters *cnt) {
+    int found = 0;
+    for (uint32_t q = 0; q < c->tlas.inst_count; q++) {   /* the visible instances that have triangles (orc_build_tlas) */
+        const uint32_t ii = c->tlas.inst[q];
+        const orc_instance *in = &c->instances[ii];
+        const v3 oo = m34_mul_point(&in->world_to_instance, o), dd = m34_mul_vec(&in->world_to_instance, d);
+        const orc_bvh *b = &c->blases[in->blas];
+        if (c->exhaustive >= 2 ? blas_exhaustive(b, oo, dd, ii, best, any_hit, cnt) : blas_traverse(b, oo, dd, ii, best, any_hit, cnt)) { found = 1; if (any_hit) return 1; }
+    }
+    return found;
+}
+
 static int scene_traverse(const OrcContext *c, v3 o, v3 d, float tmax, orc_hit *best, int any_hit, orc_counters *cnt) {
     best->inst = ORC_MAX_UINT; best->t = tmax; best->geo = best->prim = 0; best->u = best->v = 0.0f;
+    if (c->exhaustive) return scene_exhaustive(c, o, d, best, any_hit, cnt);
     const orc_bvh *tl = &c->tlas;
     if (tl->node_count == 0) return 0;
     const orc_rayb rb = rayb_make(o, V3(safe_inv(d.x), safe_inv(d.y), safe_inv(d.z)));
+    const float far_pad = tl->cull_far * orc_maxf(orc_maxf(fabsf(o.x), fabsf(o.y)), fabsf(o.z));   /* instance_cull_slack: the part that grows with the origin's coordinates */
     uint32_t stack[256]; int sp = 0; int found = 0;
     stack[sp++] = 0;
     while (sp > 0) {
         const orc_wnode *n = &tl->nodes[stack[--sp]];
         cnt->node_visits++; if (any_hit) cnt->shadow_node_visits++;
         float tn[8], tb[8]; int idx[8]; int nh = 0;
-        const unsigned hm = box_hit8(n, &rb, best->t, tb);
+        const unsigned hm = box_hit8(n, &rb, best->t, far_pad, tb);
         for (int i = 0; i < n->nchild; i++) {
             const float t = tb[i];
             if (hm >> i & 1u) {

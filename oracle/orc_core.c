@@ -425,6 +425,8 @@ int OrcSetGeometryMaterial(OrcContext *c, uint32_t h, uint32_t geometry_index, u
     c->geometries[c->instances[h].geo_offset + geometry_index].material = material;
     return 0;
 }
+/* test infrastructure: the search with its box culls switched off (orc_bvh.c scene_exhaustive); 1 = every instance entered, 2 = and every triangle tested */
+void OrcSetExhaustiveSearch(OrcContext *c, int level) { c->exhaustive = level; }
 int OrcSetPipeline(OrcContext *c, const MsnePipelineOpts *o) { c->opts = *o; clear_all_sensors(c); return 0; }
 int64_t OrcCreateSensor(OrcContext *c, Extent2D e) {
     c->sensors = (orc_sensor *)realloc(c->sensors, sizeof(orc_sensor) * (c->sensor_count + 1));

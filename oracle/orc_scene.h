@@ -40,6 +40,7 @@ typedef struct {
     orc_tri *tris; uint32_t tri_count;          /* BLAS items */
     uint32_t *inst; uint32_t inst_count;        /* TLAS items (instance indices) */
     v3 lo, hi;
+    float cull_far;                             /* TLAS: orc_bvh.c instance_cull_slack, the largest per-unit-of-origin slack of any instance */
 } orc_bvh;
 
 typedef struct { uint32_t inst, geo, prim; float t, u, v; } orc_hit;                 /* intersection.hlsl:5-9; inst==MAX_UINT: miss */
@@ -68,6 +69,7 @@ typedef struct OrcContext {
     orc_instance *instances; uint32_t instance_count;
     orc_bvh *blases; uint32_t blas_count; uint32_t *blas_key_off, *blas_key_len; uint32_t *blas_keys; uint32_t blas_keys_len;
     orc_bvh tlas; int accel_dirty;
+    int exhaustive;         /* OrcSetExhaustiveSearch: 0 = both levels culled by their boxes; 1 = every visible instance is entered; 2 = and every triangle of it is tested */
     orc_alias_entry *alias; /* entry 0 = header */
     orc_envmap env;
     orc_sensor *sensors; uint32_t sensor_count;

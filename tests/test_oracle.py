@@ -268,3 +268,43 @@ def test_geometry_material_reassignment(orc):
     for bad in ((7, 0, red), (inst, 1, red), (inst, 0, 99)):
         with pytest.raises(RuntimeError):
             c.set_geometry_material(*bad)
+
+
+def _same_hits(c, rays):
+    """every ray through the culled search and through the search without instance boxes (OrcSetExhaustiveSearch 1): the same hit record, the same occlusion"""
+    bad = []
+    for k, r in enumerate(rays):
+        c.set_exhaustive_search(0); a = c.trace_closest(r[:3], r[3:6], float(r[6])); sa = c.trace_shadow(r[:3], r[3:6], float(r[6]))
+        c.set_exhaustive_search(1); b = c.trace_closest(r[:3], r[3:6], float(r[6])); sb = c.trace_shadow(r[:3], r[3:6], float(r[6]))
+        if a[0] != b[0] or sa != sb or (a[0] and (tuple(a[1]) != tuple(b[1]) or not np.array_equal(a[2].view(np.uint32), b[2].view(np.uint32)))):
+            bad.append((k, a, b, sa, sb))
+    c.set_exhaustive_search(0)
+    return bad
+
+
+@pytest.mark.parametrize("seed", __import__("seeds").seeds(list(range(24)) + [14, 501, 593, 707, 910, 1115, 1199, 1228, 2166, 2846, 3277, 3369], 60))
+def test_instance_boxes_never_change_a_hit(orc, seed):
+    """The contract (orc_bvh.c:1-10) is the search over every triangle of every visible instance in ITS space; the TLAS boxes only cut it short.  They live in world space,
+    and the two spaces agree up to the rounding of the inverse transform and of the transformed ray: orc_bvh.c instance_cull_slack bounds that and grows the boxes by it.
+    Held here against the search that enters every instance (OrcSetExhaustiveSearch): rays at the hulls' outermost vertices, tangent to them, from inside, from 1e5 away
+    (tests/hull_rays.py), with one transform that loses six digits in its inverse.  (The seeds named are the ones on which the boxes of round 5's oracle — the transformed
+    corners grown by 1e-6 of their size — lost or invented a hit.)"""
+    import hull_rays
+    c = orc.Context(threads=1)
+    world = hull_rays.hull_scene(c, seed, harsh=True)
+    c.create_sensor(8, 8)
+    bad = _same_hits(c, hull_rays.hull_rays(world, seed))
+    assert not bad, bad[:3]
+
+
+def test_triangle_boxes_never_change_a_hit(orc):
+    """the same for the boxes inside a BLAS: the search that tests every triangle of every instance (level 2) against the one that only enters every instance (level 1)"""
+    import hull_rays
+    for seed in range(6):
+        c = orc.Context(threads=1)
+        world = hull_rays.hull_scene(c, seed, harsh=True)
+        c.create_sensor(8, 8)
+        for r in hull_rays.hull_rays(world, seed):
+            c.set_exhaustive_search(1); a = c.trace_closest(r[:3], r[3:6], float(r[6])); sa = c.trace_shadow(r[:3], r[3:6], float(r[6]))
+            c.set_exhaustive_search(2); b = c.trace_closest(r[:3], r[3:6], float(r[6])); sb = c.trace_shadow(r[:3], r[3:6], float(r[6]))
+            assert a[0] == b[0] and sa == sb and (not a[0] or (tuple(a[1]) == tuple(b[1]) and np.array_equal(a[2].view(np.uint32), b[2].view(np.uint32)))), (seed, r, a, b)
