@@ -371,6 +371,26 @@ __global__ void k_ploc_init(uint32_t n, uint32_t* cref) {
 // ---------------- collapse to 8-wide + quantise ----------------
 struct CollapseWork { uint32_t bin; uint32_t wide; };
 
+// A node's grid (Node8: origin + one power-of-two quantum per axis, children as bytes on it).  The quantum: the smallest power of two s with ext / s <= 252 — three
+// steps of headroom: one for the outward rounding of a child's upper face, one for the origin below, one for the rounding of that origin.  The ORIGIN lies one quantum
+// BELOW the node's lower face: a child on that face then quantises to floor(1 - 1e-3) = 0 and its plane sits a quantum outside it, like every other plane of the grid
+// (each is pushed outward by at least 1e-3 quantum).  Before, such a child's plane was the face itself, to the bit — and a ray that starts within the underflow range
+// of that plane (1e-45 beside it, or on it and leaving by a direction component of -1e-45) was out of the box at t = 0 while the triangle test, whose products underflow,
+// still took the edge: the one place where a box was NOT wider than its triangles by a margin the arithmetic cannot cross (tests/test_gpu_parity.py::test_lattice_rays).
+__device__ __forceinline__ uint8_t grid_exponent(float lo, float hi) {
+    const float ext = hi - lo;
+    int ex = 1;
+    if (ext > 0.0f) { const float q = ext / 252.0f; ex = (int)((f2u(q) >> 23) & 0xff) + 1; }
+    if (ex < 1) ex = 1;
+    if (ex > 254) ex = 254;
+    return (uint8_t)ex;
+}
+__device__ __forceinline__ float grid_origin(float lo, uint8_t ex) {
+    const float o = lo - u2f((uint32_t)ex << 23);
+    return (o == o && o > -3.0e38f) ? o : lo;   // (a box at the end of the range or not a number: as it is)
+}
+
+
 __global__ void k_collapse(const CollapseWork* work, uint32_t nwork, CollapseWork* next, uint32_t* next_count,
                            BinTree t, const Box* leaf_boxes, const uint32_t* sorted_idx,
                            Node8* nodes, uint32_t* node_counter, uint32_t* item_counter, uint32_t* item_src) {
@@ -432,18 +452,13 @@ __global__ void k_collapse(const CollapseWork* work, uint32_t nwork, CollapseWor
     const uint32_t qpos = n_internal ? atomicAdd(next_count, n_internal) : 0u;
 
     Node8 nd;
-    nd.ox = nb.lo[0]; nd.oy = nb.lo[1]; nd.oz = nb.lo[2];
-    uint8_t e[3]; float inv_s[3];
+    uint8_t e[3]; float inv_s[3], grid_o[3];
     for (int k = 0; k < 3; k++) {
-        const float ext = nb.hi[k] - nb.lo[k];
-        // smallest power of two s with ext/s <= 254 (one step of headroom for the outward rounding below)
-        int ex = 0;
-        if (ext > 0.0f) { const float q = ext / 254.0f; ex = (int)((f2u(q) >> 23) & 0xff) + 1; } else ex = 1;
-        if (ex < 1) ex = 1;
-        if (ex > 254) ex = 254;
-        e[k] = (uint8_t)ex;
-        inv_s[k] = u2f((uint32_t)(254 - ex) << 23);   // 2^-(ex-127)
+        e[k] = grid_exponent(nb.lo[k], nb.hi[k]);
+        inv_s[k] = u2f((uint32_t)(254 - e[k]) << 23);   // 2^-(ex-127)
+        grid_o[k] = grid_origin(nb.lo[k], e[k]);
     }
+    nd.ox = grid_o[0]; nd.oy = grid_o[1]; nd.oz = grid_o[2];
     nd.ex = e[0]; nd.ey = e[1]; nd.ez = e[2];
     uint32_t imask = 0, lmask = 0, ii = 0, io = 0;
     for (int i = 0; i < 8; i++) for (int k = 0; k < 3; k++) { nd.qlo[k][i] = 255; nd.qhi[k][i] = 0; }
@@ -454,8 +469,8 @@ __global__ void k_collapse(const CollapseWork* work, uint32_t nwork, CollapseWor
         for (int k = 0; k < 3; k++) {
             const float origin = k == 0 ? nd.ox : (k == 1 ? nd.oy : nd.oz);
             // outward by at least 1e-3 quantum: a ray that runs exactly in a face plane of the TRUE box (axis-parallel, reciprocal
-            // +-1e30) then sees the quantised plane at +-(1e-3 * scale * 1e30), far above the ~1e-5 * scale * 1e30 rounding noise of
-            // q*a + b in the traversal; a child on the node's own lower face quantises to 0 and gives t = 0 exactly
+            // 1e30) then sees the quantised plane at +-(1e-3 * scale * 1e30), far above the ~1e-5 * scale * 1e30 rounding noise of
+            // q*a + b in the traversal; a child on the node's own lower face quantises to 0: one quantum below it (grid_origin)
             float ql = floorf((cb[i].lo[k] - origin) * inv_s[k] - 1e-3f);
             float qh = ceilf((cb[i].hi[k] - origin) * inv_s[k] + 1e-3f);
             ql = fminf(fmaxf(ql, 0.0f), 255.0f); qh = fminf(fmaxf(qh, 0.0f), 255.0f);
@@ -1201,15 +1216,8 @@ __device__ __forceinline__ void refit_node(Node8* nodes, uint32_t n, const Refit
         Box u;
         for (int k = 0; k < 3; k++) { u.lo[k] = 3.0e38f; u.hi[k] = -3.0e38f; }
         for (uint32_t s = 0; s < 8; s++) if ((used >> s) & 1u) for (int k = 0; k < 3; k++) { u.lo[k] = fminf(u.lo[k], cb[s].lo[k]); u.hi[k] = fmaxf(u.hi[k], cb[s].hi[k]); }
-        nd.ox = u.lo[0]; nd.oy = u.lo[1]; nd.oz = u.lo[2];
-        for (int k = 0; k < 3; k++) {   // smallest power of two s with ext/s <= 254, as k_collapse chooses it
-            const float ext = u.hi[k] - u.lo[k];
-            int ex = 1;
-            if (ext > 0.0f) { const float q = ext / 254.0f; ex = (int)((f2u(q) >> 23) & 0xff) + 1; }
-            if (ex < 1) ex = 1;
-            if (ex > 254) ex = 254;
-            e[k] = (uint8_t)ex; origin[k] = u.lo[k];
-        }
+        for (int k = 0; k < 3; k++) { e[k] = grid_exponent(u.lo[k], u.hi[k]); origin[k] = grid_origin(u.lo[k], e[k]); }   // (the grid k_collapse would choose)
+        nd.ox = origin[0]; nd.oy = origin[1]; nd.oz = origin[2];
         nd.ex = e[0]; nd.ey = e[1]; nd.ez = e[2];
         for (uint32_t s = 0; s < 8; s++) if ((used >> s) & 1u) {
             uint8_t a[3], b[3];

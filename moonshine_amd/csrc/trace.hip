@@ -107,7 +107,11 @@ __device__ __forceinline__ bool tri_intersect(const RayK& k, f3 r0, f3 r1, f3 r2
 }
 
 // reciprocal direction for the box tests only (they carry a 1e-5 slack): v_rcp_f32, 1 ulp
-__device__ __forceinline__ float safe_inv(float d) { return absf(d) < 1e-30f ? (d < 0.0f ? -1e30f : 1e30f) : __builtin_amdgcn_rcpf(d); }
+// A component below 1e-30 does not move the ray (t <= ~1e12): the slab test of that axis must come out as "lo <= o <= hi", planes included, for every t.  With +1e30
+// WHATEVER THE SIGN it does: every quantised plane lies at least 1e-3 quantum outside its box (bvh_build.hip grid_origin, k_collapse), so an origin on a face is
+// strictly between the planes and both distances are huge with opposite signs.  (-1e30 for a tiny negative component, with the lower faces still exact, turned "on the
+// lower face" into "left at t = 0": a lost edge hit — tests/test_gpu_parity.py::test_lattice_rays, direction components of -1e-45.)
+__device__ __forceinline__ float safe_inv(float d) { return absf(d) < 1e-30f ? 1e30f : __builtin_amdgcn_rcpf(d); }
 
 struct Hit { uint32_t inst, tri; float t, u, v; };   // tri = slot of the hit triangle's record in SceneView::tris
 

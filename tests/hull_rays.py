@@ -6,10 +6,11 @@ import numpy as np
 from moonshine_amd import scenes
 
 
-def hull_scene(ctx, seed, harsh=False):
+def hull_scene(ctx, seed, harsh=False, parts=None):
     """14 instances of 4 meshes (an icosphere, a flat quad, two triangle soups; axes scaled 1e-2 ... 10): rotated, mirrored, scaled 1e-3 ... 1e3 per axis (every third),
     sheared (every fourth), carried 0 ... 3e4 away from the origin.  `harsh`: instance 9 is sheared AND scaled 1e-3 ... 1e3 — a transform whose inverse loses six digits,
-    where the world-space image of what a ray meets in instance space is anywhere: no culling is possible there, only not culling.  Returns every instance's world-space vertices"""
+    where the world-space image of what a ray meets in instance space is anywhere: no culling is possible there, only not culling.  Returns every instance's world-space vertices
+    (`parts`: a list that receives every instance's object-space vertices, for hull_move)"""
     rs = np.random.default_rng(seed)
     normal = ctx.solid_texture(0.5, 0.5); black = ctx.solid_texture(0.0, 0.0, 0.0)
     grey = ctx.create_material(scenes.LAMBERT, normal, black, color=ctx.solid_texture(0.7, 0.7, 0.7))
@@ -33,9 +34,25 @@ def hull_scene(ctx, seed, harsh=False):
         t = rs.normal(size=3) * (0.0 if k == 0 else 10.0 ** rs.uniform(0, 4.5))
         T = np.zeros((3, 4), np.float32); T[:, :3] = M; T[:, 3] = t
         ctx.create_instance([(h, grey, False)], transform=T)
+        if parts is not None:
+            parts.append(P)
         world.append(P.astype(np.float64) @ T[:, :3].astype(np.float64).T + T[:, 3].astype(np.float64))
     ctx.set_background(np.array([0.5, 0.5, 0.5, 1], np.float32), 1, 1)
     return world
+
+
+def hull_move(ctxs, seed, parts, world):
+    """new transforms of the same kinds for five of the instances, in every context of `ctxs` (transform edits: the product re-fits its TLAS in place, Accel.zig:567-601);
+    `world` is updated"""
+    rs = np.random.default_rng(seed + 991)
+    for k in rs.choice(len(parts), 5, replace=False):
+        M = scenes._rot(rs.normal(size=3), rs.uniform(0, 6.28))[:3, :3] @ np.diag(10.0 ** rs.uniform(-3, 2, 3) * rs.choice([-1.0, 1.0], 3))
+        if rs.random() < 0.4:
+            M = M @ (np.eye(3) + np.triu(rs.normal(size=(3, 3)), 1) * 0.5)
+        T = np.zeros((3, 4), np.float32); T[:, :3] = M; T[:, 3] = rs.normal(size=3) * 10.0 ** rs.uniform(0, 4.5)
+        for c in ctxs:
+            c.set_instance_transform(int(k), T)
+        world[k] = parts[k].astype(np.float64) @ T[:, :3].astype(np.float64).T + T[:, 3].astype(np.float64)
 
 
 def hull_rays(world, seed, far=None):
@@ -64,4 +81,47 @@ def hull_rays(world, seed, far=None):
                     rays.append(np.concatenate([o, d / n, [1e12 if rs.random() < 0.7 else n * rs.uniform(0.5, 1.5)]]))
     rays = np.asarray(rays, np.float32)
     rays[:, 3:6] /= np.linalg.norm(rays[:, 3:6].astype(np.float64), axis=1, keepdims=True).astype(np.float32)
+    return rays
+
+
+def lattice_scene(ctx, seed):
+    """axis-aligned unit cubes (twelve triangles each, faces in coordinate planes) at half-integer places: some as identity instances (the merged world BLAS), some
+    under 90-degree rotations, mirrors and power-of-two scales with integer translations — every coordinate, product and sum exact in f32"""
+    rs = np.random.default_rng(seed)
+    normal = ctx.solid_texture(0.5, 0.5); black = ctx.solid_texture(0.0, 0.0, 0.0)
+    grey = ctx.create_material(scenes.LAMBERT, normal, black, color=ctx.solid_texture(0.7, 0.7, 0.7))
+    c = np.array([[x, y, z] for z in (0, 1) for y in (0, 1) for x in (0, 1)], np.float32)
+    quads = [(0, 1, 3, 2), (4, 6, 7, 5), (0, 4, 5, 1), (2, 3, 7, 6), (0, 2, 6, 4), (1, 5, 7, 3)]
+    I = np.array([t for q in quads for t in ((q[0], q[1], q[2]), (q[0], q[2], q[3]))], np.uint32)
+    cube = ctx.create_mesh(c, I)
+    flat = ctx.create_mesh(c[:4] * np.float32(2), np.array([[0, 1, 3], [0, 3, 2]], np.uint32))          # a 2 x 2 square in z = 0
+    perms = [np.eye(3)[list(p)] for p in ((0, 1, 2), (1, 2, 0), (2, 0, 1), (1, 0, 2), (0, 2, 1), (2, 1, 0))]
+    for k in range(int(rs.integers(4, 9))):
+        T = np.zeros((3, 4), np.float32)
+        if k % 3 == 0:
+            T[:, :3] = np.eye(3)                                                                         # identity: world BLAS
+        else:
+            T[:, :3] = perms[int(rs.integers(6))] @ np.diag(rs.choice([-1.0, 1.0], 3) * 2.0 ** rs.integers(-1, 2, 3))
+        T[:, 3] = rs.integers(-2, 3, 3) * (0.5 if k % 2 else 1.0)
+        ctx.create_instance([(flat if k % 4 == 3 else cube, grey, False)], transform=T)
+    ctx.set_background(np.array([0.5, 0.5, 0.5, 1], np.float32), 1, 1)
+
+
+def lattice_rays(seed, n=1500):
+    """origins on the half-integer lattice of [-3, 3]^3, directions out of {-1, -1/2, 0, 1/2, 1}^3 (not normalised: t is in units of d), tmax 1e12 or a small integer or
+    half-integer: rays IN face planes, along edges, through corners, starting on faces, ending exactly on them"""
+    rs = np.random.default_rng(seed + 5)
+    o = rs.integers(-6, 7, (n, 3)) * 0.5
+    d = rs.integers(-2, 3, (n, 3)) * 0.5
+    d[(d == 0).all(1)] = (1.0, 0.0, 0.0)
+    tmax = np.where(rs.random(n) < 0.5, 1e12, rs.integers(1, 9, n) * 0.5)
+    rays = np.concatenate([o, d, tmax[:, None]], 1).astype(np.float32)
+    # a few rays that are not rays: tmax 0, negative, infinite; an infinite or NaN origin or direction component; a zero direction
+    k = rs.choice(n, 40, replace=False)
+    rays[k[:8], 6] = (0.0, -1.0, np.inf, 0.0, -0.0, np.inf, 1e-45, 3e38)
+    rays[k[8:16], 0] = (np.inf, -np.inf, np.nan, np.inf, np.nan, 3e38, -3e38, 1e-45)
+    rays[k[16:24], 4] = (np.inf, -np.inf, np.nan, np.inf, np.nan, 3e38, 1e-45, -1e-45)
+    rays[k[24:28], 3:6] = 0.0
+    rays[k[28:34], 3:6] *= np.float32(1e-30)
+    rays[k[34:40], 3:6] *= np.float32(1e30)
     return rays

@@ -291,9 +291,13 @@ def test_instance_boxes_never_change_a_hit(orc, seed):
     corners grown by 1e-6 of their size — lost or invented a hit.)"""
     import hull_rays
     c = orc.Context(threads=1)
-    world = hull_rays.hull_scene(c, seed, harsh=True)
+    parts = []
+    world = hull_rays.hull_scene(c, seed, harsh=True, parts=parts)
     c.create_sensor(8, 8)
     bad = _same_hits(c, hull_rays.hull_rays(world, seed))
+    assert not bad, bad[:3]
+    hull_rays.hull_move((c,), seed, parts, world)
+    bad = _same_hits(c, hull_rays.hull_rays(world, seed + 1)[::2])
     assert not bad, bad[:3]
 
 
@@ -308,3 +312,43 @@ def test_triangle_boxes_never_change_a_hit(orc):
             c.set_exhaustive_search(1); a = c.trace_closest(r[:3], r[3:6], float(r[6])); sa = c.trace_shadow(r[:3], r[3:6], float(r[6]))
             c.set_exhaustive_search(2); b = c.trace_closest(r[:3], r[3:6], float(r[6])); sb = c.trace_shadow(r[:3], r[3:6], float(r[6]))
             assert a[0] == b[0] and sa == sb and (not a[0] or (tuple(a[1]) == tuple(b[1]) and np.array_equal(a[2].view(np.uint32), b[2].view(np.uint32)))), (seed, r, a, b)
+
+
+@pytest.mark.parametrize("seed", __import__("seeds").seeds(list(range(12)), 20))
+def test_no_box_changes_a_pixel(orc, seed):
+    """the randomized scenes of tests/test_gpu_parity.py rendered twice by the oracle — with its two-level BVH, and testing every triangle of every visible instance for
+    every ray (OrcSetExhaustiveSearch 2, the contract with nothing in the way): the same film bit for bit, the same ray counts, the same probe rays"""
+    import test_gpu_parity as G
+    rs = np.random.default_rng(1000 + seed)
+    films, counts, hits = [], [], []
+    rays = G._random_rays(200, seed, radius=8.0)
+    bounces = int(rs.integers(1, 5))
+    for level in (0, 2):
+        c = orc.Context(threads=usable_cores())
+        s, l = G._random_scene(c, seed=seed)
+        c.set_pipeline(samples_per_run=1, max_bounces=bounces, env_samples_per_bounce=1, mesh_samples_per_bounce=1)
+        c.set_exhaustive_search(level)
+        c.render(s, l, launches=1)
+        films.append(c.sensor_data(s).copy())
+        k = c.counters(); counts.append((k["closest_rays"], k["shadow_rays"], k["samples"]))
+        hits.append([(c.trace_closest(r[:3], r[3:6], float(r[6])), c.trace_shadow(r[:3], r[3:6], float(r[6]))) for r in rays])
+    same = (films[0].view(np.uint32) == films[1].view(np.uint32)) | (np.isnan(films[0]) & np.isnan(films[1]))
+    assert same.all(), "%d values differ" % int((~same).sum())
+    assert counts[0] == counts[1]
+    for (a, sa), (b, sb) in zip(*hits):
+        assert a[0] == b[0] and sa == sb and (not a[0] or (tuple(a[1]) == tuple(b[1]) and np.array_equal(a[2].view(np.uint32), b[2].view(np.uint32))))
+
+
+@pytest.mark.parametrize("seed", __import__("seeds").seeds(list(range(8)), 24))
+def test_lattice_rays_with_and_without_boxes(orc, seed):
+    """exact arithmetic everywhere (tests/hull_rays.py lattice_*): rays in face planes, along edges, through corners, starting and ending on faces — box distances of
+    +-0, ties between up to six triangles of several instances; the culled search against the exhaustive one"""
+    import hull_rays
+    c = orc.Context(threads=1)
+    hull_rays.lattice_scene(c, seed)
+    c.create_sensor(8, 8)
+    rays = hull_rays.lattice_rays(seed)
+    bad = _same_hits(c, rays)
+    assert not bad, bad[:3]
+    c.set_exhaustive_search(0)
+    assert sum(1 for r in rays[:300] if c.trace_closest(r[:3], r[3:6], float(r[6]))[0]) > 10        # (the rays do hit things)
