@@ -1084,8 +1084,10 @@ __global__ __launch_bounds__(256) void k_instance_boxes(const TlasInst* insts, c
         if (threadIdx.x == 0) {
             for (int w = 0; w < 256 / 64; w++) r2 = fmaxf(r2, s_r2[w]);
             if (!(r2 >= 0.0f) || !(r2 < 3e38f) || !(c.x == c.x && c.y == c.y && c.z == c.z)) r2 = 3e38f;   // (not finite: a sphere nothing is outside of)
-            const float rad = r2 < 1e37f ? sqrtf(r2) * 1.000001f + 1.7320509f * in.cull_pad : 1e18f;   // (the slack is a bound per coordinate: sqrt 3 of it along a diagonal)
-            spheres[sphere_ids[i]] = make_float4(c.x, c.y, c.z, rad < 1e18f ? rad : 1e18f);   // (radius; 1e18: its square is still finite)
+            // (the slack is a bound per coordinate: sqrt 3 of it along a diagonal.  A radius whose SQUARE the traversal could not hold — vertices beyond ~1e18 from the
+            // centre, a squared distance that overflowed here — is stored as 3e38: its square is infinite there and nothing is outside of it)
+            const float rad = r2 < 1e36f ? sqrtf(r2) * 1.000001f + 1.7320509f * in.cull_pad : 3.0e38f;
+            spheres[sphere_ids[i]] = make_float4(c.x, c.y, c.z, rad < 1e18f ? rad : 3.0e38f);
         }
     }
     if (threadIdx.x != 0) return;

@@ -543,7 +543,7 @@ __device__ __forceinline__ void trace_wave_loop(const SceneView& sc, uint32_t n,
                 const float oc2 = dot(oc, oc), dd = dot(d, d), b = dot(oc, d), r2s = rr * rr;
                 const float disc = b * b - dd * (oc2 - r2s);
 #if !defined(TRACE_NO_SPHERE_CULL)
-                if (oc2 > r2s && (b <= 0.0f || disc < -1e-5f * (b * b + dd * oc2))) root = MAX_UINT;
+                if (oc2 > r2s && (b * b + dd * oc2) < 3.0e38f && (b <= 0.0f || disc < -1e-5f * (b * b + dd * oc2))) root = MAX_UINT;   // (a sum that overflowed or is not a number decides nothing)
 #endif
             }
             if (root != MAX_UINT) {

@@ -84,6 +84,11 @@ def hull_rays(world, seed, far=None):
     return rays
 
 
+def lattice_scale(seed):
+    """the scene and its rays times a power of two (exact): 1 for most seeds; 2^-40, 2^40; 2^-62 and 2^62, where products of two coordinates sit at the ends of the range"""
+    return np.float32(2.0) ** int(np.random.default_rng(seed + 3).choice([0, 0, 0, 0, -40, 40, -62, 62]))
+
+
 def lattice_scene(ctx, seed):
     """axis-aligned unit cubes (twelve triangles each, faces in coordinate planes) at half-integer places: some as identity instances (the merged world BLAS), some
     under 90-degree rotations, mirrors and power-of-two scales with integer translations — every coordinate, product and sum exact in f32"""
@@ -93,8 +98,9 @@ def lattice_scene(ctx, seed):
     c = np.array([[x, y, z] for z in (0, 1) for y in (0, 1) for x in (0, 1)], np.float32)
     quads = [(0, 1, 3, 2), (4, 6, 7, 5), (0, 4, 5, 1), (2, 3, 7, 6), (0, 2, 6, 4), (1, 5, 7, 3)]
     I = np.array([t for q in quads for t in ((q[0], q[1], q[2]), (q[0], q[2], q[3]))], np.uint32)
-    cube = ctx.create_mesh(c, I)
-    flat = ctx.create_mesh(c[:4] * np.float32(2), np.array([[0, 1, 3], [0, 3, 2]], np.uint32))          # a 2 x 2 square in z = 0
+    S = lattice_scale(seed)
+    cube = ctx.create_mesh(c * S, I)
+    flat = ctx.create_mesh(c[:4] * np.float32(2) * S, np.array([[0, 1, 3], [0, 3, 2]], np.uint32))      # a 2 x 2 square in z = 0
     perms = [np.eye(3)[list(p)] for p in ((0, 1, 2), (1, 2, 0), (2, 0, 1), (1, 0, 2), (0, 2, 1), (2, 1, 0))]
     for k in range(int(rs.integers(4, 9))):
         T = np.zeros((3, 4), np.float32)
@@ -102,7 +108,7 @@ def lattice_scene(ctx, seed):
             T[:, :3] = np.eye(3)                                                                         # identity: world BLAS
         else:
             T[:, :3] = perms[int(rs.integers(6))] @ np.diag(rs.choice([-1.0, 1.0], 3) * 2.0 ** rs.integers(-1, 2, 3))
-        T[:, 3] = rs.integers(-2, 3, 3) * (0.5 if k % 2 else 1.0)
+        T[:, 3] = rs.integers(-2, 3, 3) * (0.5 if k % 2 else 1.0) * S
         ctx.create_instance([(flat if k % 4 == 3 else cube, grey, False)], transform=T)
     ctx.set_background(np.array([0.5, 0.5, 0.5, 1], np.float32), 1, 1)
 
@@ -116,6 +122,10 @@ def lattice_rays(seed, n=1500):
     d[(d == 0).all(1)] = (1.0, 0.0, 0.0)
     tmax = np.where(rs.random(n) < 0.5, 1e12, rs.integers(1, 9, n) * 0.5)
     rays = np.concatenate([o, d, tmax[:, None]], 1).astype(np.float32)
+    rays[:, :3] *= lattice_scale(seed)                                      # (t is then in units of the scale too: d is left alone for half of the rays)
+    half = rs.random(n) < 0.5
+    rays[half, 3:6] *= lattice_scale(seed)
+    rays[~half, 6] = np.minimum(rays[~half, 6].astype(np.float64) * float(lattice_scale(seed)), 3e38).astype(np.float32)
     # a few rays that are not rays: tmax 0, negative, infinite; an infinite or NaN origin or direction component; a zero direction
     k = rs.choice(n, 40, replace=False)
     rays[k[:8], 6] = (0.0, -1.0, np.inf, 0.0, -0.0, np.inf, 1e-45, 3e38)
