@@ -6,15 +6,16 @@ import numpy as np
 from moonshine_amd import scenes
 
 
-def hull_scene(ctx, seed, harsh=False, parts=None):
+def hull_scene(ctx, seed, harsh=False, parts=None, baked=False):
     """14 instances of 4 meshes (an icosphere, a flat quad, two triangle soups; axes scaled 1e-2 ... 10): rotated, mirrored, scaled 1e-3 ... 1e3 per axis (every third),
     sheared (every fourth), carried 0 ... 3e4 away from the origin.  `harsh`: instance 9 is sheared AND scaled 1e-3 ... 1e3 — a transform whose inverse loses six digits,
     where the world-space image of what a ray meets in instance space is anywhere: no culling is possible there, only not culling.  Returns every instance's world-space vertices
-    (`parts`: a list that receives every instance's object-space vertices, for hull_move)"""
+    (`parts`: a list that receives every instance's object-space vertices, for hull_move).  `baked`: the transforms are applied to the vertices instead (in double, rounded
+    once) and every instance is an identity instance — ONE world BLAS over features of 1e-3 ... 1e3 at coordinates up to 3e4, traced by the kernels without a TLAS level"""
     rs = np.random.default_rng(seed)
     normal = ctx.solid_texture(0.5, 0.5); black = ctx.solid_texture(0.0, 0.0, 0.0)
     grey = ctx.create_material(scenes.LAMBERT, normal, black, color=ctx.solid_texture(0.7, 0.7, 0.7))
-    meshes = []
+    meshes = []; meshes_I = {}
     for k in range(4):
         if k == 0:
             P, I = scenes.icosphere(1)
@@ -23,7 +24,7 @@ def hull_scene(ctx, seed, harsh=False, parts=None):
         else:
             P = rs.normal(size=(3 * 24, 3)).astype(np.float32); I = np.arange(3 * 24, dtype=np.uint32).reshape(-1, 3)
         P = (P * np.float32(10.0) ** rs.uniform(-2, 1, (1, 3))).astype(np.float32)
-        meshes.append((ctx.create_mesh(P, I), P))
+        meshes.append((ctx.create_mesh(P, I), P)); meshes_I[meshes[-1][0]] = I
     world = []
     for k in range(14):
         h, P = meshes[int(rs.integers(len(meshes)))]
@@ -33,10 +34,16 @@ def hull_scene(ctx, seed, harsh=False, parts=None):
             M = M @ (np.eye(3) + np.triu(rs.normal(size=(3, 3)), 1))                # shear
         t = rs.normal(size=3) * (0.0 if k == 0 else 10.0 ** rs.uniform(0, 4.5))
         T = np.zeros((3, 4), np.float32); T[:, :3] = M; T[:, 3] = t
-        ctx.create_instance([(h, grey, False)], transform=T)
+        W = P.astype(np.float64) @ T[:, :3].astype(np.float64).T + T[:, 3].astype(np.float64)
+        if baked:
+            W = W.astype(np.float32)
+            ctx.create_instance([(ctx.create_mesh(W, meshes_I[h]), grey, False)])
+            W = W.astype(np.float64)
+        else:
+            ctx.create_instance([(h, grey, False)], transform=T)
         if parts is not None:
             parts.append(P)
-        world.append(P.astype(np.float64) @ T[:, :3].astype(np.float64).T + T[:, 3].astype(np.float64))
+        world.append(W)
     ctx.set_background(np.array([0.5, 0.5, 0.5, 1], np.float32), 1, 1)
     return world
 
@@ -89,7 +96,7 @@ def lattice_scale(seed):
     return np.float32(2.0) ** int(np.random.default_rng(seed + 3).choice([0, 0, 0, 0, -40, 40, -62, 62]))
 
 
-def lattice_scene(ctx, seed):
+def lattice_scene(ctx, seed, baked=False):
     """axis-aligned unit cubes (twelve triangles each, faces in coordinate planes) at half-integer places: some as identity instances (the merged world BLAS), some
     under 90-degree rotations, mirrors and power-of-two scales with integer translations — every coordinate, product and sum exact in f32"""
     rs = np.random.default_rng(seed)
@@ -109,7 +116,11 @@ def lattice_scene(ctx, seed):
         else:
             T[:, :3] = perms[int(rs.integers(6))] @ np.diag(rs.choice([-1.0, 1.0], 3) * 2.0 ** rs.integers(-1, 2, 3))
         T[:, 3] = rs.integers(-2, 3, 3) * (0.5 if k % 2 else 1.0) * S
-        ctx.create_instance([(flat if k % 4 == 3 else cube, grey, False)], transform=T)
+        if baked:
+            V, J = (c[:4] * np.float32(2) * S, np.array([[0, 1, 3], [0, 3, 2]], np.uint32)) if k % 4 == 3 else (c * S, I)
+            ctx.create_instance([(ctx.create_mesh((V.astype(np.float64) @ T[:, :3].astype(np.float64).T + T[:, 3].astype(np.float64)).astype(np.float32), J), grey, False)])
+        else:
+            ctx.create_instance([(flat if k % 4 == 3 else cube, grey, False)], transform=T)
     ctx.set_background(np.array([0.5, 0.5, 0.5, 1], np.float32), 1, 1)
 
 

@@ -939,11 +939,14 @@ def test_rays_at_the_hulls_of_far_scaled_and_sheared_instances(orc, gpu_api, see
     import hull_rays
     oc = orc.Context(threads=8); gc = gpu_api.Context()
     harsh = seed % 2 == 1                                                           # every other scene has the transform whose inverse loses six digits
+    baked = seed % 3 == 2                                                           # every third: the same geometry as ONE world BLAS (the kernels without a TLAS level)
     parts = []
-    world = hull_rays.hull_scene(oc, seed, harsh, parts); hull_rays.hull_scene(gc, seed, harsh)
+    world = hull_rays.hull_scene(oc, seed, harsh, parts, baked); hull_rays.hull_scene(gc, seed, harsh, baked=baked)
     for c in (oc, gc):
         c.create_sensor(8, 8)                                                       # builds happen at the first use
     _check_rays(oc, gc, hull_rays.hull_rays(world, seed))
+    if baked:
+        return
     updates = gc.accel_stats()["tlas_updates"]
     hull_rays.hull_move((oc, gc), seed, parts, world)                               # five instances moved: the product re-fits, with new slacks and spheres
     _check_rays(oc, gc, hull_rays.hull_rays(world, seed + 1)[::2])
@@ -961,7 +964,7 @@ def test_lattice_rays(orc, gpu_api, seed):
     import hull_rays
     oc = orc.Context(threads=8); gc = gpu_api.Context()
     for c in (oc, gc):
-        hull_rays.lattice_scene(c, seed); c.create_sensor(8, 8)
+        hull_rays.lattice_scene(c, seed, baked=seed % 3 == 2); c.create_sensor(8, 8)   # (every third scene: one world BLAS)
     _check_rays(oc, gc, hull_rays.lattice_rays(seed))
 
 
