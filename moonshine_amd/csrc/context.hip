@@ -329,6 +329,14 @@ static bool is_identity(const m34& m) {
     return true;
 }
 
+// An instance under a transform with an infinite or NaN entry cannot be hit — its inverse, and with it every ray taken into its space, has a NaN in it, and the triangle
+// test accepts nothing that is not a number (the oracle enters such an instance and finds nothing) — so it is left out of the TLAS like a hidden one: boxes of +-3e38
+// around it would take every other instance's box of the same TLAS node down to one or two quanta of a grid 1e38 wide.
+static bool finite_transform(const m34& m) {
+    for (int r = 0; r < 3; r++) for (int c = 0; c < 4; c++) if (!(fabsf(m.m[r][c]) < 3.0e38f)) return false;
+    return true;
+}
+
 // largest absolute coordinate an instance's vertices can have: in the BLAS's own space (its root box) and under the transform (|T| applied to the box's reach)
 static float coord_reach(const m34& T, const float box[6]) {
     float a[3], r = 0.0f;
@@ -533,7 +541,7 @@ bool HdMoonshine::rebuild_accel() {
         if (in_world[i]) continue;
         const BlasInfo& bi = blas_cache[keys[i]];
         r.blas_root = bi.root;
-        if (!instances[i].visible || bi.root == MAX_UINT) continue;
+        if (!instances[i].visible || bi.root == MAX_UINT || !finite_transform(instances[i].transform)) continue;
         add_box(instances[i].transform, bi.box, (uint32_t)i, &keys[i]);
     }
     m34 ident; for (int r = 0; r < 3; r++) for (int c = 0; c < 4; c++) ident.m[r][c] = r == c ? 1.0f : 0.0f;
@@ -1058,7 +1066,7 @@ void HdMoonshineSetInstanceTransform(HdMoonshine* c, InstanceHandle h, Mat3x4 t)
     // in place when the edit leaves the scene's structure alone: the instance is and stays a TLAS leaf of its own (not part of the merged world BLAS, which holds
     // the identity-transform instances), is visible, and none of its geometry is a sampled light (the alias table weighs world-space areas)
     bool in_place = !c->accel_dirty && !c->root_in_blas && h < c->built_in_world.size() && !c->built_in_world[h] && h < c->item_of_instance.size() && c->item_of_instance[h] != MAX_UINT
-                    && in.visible && !is_identity(in.transform);
+                    && in.visible && !is_identity(in.transform) && finite_transform(in.transform);
     for (const GeometryRec& g : in.geos) if (g.sampled) in_place = false;
     if (in_place) c->transform_edits.push_back(h); else c->accel_dirty = true;
     c->clear_all_sensors();

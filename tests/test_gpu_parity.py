@@ -968,6 +968,49 @@ def test_lattice_rays(orc, gpu_api, seed):
     _check_rays(oc, gc, hull_rays.lattice_rays(seed))
 
 
+def _odd_transform_scene(c, M):
+    normal = c.solid_texture(0.5, 0.5); black = c.solid_texture(0.0, 0.0, 0.0)
+    grey = c.create_material(scenes.LAMBERT, normal, black, color=c.solid_texture(0.7, 0.7, 0.7))
+    P, I = scenes.icosphere(2); m = c.create_mesh(P, I)
+    def T(M, t):
+        o = np.zeros((3, 4), np.float32); o[:, :3] = M; o[:, 3] = t
+        return o
+    c.create_instance([(m, grey, False)], transform=T(np.eye(3), (0, 0, 0)))
+    c.create_instance([(m, grey, False)], transform=T(np.diag([1, 1, 0.5]), (2.5, 0, 0)))
+    c.create_instance([(m, grey, False)], transform=T(M, (-2.5, 0, 0)))
+    c.set_background(np.array([0.5, 0.5, 0.5, 1], np.float32), 1, 1)
+    lens = c.create_lens(c.make_lens((0, -9, 1.0), (0, 1, -0.1), (0, 0, 1), 0.7, 0.0, 1.0))
+    return c.create_sensor(48, 27), lens, T
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind", ["flat", "line", "zero", "rank2", "nan", "inf", "inf_t", "huge", "tiny"])
+def test_instances_under_singular_and_non_finite_transforms(orc, gpu_api, kind):
+    """one of three instances under a transform that has no inverse (a scale of 0 in one, two, three axes; rank 2), a NaN or infinite entry, an infinite translation, or a
+    scale of 1e30 / 1e-30: it is never hit (its inverse is not finite, or it is everywhere / nowhere) and it must not cost the OTHER instances their hits — round 5's
+    first run of this lost every hit of the scene to one infinite entry (boxes of +-3e38 in the TLAS: context.hip finite_transform).  Then the transform is edited to an
+    ordinary one and another instance's to a broken one"""
+    M = {"flat": np.diag([1.0, 1.0, 0.0]), "line": np.diag([1.0, 0, 0]), "zero": np.zeros((3, 3)), "rank2": np.array([[1, 2, 3], [2, 4, 6], [0, 1, 0.0]]),
+         "nan": np.diag([1.0, np.nan, 1.0]), "inf": np.diag([1.0, np.inf, 1.0]), "inf_t": np.eye(3), "huge": np.eye(3) * 1e30, "tiny": np.eye(3) * 1e-30}[kind]
+    oc = orc.Context(threads=8); gc = gpu_api.Context()
+    (so, lo, T), (sg, lg, _) = _odd_transform_scene(oc, M), _odd_transform_scene(gc, M)
+    if kind == "inf_t":
+        for c in (oc, gc):
+            c.set_instance_transform(2, T(np.eye(3), (np.inf, 0, -np.inf)))
+    rays = _random_rays(600, 5, radius=6.0)
+    for stage in range(2):
+        _check_rays(oc, gc, rays)
+        assert int(gc.trace_rays(rays)[0][:, 0].sum()) > 300                       # (the two ordinary instances are hit)
+        for c in (oc, gc):
+            c.set_pipeline(samples_per_run=1, max_bounces=4, env_samples_per_bounce=1, mesh_samples_per_bounce=0)
+        gc.render(sg, lg, launches=2); oc.render(so, lo, launches=2)
+        a, b = gc.sensor_data(sg), oc.sensor_data(so)
+        assert ((a.view(np.uint32) == b.view(np.uint32)) | (np.isnan(a) & np.isnan(b))).all(), "%s stage %d" % (kind, stage)
+        for c in (oc, gc):                                                          # the broken one mended, an ordinary one broken
+            c.set_instance_transform(2, T(np.diag([0.8, 1.1, 0.9]), (-2.5, 0.5, 0)))
+            c.set_instance_transform(1, T(M, (2.5, 0, 0)) if kind != "inf_t" else T(np.eye(3), (0, np.inf, 0)))
+
+
 @pytest.mark.gpu
 def test_triangles_with_a_nan_vertex_are_inactive(orc, gpu_api):
     """a NaN vertex position makes its triangles inactive (never hit), as in the Vulkan acceleration-structure rules the reference
