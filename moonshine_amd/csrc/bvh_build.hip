@@ -53,6 +53,11 @@ __global__ void k_prim_boxes_tris(const BlasGeo* geos, uint32_t ngeo, uint32_t n
     Box b;
     for (int k = 0; k < 3; k++) {
         float a = ge.positions[3 * (size_t)i0 + k], bb = ge.positions[3 * (size_t)i1 + k], c = ge.positions[3 * (size_t)i2 + k];
+        // a triangle with a corner that is not a number cannot be hit (the watertight test accepts nothing that is not a number): min / max skip the NaN and the box is
+        // that of the other corners.  An INFINITE corner is the same triangle to the test and is read the same way here — kept, it made every box above it infinite
+        // (one such vertex cost a scene a quarter of its hits: tests/test_gpu_parity.py::test_triangles_with_a_vertex_that_is_not_finite)
+        const float nan = u2f(0x7fc00000u);
+        a = absf(a) < 3.4e38f ? a : nan; bb = absf(bb) < 3.4e38f ? bb : nan; c = absf(c) < 3.4e38f ? c : nan;
         b.lo[k] = fminf(a, fminf(bb, c)); b.hi[k] = fmaxf(a, fmaxf(bb, c));
     }
     boxes[i] = b;

@@ -554,7 +554,7 @@ bool HdMoonshine::rebuild_accel() {
             add_box(ident, bi.box, (uint32_t)N, nullptr);
         }
     }
-    for (TlasInst& t : tinst) { m34 T; memcpy(&T, t.T, 48); t.cull_pad = instance_cull_pad(T, t.blas_box, 16.0f * coord_radius); }
+    for (TlasInst& t : tinst) { m34 T; memcpy(&T, t.T, 48); t.cull_pad = instance_cull_pad(T, t.blas_box, std::min(16.0f * coord_radius, 3.0e38f)); }   // (a scene with a coordinate beyond 2e37: the product must stay finite, or every instance's slack is infinite)
     lap("instance records");
     if (!d_instances.alloc(irec.size())) { fail("out of device memory (instances)"); return false; }
     CHECK_HIP(this, hipMemcpyAsync(d_instances.p, irec.data(), irec.size() * sizeof(InstanceRec), hipMemcpyHostToDevice, stream));
@@ -639,7 +639,7 @@ bool HdMoonshine::refit_tlas() {
         tinst.push_back(t); items.push_back(item_of_instance[h]);
         coord_radius = std::max(coord_radius, coord_reach(instances[h].transform, bi->second.box));
     }
-    for (TlasInst& t : tinst) { m34 T; memcpy(&T, t.T, 48); t.cull_pad = instance_cull_pad(T, t.blas_box, 16.0f * coord_radius); }
+    for (TlasInst& t : tinst) { m34 T; memcpy(&T, t.T, 48); t.cull_pad = instance_cull_pad(T, t.blas_box, std::min(16.0f * coord_radius, 3.0e38f)); }   // (a scene with a coordinate beyond 2e37: the product must stay finite, or every instance's slack is infinite)
     if (transform_edits.size() > 64) CHECK_HIP(this, hipMemcpyAsync(d_instances.p, h_irec.data(), h_irec.size() * sizeof(InstanceRec), hipMemcpyHostToDevice, stream));   // many edits: the whole table in one copy
     if (!build_scratch && !(build_scratch = bvh_scratch_create())) { fail("out of host memory"); return false; }
     if (!bvh_refit_tlas(build_scratch, stream, tinst.data(), tmesh.data(), (uint32_t)tmesh.size(), items.data(), (uint32_t)items.size(), d_nodes.p, tlas_node_begin, tlas_node_end - tlas_node_begin, tlas_item_begin, n_tlas_items,
