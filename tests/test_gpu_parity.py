@@ -1012,6 +1012,40 @@ def test_instances_under_singular_and_non_finite_transforms(orc, gpu_api, kind):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("family", ["hull", "lattice"])
+@pytest.mark.parametrize("seed", __import__("seeds").seeds(list(range(6)), 30))
+def test_films_of_hull_and_lattice_scenes(orc, gpu_api, family, seed):
+    """the scenes of tests/hull_rays.py RENDERED (24 x 16, two launches of two samples, five bounces, environment light): a camera 0.3 / 1.5 / 4 radii from an instance under
+    a scaled, sheared, far-away transform, or on the half-integer lattice looking along a lattice direction — hits at t ~ 0, shading frames under transforms that lose six
+    digits, paths that leave a surface along it.  Film and ray counts against the oracle"""
+    import hull_rays
+    oc = orc.Context(threads=8); gc = gpu_api.Context()
+    rs = np.random.default_rng(seed + 9)
+    if family == "hull":
+        world = [hull_rays.hull_scene(c, seed, seed % 2 == 1, baked=seed % 3 == 2) for c in (oc, gc)][0]
+        W = world[int(rs.integers(len(world)))]; ctr = 0.5 * (W.min(0) + W.max(0)); r = max(np.linalg.norm(W - ctr, axis=1).max(), 1e-20)
+        eye = ctr + rs.normal(size=3) * r * rs.choice([0.3, 1.5, 4.0]); fwd = ctr - eye + rs.normal(size=3) * r * 0.1
+    else:
+        S = float(hull_rays.lattice_scale(seed))
+        if not 1e-10 < S < 1e10:
+            pytest.skip("a camera needs a frame: the lattice at 2^+-62 is for rays only")
+        for c in (oc, gc):
+            hull_rays.lattice_scene(c, seed, baked=seed % 3 == 2)
+        eye = rs.integers(-6, 7, 3) * 0.5 * S; fwd = rs.integers(-2, 3, 3) * 1.0
+        if not fwd.any():
+            fwd = np.array([1.0, 0, 0])
+    up = np.array([0, 0, 1.0]) if abs(fwd[2]) < 0.9 * np.linalg.norm(fwd) else np.array([0, 1.0, 0])
+    films = []
+    for c in (oc, gc):
+        lens = c.create_lens(c.make_lens(tuple(eye), tuple(fwd / np.linalg.norm(fwd)), tuple(up), 0.9, 0.0, 1.0)); sn = c.create_sensor(24, 16)
+        c.set_pipeline(samples_per_run=2, max_bounces=5, env_samples_per_bounce=1, mesh_samples_per_bounce=0)
+        c.render(sn, lens, launches=2); films.append(c.sensor_data(sn).copy())
+    same = (films[0].view(np.uint32) == films[1].view(np.uint32)) | (np.isnan(films[0]) & np.isnan(films[1]))
+    assert same.all(), "%d pixels differ" % int((~same).any(-1).sum())
+    assert gc.counters() == {k: v for k, v in oc.counters().items() if k in ("closest_rays", "shadow_rays", "samples")}
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("bad", [np.inf, -np.inf, 3e38, 1e38, 1e33])
 @pytest.mark.parametrize("layout", ["world", "world+instance", "instances"])
 def test_triangles_with_a_vertex_that_is_not_finite(orc, gpu_api, bad, layout):
