@@ -96,7 +96,7 @@ def lattice_scale(seed):
     return np.float32(2.0) ** int(np.random.default_rng(seed + 3).choice([0, 0, 0, 0, -40, 40, -62, 62]))
 
 
-def lattice_scene(ctx, seed, baked=False):
+def lattice_scene(ctx, seed, baked=False, scale=None):
     """axis-aligned unit cubes (twelve triangles each, faces in coordinate planes) at half-integer places: some as identity instances (the merged world BLAS), some
     under 90-degree rotations, mirrors and power-of-two scales with integer translations — every coordinate, product and sum exact in f32"""
     rs = np.random.default_rng(seed)
@@ -105,7 +105,7 @@ def lattice_scene(ctx, seed, baked=False):
     c = np.array([[x, y, z] for z in (0, 1) for y in (0, 1) for x in (0, 1)], np.float32)
     quads = [(0, 1, 3, 2), (4, 6, 7, 5), (0, 4, 5, 1), (2, 3, 7, 6), (0, 2, 6, 4), (1, 5, 7, 3)]
     I = np.array([t for q in quads for t in ((q[0], q[1], q[2]), (q[0], q[2], q[3]))], np.uint32)
-    S = lattice_scale(seed)
+    S = lattice_scale(seed) if scale is None else np.float32(scale)
     cube = ctx.create_mesh(c * S, I)
     flat = ctx.create_mesh(c[:4] * np.float32(2) * S, np.array([[0, 1, 3], [0, 3, 2]], np.uint32))      # a 2 x 2 square in z = 0
     perms = [np.eye(3)[list(p)] for p in ((0, 1, 2), (1, 2, 0), (2, 0, 1), (1, 0, 2), (0, 2, 1), (2, 1, 0))]
@@ -145,4 +145,28 @@ def lattice_rays(seed, n=1500):
     rays[k[24:28], 3:6] = 0.0
     rays[k[28:34], 3:6] *= np.float32(1e-30)
     rays[k[34:40], 3:6] *= np.float32(1e30)
+    return rays
+
+
+def face_rays(seed, n=600):
+    """rays that LEAVE the faces of the lattice scenes' cubes from almost no distance: origins on a lattice plane in one axis (generic or lattice in the others), moved off
+    it by 0 ... 300 ulps (from 0: denormals), 2^-16 or 2^-10, directions anywhere in the half space they move into — the triangle test computes their t to the face as a
+    cancellation of O(1) terms (+-2e-8 around a true 0 or -1e-42) and takes some of them"""
+    rs = np.random.default_rng(seed + 21)
+    rays = np.zeros((n, 7), np.float32)
+    for k in range(n):
+        p = rs.integers(-6, 7, 3) * 0.5 + rs.random(3) * (rs.random(3) < 0.6)
+        ax = int(rs.integers(3)); p[ax] = rs.integers(-6, 7) * 0.5
+        sgn = float(rs.choice([-1.0, 1.0]))
+        o = p.astype(np.float32)
+        off = rs.choice([1.0 / 65536, 2.0 ** -10, 0.0])
+        if off == 0.0:
+            for _ in range(int(rs.integers(0, 300))):
+                o[ax] = np.nextafter(o[ax], np.float32(np.inf * sgn))
+        else:
+            o[ax] += np.float32(off * sgn)
+        d = rs.normal(size=3); d /= np.linalg.norm(d)
+        if d[ax] * sgn < 0:
+            d = -d
+        rays[k, :3] = o; rays[k, 3:6] = d; rays[k, 6] = 1e12
     return rays

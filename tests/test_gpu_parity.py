@@ -966,6 +966,8 @@ def test_lattice_rays(orc, gpu_api, seed):
     for c in (oc, gc):
         hull_rays.lattice_scene(c, seed, baked=seed % 3 == 2); c.create_sensor(8, 8)   # (every third scene: one world BLAS)
     _check_rays(oc, gc, hull_rays.lattice_rays(seed))
+    if float(hull_rays.lattice_scale(seed)) == 1.0:
+        _check_rays(oc, gc, hull_rays.face_rays(seed))                              # rays leaving faces from 0 ... 300 ulps off them
 
 
 def _odd_transform_scene(c, M):
@@ -1013,11 +1015,13 @@ def test_instances_under_singular_and_non_finite_transforms(orc, gpu_api, kind):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("family", ["hull", "lattice"])
-@pytest.mark.parametrize("seed", __import__("seeds").seeds(list(range(6)), 30))
+@pytest.mark.parametrize("seed", __import__("seeds").seeds(list(range(6)), 14))
 def test_films_of_hull_and_lattice_scenes(orc, gpu_api, family, seed):
     """the scenes of tests/hull_rays.py RENDERED (24 x 16, two launches of two samples, five bounces, environment light): a camera 0.3 / 1.5 / 4 radii from an instance under
     a scaled, sheared, far-away transform, or on the half-integer lattice looking along a lattice direction — hits at t ~ 0, shading frames under transforms that lose six
-    digits, paths that leave a surface along it.  Film and ray counts against the oracle"""
+    digits, paths that leave a surface along it.  Film and ray counts against the oracle.
+    OPEN at the end of round 5 (profiles/r05_fuzz_sweeps.txt): in 4 of 6 002 such scenes (seeds 6200053 lattice; 6200851, 6201195, 6201640 hull) one or two pixels differ, and
+    the oracle agrees with its own exhaustive search on all four — the product drops a hit the triangle test takes.  Not yet located."""
     import hull_rays
     oc = orc.Context(threads=8); gc = gpu_api.Context()
     rs = np.random.default_rng(seed + 9)
@@ -1028,9 +1032,9 @@ def test_films_of_hull_and_lattice_scenes(orc, gpu_api, family, seed):
     else:
         S = float(hull_rays.lattice_scale(seed))
         if not 1e-10 < S < 1e10:
-            pytest.skip("a camera needs a frame: the lattice at 2^+-62 is for rays only")
+            S = 1.0                                                                 # (a camera needs a frame: the lattice at 2^+-40 and 2^+-62 is for rays only)
         for c in (oc, gc):
-            hull_rays.lattice_scene(c, seed, baked=seed % 3 == 2)
+            hull_rays.lattice_scene(c, seed, baked=seed % 3 == 2, scale=S)
         eye = rs.integers(-6, 7, 3) * 0.5 * S; fwd = rs.integers(-2, 3, 3) * 1.0
         if not fwd.any():
             fwd = np.array([1.0, 0, 0])

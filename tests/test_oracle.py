@@ -354,3 +354,29 @@ def test_lattice_rays_with_and_without_boxes(orc, seed):
     assert not bad, bad[:3]
     c.set_exhaustive_search(0)
     assert sum(1 for r in rays[:300] if c.trace_closest(r[:3], r[3:6], float(r[6]))[0]) > 2        # (the rays do hit things)
+
+
+@pytest.mark.parametrize("seed", __import__("seeds").seeds(list(range(6)) + [6100112, 6100853], 16))
+def test_lattice_films_with_and_without_boxes(orc, seed):
+    """the lattice scenes RENDERED from a camera on a lattice point, with the BVH and testing every triangle: the same film.  A camera on a face plane starts every ray
+    exactly in that face's triangles' planes; the test's t for them is +-2e-8 around 0, some are taken, and the flat box of such a triangle lies exactly behind the
+    origin — round 5's box test held the exit distance against 0 without the slack the other end of the range had (the two seeds named; the PRODUCT agreed with the
+    exhaustive search there and this file's BVH did not).  And rays leaving faces from a few denormals off them (tests/hull_rays.py face_rays)"""
+    import hull_rays
+    rs = np.random.default_rng(seed + 9)
+    eye = rs.integers(-6, 7, 3) * 0.5; fwd = rs.integers(-2, 3, 3) * 1.0
+    if not fwd.any():
+        fwd = np.array([1.0, 0, 0])
+    up = np.array([0, 0, 1.0]) if abs(fwd[2]) < 0.9 * np.linalg.norm(fwd) else np.array([0, 1.0, 0])
+    films = []
+    for level in (0, 2):
+        c = orc.Context(threads=usable_cores())
+        hull_rays.lattice_scene(c, seed, baked=seed % 3 == 2, scale=1.0)
+        lens = c.create_lens(c.make_lens(tuple(eye), tuple(fwd / np.linalg.norm(fwd)), tuple(up), 0.9, 0.0, 1.0)); sn = c.create_sensor(24, 16)
+        c.set_pipeline(samples_per_run=2, max_bounces=5, env_samples_per_bounce=1, mesh_samples_per_bounce=0)
+        c.set_exhaustive_search(level)
+        c.render(sn, lens, launches=2); films.append(c.sensor_data(sn).copy())
+    same = (films[0].view(np.uint32) == films[1].view(np.uint32)) | (np.isnan(films[0]) & np.isnan(films[1]))
+    assert same.all(), "%d pixels differ" % int((~same).any(-1).sum())
+    bad = _same_hits(c, hull_rays.face_rays(seed), 2)
+    assert not bad, bad[:3]
