@@ -408,6 +408,14 @@ class Context:
     def reset_stats(self):
         self.L.MsneResetStats(self.h)
 
+    def set_max_inflight(self, paths):
+        """most paths traced concurrently (batches of launches are cut to fit; the default is 160 Mi)"""
+        if self.L.MsneSetMaxInflight(self.h, int(paths)) != 0:
+            self._err("MsneSetMaxInflight")
+
+    def max_inflight(self):
+        return int(self.L.MsneGetMaxInflight(self.h))
+
     def counters(self):
         s = self.stats()
         return {"closest_rays": s["closest_rays"], "shadow_rays": s["shadow_rays"], "samples": s["samples"]}

@@ -390,6 +390,13 @@ __device__ __forceinline__ uint8_t grid_exponent(float lo, float hi) {
     if (ex > 254) ex = 254;
     return (uint8_t)ex;
 }
+// No axis of a grid finer than a quarter of its coarsest: a node of coplanar children (extent 0 in one axis: quantum 2^-126) otherwise has NO margin in that axis, and the
+// triangle test's t is only good to ~1e-7 of the triangle's size — a ray that starts in such a triangle's plane is given t = +2e-8 by it and was already out of the box
+// ("The oracle, corrected by the product").  With this the flat axis keeps 1e-3 quantum = ~1e-6 of the node's largest extent.
+__device__ __forceinline__ void grid_no_axis_much_finer(uint8_t e[3]) {
+    const int em = max((int)e[0], max((int)e[1], (int)e[2]));
+    for (int k = 0; k < 3; k++) if ((int)e[k] < em - 2) e[k] = (uint8_t)(em - 2);
+}
 __device__ __forceinline__ float grid_origin(float lo, uint8_t ex) {
     const float o = lo - u2f((uint32_t)ex << 23);
     return (o == o && o > -3.0e38f) ? o : lo;   // (a box at the end of the range or not a number: as it is)
@@ -458,8 +465,9 @@ __global__ void k_collapse(const CollapseWork* work, uint32_t nwork, CollapseWor
 
     Node8 nd;
     uint8_t e[3]; float inv_s[3], grid_o[3];
+    for (int k = 0; k < 3; k++) e[k] = grid_exponent(nb.lo[k], nb.hi[k]);
+    grid_no_axis_much_finer(e);
     for (int k = 0; k < 3; k++) {
-        e[k] = grid_exponent(nb.lo[k], nb.hi[k]);
         inv_s[k] = u2f((uint32_t)(254 - e[k]) << 23);   // 2^-(ex-127)
         grid_o[k] = grid_origin(nb.lo[k], e[k]);
     }
@@ -1223,7 +1231,9 @@ __device__ __forceinline__ void refit_node(Node8* nodes, uint32_t n, const Refit
         Box u;
         for (int k = 0; k < 3; k++) { u.lo[k] = 3.0e38f; u.hi[k] = -3.0e38f; }
         for (uint32_t s = 0; s < 8; s++) if ((used >> s) & 1u) for (int k = 0; k < 3; k++) { u.lo[k] = fminf(u.lo[k], cb[s].lo[k]); u.hi[k] = fmaxf(u.hi[k], cb[s].hi[k]); }
-        for (int k = 0; k < 3; k++) { e[k] = grid_exponent(u.lo[k], u.hi[k]); origin[k] = grid_origin(u.lo[k], e[k]); }   // (the grid k_collapse would choose)
+        for (int k = 0; k < 3; k++) e[k] = grid_exponent(u.lo[k], u.hi[k]);   // (the grid k_collapse would choose)
+        grid_no_axis_much_finer(e);
+        for (int k = 0; k < 3; k++) origin[k] = grid_origin(u.lo[k], e[k]);
         nd.ox = origin[0]; nd.oy = origin[1]; nd.oz = origin[2];
         nd.ex = e[0]; nd.ey = e[1]; nd.ez = e[2];
         for (uint32_t s = 0; s < 8; s++) if ((used >> s) & 1u) {

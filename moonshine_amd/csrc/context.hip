@@ -180,6 +180,14 @@ struct HdMoonshine {
     int trace_grid = 1024, shade_grid = 2048, shade_k_grid = 2048;
     uint32_t refill = 16;              // traversal: idle lanes (of 64) at which a wave refills from the ray queue; $MSNE_REFILL
     size_t max_inflight = 160u << 20;  // most paths traced concurrently (288 B of wavefront state each at one env + one mesh light sample, allocated on demand); $MSNE_MAX_INFLIGHT
+    // ... and what a batch may hold of it: a path names its first shadow-queue entry by a position of SHQ_POS_BITS bits (msne_device.h shq_pack), a pipe's shadow queue
+    // holds (env + mesh samples) entries per path of its capacity (the paths rounded up to a round of sub-queue tiles: ensure_wavefront), so capacity x samples stays below
+    // 2^SHQ_POS_BITS.  One sub-queue, 1 + 1 samples: 2 Gi paths, far above the default; eight sub-queues and 4 + 4 samples: 64 Mi — batches get smaller, nothing wraps.
+    size_t inflight_budget() const {
+        const size_t ns = std::max(1u, opts.env_samples + opts.mesh_samples), slack = 256 + (size_t)QUEUE_SUBS * 256;
+        const size_t most = ((size_t)1 << SHQ_POS_BITS) / ns;
+        return std::max<size_t>(1, std::min(max_inflight, most > 2 * slack ? most - slack : most / 2));
+    }
     // statistics
     MsneStats stats{};
     bool profile = false, trace_stats = false;
@@ -732,6 +740,10 @@ bool HdMoonshine::ensure_wavefront(size_t npaths, size_t slots, int npipes) {
             pp.cap = c; pp.shq_samples = 0;
         }
         const uint32_t ns = std::max(1u, opts.env_samples + opts.mesh_samples);   // shadow-queue entries per path
+        if ((unsigned long long)ns * pp.cap > (1ull << SHQ_POS_BITS)) {   // (only a film of more pixels than inflight_budget() gets here: one sample of it is the smallest batch)
+            fail("film too large for the light-sample queue: " + std::to_string(pp.cap) + " paths x " + std::to_string(ns) + " light samples per bounce exceed 2^" + std::to_string(SHQ_POS_BITS) + " entries");
+            return false;
+        }
         if (ns > pp.shq_samples) {
             if (!pp.shq_f.alloc(4 * 4 * (size_t)ns * pp.cap)) { pp.shq_samples = 0; fail("out of device memory (shadow queue)"); return false; }
             pp.shq_samples = ns;
@@ -797,6 +809,7 @@ bool HdMoonshine::render(uint32_t sensor, uint32_t lens, uint32_t launches, bool
     // film in launch order by k_film — bit-identical to nb sequential dispatches, because the RNG is keyed by the sample
     // index, main.hlsl:85); a launch too large for the in-flight budget is split into chunks of its samples instead.
     const size_t per_launch = P * (size_t)spr;
+    const size_t max_inflight = inflight_budget();   // (shadows the member: the shadow queue's 32-bit positions bound a batch too)
     const uint32_t max_batch = per_launch <= max_inflight ? (uint32_t)std::max<size_t>(1, max_inflight / per_launch) : 1u;
     const uint32_t chunk = per_launch <= max_inflight ? spr : (uint32_t)std::max<size_t>(1, max_inflight / P);
     const uint32_t first_batch = chunk == spr ? std::min<uint32_t>(max_batch, launches) : 1u;
@@ -1140,11 +1153,12 @@ int MsneReserve(HdMoonshine* c, SensorHandle sh, uint32_t launches) {
     if (!c->bind() || sh >= c->sensors.size()) return -1;
     const size_t P = c->sensors[sh]->shard.pixels, per_launch = P * (size_t)c->opts.samples_per_run;
     if (per_launch == 0) return 0;
-    const size_t nb = per_launch <= c->max_inflight ? std::min<size_t>(std::max<size_t>(1, c->max_inflight / per_launch), std::max<uint32_t>(launches, 1)) : 1;
-    const size_t n = per_launch <= c->max_inflight ? per_launch * nb : P * std::max<size_t>(1, c->max_inflight / P);
+    const size_t budget = c->inflight_budget();
+    const size_t nb = per_launch <= budget ? std::min<size_t>(std::max<size_t>(1, budget / per_launch), std::max<uint32_t>(launches, 1)) : 1;
+    const size_t n = per_launch <= budget ? per_launch * nb : P * std::max<size_t>(1, budget / P);
     const uint32_t nbu = (uint32_t)nb;
-    const int K = (per_launch > c->max_inflight || nbu < 2 || per_launch * nbu >= c->single_pipe_paths) ? 1 : (int)std::min<uint32_t>((uint32_t)c->n_pipes, nbu);
-    const size_t per_pipe = per_launch <= c->max_inflight ? per_launch * ((nbu + K - 1) / K) : n;
+    const int K = (per_launch > budget || nbu < 2 || per_launch * nbu >= c->single_pipe_paths) ? 1 : (int)std::min<uint32_t>((uint32_t)c->n_pipes, nbu);
+    const size_t per_pipe = per_launch <= budget ? per_launch * ((nbu + K - 1) / K) : n;
     return c->ensure_wavefront(per_pipe, n, K) ? 0 : -1;
 }
 int MsneSetMaxInflight(HdMoonshine* c, uint64_t paths) {

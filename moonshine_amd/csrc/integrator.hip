@@ -178,7 +178,7 @@ __global__ __launch_bounds__(SHADE_BLOCK, shade_spec_wps(SPEC, TEX)) void k_shad
                     // and zeroed by k_trace_shadow if the ray was blocked.  Added HERE, by the thread that owns the queue entry, as soon as the entry's flags and sample
                     // position are in: the fetches run next to the hit / geometry / material chain below instead of after the sort
                     if (fl & PATH_FLAG_NEE) {
-                        const uint32_t pq = sq_own.y & 0x0fffffffu, pk = sq_own.y >> 28;   // position in its sub-queue | sub-queue
+                        const uint32_t pq = shq_pos(sq_own.y), pk = shq_sub(sq_own.y);   // position in its sub-queue | sub-queue (msne_device.h shq_pack)
                         const uint32_t ps = (fl >> PATH_STRIDE_SHIFT) & 0x1ffu;
                         for (uint32_t k = 0; k < n_nee; k++) { const float4 c = nt_load(&c_prev[queue_slot(pq + k * ps, pk)]); lr_own.x = lr_own.x + c.x; lr_own.y = lr_own.y + c.y; lr_own.z = lr_own.z + c.z; }
                     }
@@ -424,7 +424,7 @@ __global__ __launch_bounds__(SHADE_BLOCK, shade_spec_wps(SPEC, TEX)) void k_shad
             if (sample.pdf == 0.0f) {
                 // the path ends here; with light samples in flight it is finalised one pass later (after their shadow rays)
                 if (TRUNC == 0) atomicAdd(&cnt[1].zombies, 1u);
-                if (valid) { st4(&nxt.ro[j], make_float4(0.0f, 0.0f, 0.0f, u2f(PATH_FLAG_ZOMBIE | PATH_FLAG_NEE | (stride << PATH_STRIDE_SHIFT)))); st4(&nxt.lr[j], make_float4(L.x, L.y, L.z, 0.0f)); st2(&nxt.sq[j], make_uint2(slot, q | (kq << 28))); }
+                if (valid) { st4(&nxt.ro[j], make_float4(0.0f, 0.0f, 0.0f, u2f(PATH_FLAG_ZOMBIE | PATH_FLAG_NEE | (stride << PATH_STRIDE_SHIFT)))); st4(&nxt.lr[j], make_float4(L.x, L.y, L.z, 0.0f)); st2(&nxt.sq[j], make_uint2(slot, shq_pack(q, kq))); }
                 else { st4(&nxt.ro[j], make_float4(0.0f, 0.0f, 0.0f, u2f(PATH_FLAG_ZOMBIE | PATH_FLAG_DEAD))); st4(&lbuf[slot], make_float4(L.x, L.y, L.z, 0.0f)); }
             } else {
                 const f3 nd = frame_frame_to_world(shadingFrame, sample.dirFs);
@@ -434,7 +434,7 @@ __global__ __launch_bounds__(SHADE_BLOCK, shade_spec_wps(SPEC, TEX)) void k_shad
                 const f3 tp = mul(throughput, F3(f.x * ac / sample.pdf, f.y * ac / sample.pdf, f.z * ac / sample.pdf));
                 const uint32_t nf = ((bounceCount + 1u) & 0xFFFFu) | (delta ? PATH_FLAG_DELTA : 0u) | (nee ? (PATH_FLAG_NEE | (stride << PATH_STRIDE_SHIFT)) : 0u);
                 st4(&nxt.ro[j], make_float4(no.x, no.y, no.z, u2f(nf))); st4(&nxt.rd[j], make_float4(nd.x, nd.y, nd.z, 0.0f));
-                st4(&nxt.tp[j], make_float4(tp.x, tp.y, tp.z, sample.pdf)); st4(&nxt.lr[j], make_float4(L.x, L.y, L.z, u2f(rng))); st2(&nxt.sq[j], make_uint2(slot, q | (kq << 28)));
+                st4(&nxt.tp[j], make_float4(tp.x, tp.y, tp.z, sample.pdf)); st4(&nxt.lr[j], make_float4(L.x, L.y, L.z, u2f(rng))); st2(&nxt.sq[j], make_uint2(slot, shq_pack(q, kq)));
             }
         }
     }

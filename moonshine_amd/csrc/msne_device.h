@@ -188,7 +188,7 @@ struct PathState {
     float4* rd;     // ray direction xyz | w unused
     float4* tp;     // throughput rgb | w = pdf of the last BSDF sample
     float4* lr;     // accumulated radiance rgb | w = rng state (bit pattern)
-    uint2* sq;      // x = sample slot (s_local * pixels + pixel_local), y = first of the path's light-sample entries in the shadow queue: position in its sub-queue | sub-queue << 28
+    uint2* sq;      // x = sample slot (s_local * pixels + pixel_local), y = first of the path's light-sample entries in the shadow queue: shq_pack(position in its sub-queue, sub-queue)
     // flags (in ro.w): bits 0..15 bounce count, bit 16 last material delta, bit 17 no ray (finalise only), bit 18 masked,
     // bit 19 light samples pending (env_samples + mesh_samples entries from sq.y, PATH_STRIDE apart), bit 20 dead
 };
@@ -235,6 +235,15 @@ struct ShadowQueue {
 #define MSNE_QUEUE_SUBS 1
 #endif
 constexpr uint32_t QUEUE_SUBS = MSNE_QUEUE_SUBS, QUEUE_TILE_SHIFT = 8u;   // (a power of two; 1 = one head per queue, as before round 5)
+static_assert(QUEUE_SUBS >= 1u && (QUEUE_SUBS & (QUEUE_SUBS - 1u)) == 0u && QUEUE_SUBS <= 256u, "QUEUE_SUBS: a power of two");
+// A path names its first shadow-queue entry in ONE word: position in its sub-queue | sub-queue in the top log2(QUEUE_SUBS) bits — with one sub-queue the position keeps all
+// 32 bits (round 5 packed 28 | 4 in every build: a 1080p batch of 65 launches at 1 + 1 light samples passes 2^28 entries and read another path's samples; advisor, round 5).
+// The host keeps a batch's shadow queue below 2^SHQ_POS_BITS entries (context.hip inflight_budget).
+constexpr uint32_t queue_sub_bits(uint32_t n) { return n <= 1u ? 0u : 1u + queue_sub_bits(n >> 1); }
+constexpr uint32_t QUEUE_SUB_BITS = queue_sub_bits(QUEUE_SUBS), SHQ_POS_BITS = 32u - QUEUE_SUB_BITS;
+MSNE_HD uint32_t shq_pack(uint32_t pos, uint32_t sub) { return QUEUE_SUB_BITS ? (pos | (sub << (SHQ_POS_BITS & 31u))) : pos; }
+MSNE_HD uint32_t shq_pos(uint32_t w) { return QUEUE_SUB_BITS ? (w & (0xffffffffu >> QUEUE_SUB_BITS)) : w; }
+MSNE_HD uint32_t shq_sub(uint32_t w) { return QUEUE_SUB_BITS ? (w >> (SHQ_POS_BITS & 31u)) : 0u; }
 struct alignas(128) QueueHead { uint32_t n_paths, n_shadow; uint32_t pad[30]; };   // (adjacent: ONE 64-bit atomic per workgroup appends to both)
 struct alignas(128) BounceCounters {
     QueueHead sub[QUEUE_SUBS];           // path entries | shadow-queue entries of this bounce's queues, per sub-queue
