@@ -15,8 +15,9 @@ Timed region: EXACTLY `steps` steps, bracketed by barrier + synchronize on both 
 repeated `--repeats` times (default 5, SURVEY.md §8(d): "median of >= 5 runs") on a cleared sensor; `value` is the median
 repeat, every repeat is listed in `repeat_values`.
 After the headline (N = 1, S1, constant environment): `other_configs` = the same K-step batch on BASELINE.json's other single-GPU configurations — S2 (configs[4]: 10.24 M
-instanced triangles) and S1 under the image environment — each in a context of its own, median of 3 (`--no-other-configs` skips them; never the headline `value`);
-`--sustain-seconds S`: the batch back to back for >= S seconds (`sustained`: rate per 1-s window, shader clock probed while it runs).
+instanced triangles), S1 under the image environment and the configs[2] stand-in (textured, GLB + PIZ EXR through the importers) — each in a context of its own, median of 3
+(`--no-other-configs` skips them; never the headline `value`); `--sustain-seconds S` (default 3): the batch back to back for >= S seconds (`sustained`: rate per 1-s window,
+shader clock probed while it runs; 0 = off).
 """
 import argparse
 import json
@@ -45,12 +46,33 @@ def build_scene(ctx, a):
     return scenes.s1(ctx, extent=(a.width, a.height), env=a.env)
 
 
+def standin_files():
+    """the configs[2] stand-in (the Salle-de-bain asset exists nowhere offline: SURVEY.md §8(d) "asset substituted") written to a scratch directory: a GLB of 983 052
+    textured triangles in 54 transformed instances, 196 PNG textures, and a 2048x1024 PIZ-compressed HDR environment — the generator the parity tests use
+    (tests/io_common.py write_bathroom_standin; about ten seconds of host time, outside every timed region)"""
+    import tempfile
+    from tests import io_common as io
+    d = tempfile.mkdtemp(prefix="msne_standin_")
+    glb, exr = os.path.join(d, "bath.glb"), os.path.join(d, "sky.exr")
+    io.write_bathroom_standin(glb, exr)
+    return glb, exr
+
+
 def other_config(a, dev, scene, env):
     """BASELINE.json's other single-GPU configuration(s) in the same record (never the headline `value`): the same K-step batch on another scene, median of 3 repeats,
-    in a context of its own after the headline measurement is over.  configs[4] = S2, the 10 M-triangle instanced traversal stress."""
+    in a context of its own after the headline measurement is over.  configs[4] = S2, the 10 M-triangle instanced traversal stress; "standin" = configs[2]'s workload on
+    the substituted asset (textured k_shade instantiation, image environment with the mip descent, GLB + EXR importers)."""
     b = argparse.Namespace(scene=scene, env=env, width=a.width, height=a.height, steps=a.steps)
     c = api.Context(device=dev)
-    sensor, lens = build_scene(c, b)
+    if scene == "standin":
+        glb, exr = standin_files()
+        lens, _ = c.load_glb(glb); c.set_background_exr(exr)
+        sensor = c.create_sensor(a.width, a.height)
+        name = ("configs[2] stand-in (asset substituted): 983 052 textured triangles in 54 instances, 196 PNG textures, 2048x1024 PIZ HDR environment"
+                ", %dx%d, %d spp, max_bounces 8, env+mesh NEE with MIS" % (a.width, a.height, a.steps))
+    else:
+        sensor, lens = build_scene(c, b)
+        name = workload_name(b)
     c.set_pipeline(samples_per_run=1, max_bounces=8, env_samples_per_bounce=1, mesh_samples_per_bounce=1)
     c.render(sensor, lens, launches=0, readback=False)
     c.set_profiling(kernel_events=False, traversal_counters=False)
@@ -66,7 +88,7 @@ def other_config(a, dev, scene, env):
     st = c.stats(); dt = statistics.median(ts)
     rays = (st["closest_rays"] + st["shadow_rays"]) / 3.0
     c.close()
-    return {"workload": workload_name(b), "value": rays / dt / 1e6, "unit": "Mrays/s", "ms_per_step": dt / a.steps * 1e3, "steps": a.steps, "repeats": 3,
+    return {"workload": name, "value": rays / dt / 1e6, "unit": "Mrays/s", "ms_per_step": dt / a.steps * 1e3, "steps": a.steps, "repeats": 3,
             "msamples_per_s": st["samples"] / 3.0 / dt / 1e6}
 
 
@@ -219,7 +241,7 @@ def main():
     ap.add_argument("--env", default="constant", choices=["constant", "sky"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-other-configs", action="store_true", help="skip the secondary single-GPU configurations (S2, S1 under the sky) reported next to the headline")
-    ap.add_argument("--sustain-seconds", type=float, default=0.0,
+    ap.add_argument("--sustain-seconds", type=float, default=3.0,
                     help="after the timed repeats: back-to-back K-step batches for at least this long, reported as `sustained` (rate per 1-s window, shader clock at both ends); 0 = off")
     ap.add_argument("--dump-film", default=None, help="rank 0 saves the assembled film of the last repeat here (.npy): parity tests of the gather path")
     a = ap.parse_args()
@@ -289,15 +311,18 @@ def main():
     gather()
     warm = ctx.stats()
     ctx.reset_stats()
-    times = []
+    times, t_render, t_gather = [], [], []
     for _ in range(max(a.repeats, 1)):
         ctx.clear_sensor(sensor)
         sync()
         t0 = time.perf_counter()
         ctx.render(sensor, lens, launches=a.steps, readback=False)   # EXACTLY K steps; returns after the stream is idle
+        t1 = time.perf_counter()
         gather()
+        t2 = time.perf_counter()
         sync()
         times.append(time.perf_counter() - t0)
+        t_render.append(t1 - t0); t_gather.append(t2 - t1)           # this rank's own share: its K steps, then the gather (a sender returns once its film is handed over; rank 0 also unpacks)
     st = ctx.stats()          # sums over the repeats (every repeat traces the same rays: same sample indices)
     R = len(times)
     # attribution pass (outside the timed region): the same K steps once more with the kernels in STREAM ORDER, so that each kernel's HIP-event
@@ -308,6 +333,11 @@ def main():
     ctx.render(sensor, lens, launches=a.steps, readback=False)
     sync()
     sa = ctx.stats()
+    # ... and what each bounce of this rank's shard cost in that pass: launches arrive as closest(b), shade(b), shadow(b) per batch (moonshine_amd.h MsneGetLaunchTimes)
+    NB = 8 + 2                                                         # max_bounces + 2 passes per batch (HdMoonshine::render max_iter)
+    per_bounce = {0: [0.0] * NB, 1: [0.0] * NB, 2: [0.0] * NB}; seen = {0: 0, 1: 0, 2: 0}
+    for kind, ms in ctx.launch_times():
+        per_bounce[kind][seen[kind] % (NB - 1 if kind == 1 else NB)] += ms; seen[kind] += 1
     ctx.set_profiling(kernel_events=False, traversal_counters=False)
 
     # A render is seconds of launches (offline/main.zig:131-165), the timed region above a burst of tens of milliseconds: with --sustain-seconds S the same K-step batch
@@ -359,6 +389,18 @@ def main():
         devices_seen = int(tmax[R + 4:].sum())
     else:
         devices_seen = 1
+    # every rank's own numbers, so that a scaling result below the prediction can be attributed from the one line: its K steps (median repeat), its gather, the
+    # attribution pass by bounce — the thin late bounces of a small shard are where DESIGN.md section 7 expects the loss
+    mine = torch.tensor([statistics.median(t_render) * 1e3, statistics.median(t_gather) * 1e3, sa["render_ms"], float(st["closest_rays"] + st["shadow_rays"]) / R]
+                        + per_bounce[0] + per_bounce[2] + per_bounce[1], dtype=torch.float64, device="cuda")
+    if world > 1:
+        allr = [torch.empty_like(mine) for _ in range(world)]
+        dist.all_gather(allr, mine)
+    else:
+        allr = [mine]
+    per_rank = [{"rank": r, "render_ms": float(v[0]), "gather_ms": float(v[1]), "render_ms_stream_order": float(v[2]), "rays": float(v[3]),
+                 "closest_ms_by_bounce": [round(float(x), 4) for x in v[4:4 + NB]], "shade_ms_by_bounce": [round(float(x), 4) for x in v[4 + NB:4 + 2 * NB]],
+                 "shadow_ms_by_bounce": [round(float(x), 4) for x in v[4 + 2 * NB:4 + 3 * NB - 1]]} for r, v in enumerate(allr)]
     closest, shadow, samples = float(tt[R]), float(tt[R + 1]), float(tt[R + 2])     # per repeat, all ranks
     ranks_seen = int(round(float(tt[R + 3])))                                         # ranks that took part in the reduction (counted, not assumed)
     rays = closest + shadow
@@ -455,6 +497,8 @@ def main():
             "msamples_per_s": samples / dt / 1e6,
             "rays": {"closest": closest, "shadow": shadow, "per_sample": rays / max(samples, 1.0)},
             "roofline": roof, "build": build_ms,
+            # per rank: wall time of its own K steps and of its gather in the median repeat; the stream-order pass by bounce (sums over the batch's launches of that bounce)
+            "per_rank": per_rank,
             "whole_path_roofline_frac": (rays / dt * fx["B_ray"] + samples / dt * (fx["B_shade"] + 32)) / HBM_PEAK / world,
             "kernel_ms_stream_order": {k: kms[k] for k in KERNELS}, "render_ms_stream_order": sa["render_ms"], "render_ms_per_repeat": st["render_ms"] / R,
             "kernel_hbm_algorithmic_frac": {k: unit_bytes[k] * kun[k] / max(kms[k] * 1e-3, 1e-12) / HBM_PEAK for k in KERNELS},
@@ -468,7 +512,7 @@ def main():
             out["sustained"] = sustained     # this rank's batches (at N > 1 every rank runs the same loop, gather included)
         if world == 1 and a.scene == "s1" and a.env == "constant" and not a.no_other_configs:
             # the other single-GPU configurations of BASELINE.json, measured after the headline (a second or two): configs[4] (S2) and S1 under the image environment
-            out["other_configs"] = {"s2": other_config(a, dev, "s2", "constant"), "s1_sky": other_config(a, dev, "s1", "sky")}
+            out["other_configs"] = {"s2": other_config(a, dev, "s2", "constant"), "s1_sky": other_config(a, dev, "s1", "sky"), "standin": other_config(a, dev, "standin", "image")}
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(a)
         print(json.dumps(out))

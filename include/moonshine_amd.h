@@ -295,6 +295,9 @@ int MsneGetTraversalCounters(HdMoonshine*, uint64_t out[20]); /* [0..3] closest 
 int MsneGetTraversalLaneUse(HdMoonshine*, uint64_t out[24]);
 /* queue lengths of the last batch, per bounce b: out[4b..4b+3] = {path-queue entries, of which entries without a ray, shadow-queue entries, shadow rays traced}; returns the number of bounces written */
 int MsneGetBounceCounters(HdMoonshine*, uint32_t* out, uint32_t max_bounces);
+/* the last render made with kernel events on: its k_trace_closest (kind 0) / k_trace_shadow (1) / k_shade (2) launches in issue order — closest(b), shade(b), shadow(b)
+   for b = 0, 1, ... — and each one's duration in ms; returns the number written */
+int MsneGetLaunchTimes(HdMoonshine*, int32_t* kinds, float* ms, uint32_t max_launches);
 /* rays: 7 floats each (origin, direction, tmax); out_ids: 4 per ray {hit, instance, geometry, primitive}; out_tuv: 3 per ray */
 int MsneTraceRays(HdMoonshine*, const float* rays, uint32_t n, int any_hit, uint32_t* out_ids, float* out_tuv);
 /* Batch probe of the device-side shading functions (the material.hlsl / light.hlsl / mappings.hlsl / math.hlsl restatements that

@@ -145,6 +145,7 @@ SYMBOLS = [
     ("MsneReadEnv", C.c_int, [_vp, _vp, _vp]),
     ("MsneGetAliasTable", _u32, [_vp, _vp, _u32]),
     ("MsneGetBounceCounters", C.c_int, [_vp, _vp, _u32]),
+    ("MsneGetLaunchTimes", C.c_int, [_vp, _vp, _vp, _u32]),
     ("MsneGetPackedFilmStride", C.c_uint64, [_vp, _u32]),
     ("MsneSetMaxInflight", C.c_int, [_vp, C.c_uint64]),
     ("MsneGetMaxInflight", C.c_uint64, [_vp]),
@@ -484,6 +485,12 @@ class Context:
         if n < 0:
             self._err("MsneGetBounceCounters")
         return out[:n]
+
+    def launch_times(self, max_launches=4096):
+        """[(kind, ms)] of the last render made with kernel events on: 0 = k_trace_closest, 1 = k_trace_shadow, 2 = k_shade, in issue order (closest(b), shade(b), shadow(b), ...)"""
+        kinds = np.zeros(max_launches, np.int32); ms = np.zeros(max_launches, np.float32)
+        n = self.L.MsneGetLaunchTimes(self.h, _ptr(kinds), _ptr(ms), max_launches)
+        return [(int(kinds[i]), float(ms[i])) for i in range(max(n, 0))]
 
     def shade_probe(self, fn, win, wout, x):
         """batch probe of the device shading functions (MsneShadeProbe): x (n, win) float32 -> (n, wout) float32"""

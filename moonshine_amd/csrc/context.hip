@@ -142,6 +142,20 @@ struct HdMoonshine {
     BuildScratch* build_scratch = nullptr;                // this context's BVH build buffers: nothing is shared between contexts
     uint32_t tlas_root = MAX_UINT, root_in_blas = 0, n_tlas_items = 0;
     float coord_radius = 0.0f;   // bound on the absolute vertex coordinates of the built scene, in world space and in every BLAS's object space (SceneView::coord_slack)
+    // Ray origins and the instances' culling volumes (instance_cull_pad: the |o| term).  Secondary rays start on surfaces — inside coord_radius; PRIMARY rays start where the
+    // caller puts them (intersection.hlsl:20: TraceRay takes any origin), and the host knows where before it launches anything: the lens of a render or a pick, the origins
+    // handed to MsneTraceRays.  `origin_needed` is that call's largest origin coordinate; the TLAS in use was baked for `baked_origin_reach` (16 x coord_radius at least —
+    // ordinary cameras never get here); an origin beyond it re-bakes every pad and sphere for twice what was asked (`origin_reach_floor`, kept: a camera that keeps backing
+    // away re-bakes at every doubling, not at every frame).  A TLAS-only rebuild: the BLASes are cached, 17 ms for 100 000 instances.
+    float origin_needed = 0.0f, origin_reach_floor = 0.0f, baked_origin_reach = 0.0f;
+    float origin_reach_wanted() {
+        if (origin_needed > 16.0f * coord_radius && origin_needed > origin_reach_floor) origin_reach_floor = 2.0f * origin_needed;
+        return std::min(std::max(16.0f * coord_radius, origin_reach_floor), 3.0e38f);   // (a scene with a coordinate beyond 2e37: the product must stay finite, or every instance's slack is infinite)
+    }
+    void need_origin(float x, float y, float z, float extra = 0.0f) {   // (NaN and infinite origins hit nothing in any space: they ask for nothing)
+        const float m = fmaxf(fmaxf(fabsf(x), fabsf(y)), fabsf(z)) + fabsf(extra);
+        if (m < 1.5e38f && m > origin_needed) origin_needed = m;
+    }
     // in-place TLAS update (Accel.zig:567-601): transform edits since the last build, and what a refit needs of that build
     std::vector<uint32_t> transform_edits;
     std::vector<char> built_in_world; std::vector<uint32_t> item_of_instance;   // per instance, as of the last rebuild (MAX_UINT: not in the TLAS)
@@ -194,6 +208,7 @@ struct HdMoonshine {
     std::vector<hipEvent_t> events; size_t events_used = 0;
     struct Span { size_t a, b; int kind; };
     std::vector<Span> spans;
+    std::vector<std::pair<int, float>> launch_times;   // the last profiled render's trace / shade launches in issue order: {kind, ms} (MsneGetLaunchTimes)
 
     void fail(const std::string& m) { last_error = m; if (getenv("MSNE_VERBOSE")) fprintf(stderr, "moonshine_amd: %s\n", m.c_str()); }
     void clear_all_sensors() { for (auto* s : sensors) s->sample_count = 0; }   // Camera.clearAllSensors Camera.zig:73-77
@@ -360,7 +375,7 @@ static float coord_reach(const m34& T, const float box[6]) {
 // Every world-space volume an instance is culled by (its TLAS leaf box and, through it, the boxes above; its bounding sphere) is grown by this much
 // (bvh_build.hip k_instance_boxes).  Well-conditioned transforms: a few ulps of the coordinates.  A shear between scales 1e6 apart, or an instance a few ulps of its own
 // coordinates wide: as large as the instance — nothing is culled there, which is the contract (the oracle's search without boxes, tests/test_oracle.py).  Ray origins
-// farther out than origin_reach (16 x the scene's largest coordinate) are outside what is baked: DESIGN.md section 2.
+// farther out than origin_reach are the host's business: it knows every primary origin before it launches (HdMoonshine::need_origin) and re-bakes; DESIGN.md section 2.
 static float instance_cull_pad(const m34& T, const float box[6], float origin_reach) {
     if (is_identity(T)) return 0.0f;   // (the traversal does not transform at all: trace.hip `ident`)
     const m34 W = m34_inverse_affine(T);
@@ -562,7 +577,10 @@ bool HdMoonshine::rebuild_accel() {
             add_box(ident, bi.box, (uint32_t)N, nullptr);
         }
     }
-    for (TlasInst& t : tinst) { m34 T; memcpy(&T, t.T, 48); t.cull_pad = instance_cull_pad(T, t.blas_box, std::min(16.0f * coord_radius, 3.0e38f)); }   // (a scene with a coordinate beyond 2e37: the product must stay finite, or every instance's slack is infinite)
+    baked_origin_reach = origin_reach_wanted();
+    bool padded = false;
+    for (TlasInst& t : tinst) { m34 T; memcpy(&T, t.T, 48); t.cull_pad = instance_cull_pad(T, t.blas_box, baked_origin_reach); padded = padded || t.cull_pad != 0.0f; }
+    if (!padded) baked_origin_reach = 3.0e38f;   // (identity instances only — S1: the traversal never changes space, nothing was grown for anything)
     lap("instance records");
     if (!d_instances.alloc(irec.size())) { fail("out of device memory (instances)"); return false; }
     CHECK_HIP(this, hipMemcpyAsync(d_instances.p, irec.data(), irec.size() * sizeof(InstanceRec), hipMemcpyHostToDevice, stream));
@@ -647,7 +665,10 @@ bool HdMoonshine::refit_tlas() {
         tinst.push_back(t); items.push_back(item_of_instance[h]);
         coord_radius = std::max(coord_radius, coord_reach(instances[h].transform, bi->second.box));
     }
-    for (TlasInst& t : tinst) { m34 T; memcpy(&T, t.T, 48); t.cull_pad = instance_cull_pad(T, t.blas_box, std::min(16.0f * coord_radius, 3.0e38f)); }   // (a scene with a coordinate beyond 2e37: the product must stay finite, or every instance's slack is infinite)
+    // the pads and spheres of the instances that are NOT edited were baked for origins up to baked_origin_reach (16 x the coord_radius of that build, or more): an edit
+    // that carries an instance beyond it — so that rays starting ON it lie outside what the others were grown for — is a rebuild (advisor, round 5)
+    if (coord_radius * 1.01f > baked_origin_reach) return false;
+    for (TlasInst& t : tinst) { m34 T; memcpy(&T, t.T, 48); t.cull_pad = instance_cull_pad(T, t.blas_box, baked_origin_reach); }
     if (transform_edits.size() > 64) CHECK_HIP(this, hipMemcpyAsync(d_instances.p, h_irec.data(), h_irec.size() * sizeof(InstanceRec), hipMemcpyHostToDevice, stream));   // many edits: the whole table in one copy
     if (!build_scratch && !(build_scratch = bvh_scratch_create())) { fail("out of host memory"); return false; }
     if (!bvh_refit_tlas(build_scratch, stream, tinst.data(), tmesh.data(), (uint32_t)tmesh.size(), items.data(), (uint32_t)items.size(), d_nodes.p, tlas_node_begin, tlas_node_end - tlas_node_begin, tlas_item_begin, n_tlas_items,
@@ -664,6 +685,7 @@ bool HdMoonshine::ensure_scene() {
     // Transform edits re-fit the TLAS in place (every edit its own thread: bvh_refit_tlas) while they are a minority of the instances; when a quarter of the scene moves
     // at once the tree's shape is stale anyway and the rebuild is cheap (17 ms for 100 000 instances).  A re-fitted tree keeps its shape and its re-made grids round
     // outward, so its boxes only ever grow: after 64 re-fits in a row it is rebuilt (the reference's UPDATE-mode builds degrade the same way, Accel.zig:567-601).
+    if (!accel_dirty && origin_needed > baked_origin_reach) accel_dirty = true;   // a primary ray from farther out than the instances' culling volumes were grown for
     if (!accel_dirty && !transform_edits.empty() &&
         (transform_edits.size() > std::max<size_t>(256, instances.size() / 4) || refits_since_rebuild >= 64 || !refit_tlas())) accel_dirty = true;
     if (accel_dirty) geometry_edits.clear();   // (the rebuild writes the whole geometry table from the instances)
@@ -788,6 +810,7 @@ bool HdMoonshine::readback(SensorH* s) {
 
 bool HdMoonshine::render(uint32_t sensor, uint32_t lens, uint32_t launches, bool do_readback) {
     if (sensor >= sensors.size() || lens >= lenses.size()) { fail("render: bad sensor or lens handle"); return false; }
+    origin_needed = 0.0f; need_origin(lenses[lens].origin.x, lenses[lens].origin.y, lenses[lens].origin.z, lenses[lens].aperture);   // camera rays start on the lens (camera.hlsl:31-40)
     if (!ensure_scene()) return false;
     // normals / texcoords are read by vertex index (indexed_attributes, the glTF path) or by corner = 3 * triangle + k (Hydra's
     // face-varying path, world.hlsl:127-135): the array every referenced mesh handed over must cover what this pipeline reads
@@ -931,8 +954,10 @@ bool HdMoonshine::render(uint32_t sensor, uint32_t lens, uint32_t launches, bool
     if (!check_overflow()) { s->sample_count = 0; return false; }   // the film holds truncated traversals: the next render starts it over (Sensor.clear)
     float ms = 0.0f;
     if (ev_begin && ev_end && hipEventElapsedTime(&ms, ev_begin, ev_end) == hipSuccess) stats.render_ms += ms;
+    launch_times.clear();
     for (const Span& sp : spans) {
         if (hipEventElapsedTime(&ms, events[sp.a], events[sp.b]) != hipSuccess) continue;
+        launch_times.emplace_back(sp.kind, ms);
         if (sp.kind == 0) { stats.trace_closest_ms += ms; stats.trace_closest_launches++; }
         else if (sp.kind == 1) { stats.trace_shadow_ms += ms; stats.trace_shadow_launches++; }
         else { stats.shade_ms += ms; stats.shade_launches++; }
@@ -1274,6 +1299,8 @@ int MsneGetTraversalLaneUse(HdMoonshine* c, uint64_t out[24]) {   // [0..11] clo
 // rays: 7 floats each (origin, direction, tmax); out_ids 4 per ray {hit, instance, geometry, primitive}; out_tuv 3 per ray
 int MsneTraceRays(HdMoonshine* c, const float* rays, uint32_t n, int any_hit, uint32_t* out_ids, float* out_tuv) {
     LOCK(c);
+    c->origin_needed = 0.0f;
+    for (uint32_t i = 0; rays && i < n; i++) c->need_origin(rays[7 * (size_t)i], rays[7 * (size_t)i + 1], rays[7 * (size_t)i + 2]);
     if (!c->bind() || !c->ensure_scene() || !c->ensure_wavefront(1, 1, 1)) return -1;
     if (n == 0) return 0;
     DevBuf<float> dr; DevBuf<uint32_t> di; DevBuf<float> dt;
@@ -1286,6 +1313,14 @@ int MsneTraceRays(HdMoonshine* c, const float* rays, uint32_t n, int any_hit, ui
     if (hipMemcpyAsync(out_tuv, dt.p, 12 * (size_t)n, hipMemcpyDeviceToHost, c->stream) != hipSuccess) return -1;
     if (hipStreamSynchronize(c->stream) != hipSuccess) { c->fail("probe failed"); return -1; }
     return c->check_overflow() ? 0 : -1;
+}
+// the last render made with kernel events on (MsneSetProfiling): every k_trace_closest (kind 0) / k_trace_shadow (1) / k_shade (2) launch in issue order — closest(b),
+// shade(b), shadow(b) for b = 0, 1, ... per batch and pipe — with its HIP-event duration: what a bounce of a shard costs, per rank (bench.py per_rank)
+int MsneGetLaunchTimes(HdMoonshine* c, int32_t* kinds, float* ms, uint32_t max_launches) {
+    LOCK(c);
+    const uint32_t n = (uint32_t)std::min<size_t>(max_launches, c->launch_times.size());
+    for (uint32_t i = 0; i < n; i++) { if (kinds) kinds[i] = c->launch_times[i].first; if (ms) ms[i] = c->launch_times[i].second; }
+    return (int)n;
 }
 // queue lengths of the last batch traced on pipe 0, per bounce: {paths, of which zombies, shadow entries, shadow rays traced}
 int MsneGetBounceCounters(HdMoonshine* c, uint32_t* out, uint32_t max_bounces) {

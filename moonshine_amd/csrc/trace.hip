@@ -34,8 +34,13 @@ constexpr int TRACE_BLOCK = 256;
 #ifndef TRACE_WPS
 #define TRACE_WPS 6          // resident waves per SIMD the trace kernels are register-allocated for (= blocks of 256 per CU)
 #endif
+// Two-level scenes: the world-space half of the ray a lane keeps while inside an instance costs 13 spilled registers at 80 —
+// and 6 waves per SIMD are still 3 % faster than 5 at 96 registers without spills (S2 3597 / 3481 Mrays/s,
+// profiles/r04_s2_lane_use.txt "6 instead of 5 waves per SIMD"; round 3 measured the opposite before the leaf records took
+// the InstanceRec hop out of the space body).  7 and 8 waves per SIMD — 72 / 64 registers, LDS stacks of 10 / 9 entries —
+// lose 2-3 % / 12-20 % (profiles/r05_tri_density.txt).  With both at 6 the grid rescaling in the launch wrappers is the identity.
 #ifndef TRACE_WPS_TLAS
-#define TRACE_WPS_TLAS 6     // two-level scenes: the world-space half of the ray a lane keeps while inside an instance costs 13 spilled registers at 80 — and 6 waves per SIMD are still 3 % faster than 5 at 96 registers without spills (S2 3597 / 3481 Mrays/s, profiles/r04_s2_lane_use.txt "6 instead of 5 waves per SIMD"; round 3 measured the opposite before the leaf records took the InstanceRec hop out of the space body; 7 and 8 waves per SIMD — 72 / 64 registers, LDS stacks of 10 / 9 entries — lose 2-3 % / 12-20 %: profiles/r05_tri_density.txt).  With both at 6 the grid rescaling in the launch wrappers is the identity
+#define TRACE_WPS_TLAS 6
 #endif
 #ifndef TRACE_TRI_MIN_LANES
 #define TRACE_TRI_MIN_LANES 1

@@ -91,6 +91,25 @@ def hull_rays(world, seed, far=None):
     return rays
 
 
+def far_rays(world, seed, far):
+    """(n, 7) rays from `far` times the scene's largest coordinate out (half to all of it, any direction), at the six outermost vertices of every instance and 1e-6 ... 0.3
+    instance sizes beside them: origins whose coordinates carry an ulp of up to 0.06 scene sizes — what the instance-space twin of the ray is rounded to, and what every
+    world-space volume an instance is culled by has to allow for"""
+    rs = np.random.default_rng(seed + 4242)
+    reach = max(float(np.abs(W).max()) for W in world)
+    rays = []
+    for W in world:
+        c0 = 0.5 * (W.min(0) + W.max(0)); r = np.linalg.norm(W - c0, axis=1)
+        for v in W[np.argsort(r)[-6:]]:
+            o = rs.normal(size=3); o = o / np.linalg.norm(o) * reach * far * rs.uniform(0.5, 1.0)
+            tgt = v + rs.normal(size=3) * max(r.max(), 1e-30) * rs.choice([0.0, 1e-6, 1e-3, 0.3])
+            d = tgt - o; n = np.linalg.norm(d)
+            rays.append(np.concatenate([o, d / n, [1e30 if rs.random() < 0.7 else n * rs.uniform(0.9, 1.1)]]))
+    rays = np.asarray(rays, np.float32)
+    rays[:, 3:6] /= np.linalg.norm(rays[:, 3:6].astype(np.float64), axis=1, keepdims=True).astype(np.float32)
+    return rays
+
+
 def lattice_scale(seed):
     """the scene and its rays times a power of two (exact): 1 for most seeds; 2^-40, 2^40; 2^-62 and 2^62, where products of two coordinates sit at the ends of the range"""
     return np.float32(2.0) ** int(np.random.default_rng(seed + 3).choice([0, 0, 0, 0, -40, 40, -62, 62]))

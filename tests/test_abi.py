@@ -23,7 +23,7 @@ def test_library_exports_every_declared_symbol(gpu_api):
 
 # diagnostics (header part 3) a renderer front end never calls: the Zig binding leaves them out
 _ZIG_LEAVES_OUT = {"MsneSetProfiling", "MsneGetAccelStats", "MsneGetTexelPoolBytes", "MsneSetBuildQuality", "MsneGetTraversalCounters", "MsneGetTraversalLaneUse",
-                   "MsneGetBounceCounters", "MsneTraceRays", "MsneShadeProbe", "MsneGetEnvSize", "MsneReadEnv", "MsneGetAliasTable", "MsneReadBvh", "MsneProbeClockGhz"}
+                   "MsneGetBounceCounters", "MsneGetLaunchTimes", "MsneTraceRays", "MsneShadeProbe", "MsneGetEnvSize", "MsneReadEnv", "MsneGetAliasTable", "MsneReadBvh", "MsneProbeClockGhz"}
 
 
 def _split_args(a):

@@ -1034,6 +1034,55 @@ def test_instances_under_singular_and_non_finite_transforms(orc, gpu_api, kind):
             c.set_instance_transform(1, T(M, (2.5, 0, 0)) if kind != "inf_t" else T(np.eye(3), (0, np.inf, 0)))
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("far", [1e2, 1e3, 1e4, 1e5, 1e6])
+@pytest.mark.parametrize("seed", __import__("seeds").seeds(list(range(4)), 8))
+def test_camera_far_outside_the_baked_reach(orc, gpu_api, seed, far):
+    """intersection.hlsl:20 — TraceRay takes any origin.  The instances' culling volumes are grown by a bound that holds a term in the ray's ORIGIN (context.hip
+    instance_cull_pad: the instance-space twin of a ray is fl(W o + w) + s fl(W d)), baked for origins up to 16 x the scene's largest coordinate until round 5 — a camera
+    farther out was "outside what is guaranteed".  The host knows every primary origin before it launches (the lens; the rays handed to MsneTraceRays) and re-bakes
+    (HdMoonshine::need_origin).  The hull scenes (scaled, sheared, far-away instances; every other one with the transform whose inverse loses six digits; every third as one
+    world BLAS) seen from 1e2 ... 1e6 scene sizes away: rays aimed at the instances' outermost vertices and a film framing one instance, against the ORACLE'S SEARCH WITHOUT
+    BOXES (every instance entered, on even seeds every triangle tested) — then the camera comes back and nothing is re-baked again."""
+    import hull_rays
+    oc = orc.Context(threads=8); gc = gpu_api.Context()
+    baked = seed % 3 == 2
+    world = [hull_rays.hull_scene(c, seed, seed % 2 == 1, baked=baked) for c in (oc, gc)][0]
+    oc.set_exhaustive_search(2 if seed % 2 == 0 else 1)
+    rs = np.random.default_rng(seed + 4242)
+    reach = max(float(np.abs(W).max()) for W in world)
+    sn = [c.create_sensor(24, 16) for c in (oc, gc)]
+    rays = hull_rays.far_rays(world, seed, far)                                     # from `far` scene sizes out, at the six outermost vertices of every instance
+    before = gc.accel_stats()["rebuilds"]
+    _check_rays(oc, gc, rays)
+    if not baked and far > 16:
+        assert gc.accel_stats()["rebuilds"] > before + 1, "origins beyond the baked reach and no re-bake"      # (the first build + the re-bake)
+    # a film: the camera `far` scene sizes out, framing one instance (the focal plane at the instance, so that pixels differ by positions, not by directions' last bits)
+    W = world[int(rs.integers(len(world)))]; ctr = 0.5 * (W.min(0) + W.max(0)); r = max(np.linalg.norm(W - ctr, axis=1).max(), 1e-20)
+    eye = rs.normal(size=3); eye = eye / np.linalg.norm(eye) * reach * far * 1.7
+    fwd = ctr - eye; dist = np.linalg.norm(fwd); fwd = fwd / dist
+    up = np.array([0, 0, 1.0]) if abs(fwd[2]) < 0.9 else np.array([0, 1.0, 0])
+    films = []
+    for c, s_ in zip((oc, gc), sn):
+        lens = c.create_lens(c.make_lens(tuple(eye), tuple(fwd), tuple(up), float(2.0 * np.arctan(1.5 * r / dist)), float(rs.choice([0.0, 0.5 * r])), float(dist)))
+        c.set_pipeline(samples_per_run=2, max_bounces=3, env_samples_per_bounce=1, mesh_samples_per_bounce=0)
+        c.render(s_, lens, launches=2); films.append(c.sensor_data(s_).copy())
+    same = (films[0].view(np.uint32) == films[1].view(np.uint32)) | (np.isnan(films[0]) & np.isnan(films[1]))
+    assert same.all(), "%d pixels differ" % int((~same).any(-1).sum())
+    assert gc.counters() == {k: v for k, v in oc.counters().items() if k in ("closest_rays", "shadow_rays", "samples")}
+    # and back: an ordinary camera needs nothing re-baked (the larger reach stays)
+    n_re = gc.accel_stats()["rebuilds"]
+    eye2 = ctr + rs.normal(size=3) * r * 3.0; fwd2 = (ctr - eye2) / np.linalg.norm(ctr - eye2)
+    up2 = np.array([0, 0, 1.0]) if abs(fwd2[2]) < 0.9 else np.array([0, 1.0, 0])
+    films = []
+    for c, s_ in zip((oc, gc), sn):
+        lens = c.create_lens(c.make_lens(tuple(eye2), tuple(fwd2), tuple(up2), 0.9, 0.0, 1.0))
+        c.clear_sensor(s_); c.render(s_, lens, launches=1); films.append(c.sensor_data(s_).copy())
+    same = (films[0].view(np.uint32) == films[1].view(np.uint32)) | (np.isnan(films[0]) & np.isnan(films[1]))
+    assert same.all(), "%d pixels differ (camera back inside)" % int((~same).any(-1).sum())
+    assert gc.accel_stats()["rebuilds"] == n_re
+
+
 _FLAT_NODE_SEEDS = [6200053, 6200851, 6201195, 6201640]   # round 5's sweep: a hit at t ~ 1e-8 dropped under a node of coplanar children (no margin in the flat axis)
 
 
@@ -1983,7 +2032,7 @@ def test_bench_gather_path_with_two_ranks(tmp_path):
     code runs with world > 1 and assembles the film a single rank renders"""
     import json, subprocess, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    args = ["--steps", "3", "--warmup", "1", "--repeats", "2", "--width", "328", "--height", "200", "--no-cpu-baseline"]
+    args = ["--steps", "3", "--warmup", "1", "--repeats", "2", "--width", "328", "--height", "200", "--no-cpu-baseline", "--no-other-configs", "--sustain-seconds", "0.2"]
     one, two = str(tmp_path / "one.npy"), str(tmp_path / "two.npy")
     r1 = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--dump-film", one] + args, capture_output=True, text=True, timeout=900)
     assert r1.returncode == 0, r1.stderr[-2000:]
@@ -1995,6 +2044,12 @@ def test_bench_gather_path_with_two_ranks(tmp_path):
     assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
     l1 = json.loads([x for x in r1.stdout.splitlines() if x.startswith("{")][-1]); l2 = json.loads([x for x in r2.stdout.splitlines() if x.startswith("{")][-1])
     assert l2["n_gpus"] == 2 and l1["rays"] == l2["rays"] and len(l2["repeat_values"]) == 2       # the same rays, counted over both ranks
+    # every rank's own times in the one line: its steps, its gather, its bounces
+    assert [r["rank"] for r in l2["per_rank"]] == [0, 1] and len(l1["per_rank"]) == 1
+    for r in l2["per_rank"]:
+        assert r["render_ms"] > 0 and r["gather_ms"] > 0 and len(r["closest_ms_by_bounce"]) == 10 and r["closest_ms_by_bounce"][0] > 0 and r["shade_ms_by_bounce"][0] > 0
+    assert abs(sum(r["rays"] for r in l2["per_rank"]) - (l2["rays"]["closest"] + l2["rays"]["shadow"])) < 1.0
+    assert l1["sustained"]["batches"] >= 1 and l2["sustained"]["batches"] >= 1
 
 
 def test_bench_starts_its_own_ranks(tmp_path):
@@ -2004,15 +2059,15 @@ def test_bench_starts_its_own_ranks(tmp_path):
     import json, subprocess, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "MSNE_BENCH_BACKEND")}
-    args = ["--steps", "3", "--warmup", "1", "--repeats", "2", "--width", "328", "--height", "200", "--no-cpu-baseline"]
+    args = ["--steps", "3", "--warmup", "1", "--repeats", "2", "--width", "328", "--height", "200", "--no-cpu-baseline", "--no-other-configs", "--sustain-seconds", "0"]
     films, lines = {}, {}
-    for name, extra in (("one", ["--gpus", "1"]), ("ranks", ["--gpus", "2"]), ("group", ["--gpus", "2", "--launcher", "group"]), ("ranks3", ["--gpus", "3"])):
+    for name, extra in (("one", ["--gpus", "1"]), ("ranks", ["--gpus", "2"]), ("group", ["--gpus", "2", "--launcher", "group"]), ("ranks3", ["--gpus", "3"]), ("ranks8", ["--gpus", "8"])):
         f = str(tmp_path / (name + ".npy"))
         r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--dump-film", f] + extra + args, capture_output=True, text=True, timeout=900, env=env)
         assert r.returncode == 0, (name, r.stderr[-3000:])
         films[name] = np.load(f)
         lines[name] = json.loads([x for x in r.stdout.splitlines() if x.startswith("{")][-1])
-    for name in ("ranks", "group", "ranks3"):
+    for name in ("ranks", "group", "ranks3", "ranks8"):
         assert np.array_equal(films[name].view(np.uint32), films["one"].view(np.uint32)), name
         assert lines[name]["rays"] == lines["one"]["rays"], name
     import torch
@@ -2020,6 +2075,7 @@ def test_bench_starts_its_own_ranks(tmp_path):
     assert lines["one"]["transport"] == "none" and lines["one"]["n_gpus"] == 1
     assert lines["ranks"]["n_gpus"] == 2 and lines["ranks"]["ranks_seen"] == 2 and lines["ranks"]["transport"] == ("gloo" if shared else "rccl")
     assert lines["ranks3"]["n_gpus"] == 3 and lines["ranks3"]["ranks_seen"] == 3
+    assert lines["ranks8"]["n_gpus"] == 8 and lines["ranks8"]["ranks_seen"] == 8 and len(lines["ranks8"]["per_rank"]) == 8     # the driver's scaling command, as far as one GPU goes
     assert lines["group"]["n_gpus"] == 2 and lines["group"]["ranks_seen"] == 2 and lines["group"]["transport"] == ("copy" if shared else "rccl")
     assert lines["ranks"]["devices_seen"] == (1 if shared else 2)
 

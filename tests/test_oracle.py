@@ -303,6 +303,19 @@ def test_instance_boxes_never_change_a_hit(orc, seed):
     assert not bad, bad[:3]
 
 
+@pytest.mark.parametrize("far", [1e2, 1e4, 1e6])
+@pytest.mark.parametrize("seed", __import__("seeds").seeds(list(range(6)), 6))
+def test_far_origins_with_and_without_boxes(orc, seed, far):
+    """intersection.hlsl:20: any origin.  The oracle's instance slack takes the ray's origin per ray (orc_bvh.c instance_cull_slack); held here from 1e2 ... 1e6 scene
+    sizes out against the search without boxes — the product's far-camera test (tests/test_gpu_parity.py::test_camera_far_outside_the_baked_reach) leans on it"""
+    import hull_rays
+    c = orc.Context(threads=1)
+    world = hull_rays.hull_scene(c, seed, harsh=seed % 2 == 1, baked=seed % 3 == 2)
+    c.create_sensor(8, 8)
+    bad = _same_hits(c, hull_rays.far_rays(world, seed, far), 2 if seed % 2 == 0 else 1)
+    assert not bad, bad[:3]
+
+
 def test_triangle_boxes_never_change_a_hit(orc):
     """the same for the boxes inside a BLAS: the search that tests every triangle of every instance (level 2) against the one that only enters every instance (level 1)"""
     import hull_rays
