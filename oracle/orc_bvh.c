@@ -295,12 +295,26 @@ static inline float safe_inv(float d) { return fabsf(d) < 1e-30f ? (d < 0.0f ? -
  * Until round 5 the exit distance was held against 0 without the slack (found when the product's film differed from this file's on two of 750 lattice scenes and
  * turned out to agree with the search that tests every triangle: tests/test_oracle.py::test_lattice_films_with_and_without_boxes).  The product's quantised planes
  * lie at least 1e-3 quantum outside their boxes, which is what covers it there. */
-/* What box_hit needs of the ray beyond (o, 1/d), once per ray and space instead of once per box: which axes are dominant (smallest |1/d|; all that tie). */
-typedef struct { v3 o, id; int domx, domy, domz; } orc_rayb;
+/* Round 6, what the slack of the RANGE tests has to look like.  The computed t is T / det with T = U*Az + V*Bz + W*Cz and U, V, W >= 0 (or all <= 0): a convex
+ * combination of Az, Bz, Cz — so it lies, to a few ulps, INSIDE THE TRIANGLE'S RANGE ALONG THE DOMINANT AXIS, and that is all that is certain about it.  U, V, W are
+ * differences of products; their rounding errors move the computed barycentric point around inside the triangle by eps x size / sin(angle between ray and plane), and
+ * t with it: a shadow ray that leaves a 19 x 0.1 flat quad at 1.4 degrees from 8e-7 above it has a true t of -2.4e-3 and a computed one of +6.8e-4 — an occluder for
+ * the search over every triangle, while the quad's flat box lay "behind the origin" by 2.6e-6 of its far distance, more than the 1.5e-6 the range tests allowed
+ * (tests/test_oracle.py::test_hull_films_with_and_without_boxes, seed 6204351, found by the GPU sweep of round 6: the product takes the hit).  The error is one of
+ * POSITION ALONG THE RAY'S LINE, so per axis it is worth |1/d_a|: each axis interval is widened by 1.5e-6 x (the box's larger plane distance across the dominant axis,
+ * as a length: far_ / |1/d_kz|) x |1/d_a| — for the dominant axis the 1.5e-6 far_ of before, for an axis the ray barely moves along as much more as it moves less.
+ * Then the plain tests: the interval is not empty, ends after 0, starts before tmax. */
+/* What box_hit needs of the ray beyond (o, 1/d), once per ray and space instead of once per box: which axes are dominant (smallest |1/d|; all that tie), and every
+ * axis' |1/d| over the dominant one's (>= 1; 1 where that is not a number — a direction component that is infinite or zero against another: rays that are not rays). */
+typedef struct { v3 o, id; int domx, domy, domz; float rx, ry, rz; } orc_rayb;
 static inline orc_rayb rayb_make(v3 o, v3 id) {
     orc_rayb r; r.o = o; r.id = id;
     const float ax = fabsf(id.x), ay = fabsf(id.y), az = fabsf(id.z), amin = orc_minf(ax, orc_minf(ay, az));
     r.domx = ax == amin; r.domy = ay == amin; r.domz = az == amin;
+    r.rx = ax / amin; r.ry = ay / amin; r.rz = az / amin;
+    if (!(r.rx >= 1.0f)) r.rx = 1.0f; else if (r.rx > 3e38f) r.rx = 3e38f;   /* (finite: a box at distance 0 must get a slack of 0, not infinity x 0) */
+    if (!(r.ry >= 1.0f)) r.ry = 1.0f; else if (r.ry > 3e38f) r.ry = 3e38f;
+    if (!(r.rz >= 1.0f)) r.rz = 1.0f; else if (r.rz > 3e38f) r.rz = 3e38f;
     return r;
 }
 /* All eight boxes of a node at once (the best hit does not change between the box tests of one visit): bit i of the result = box i is hit, tnear[i] its entry
@@ -309,20 +323,24 @@ static inline unsigned box_hit8(const orc_wnode *n, const orc_rayb *r, float tma
     const float ox = r->o.x, oy = r->o.y, oz = r->o.z, ix = r->id.x, iy = r->id.y, iz = r->id.z;
     const float fx = r->domx ? 1.0f : 0.0f, fy = r->domy ? 1.0f : 0.0f, fz = r->domz ? 1.0f : 0.0f;   /* the dominant axis has the smallest |1/d|; among equals the larger distance */
     const float px = pad * fabsf(ix), py = pad * fabsf(iy), pz = pad * fabsf(iz);
+    const float sx = 1.5e-6f * r->rx, sy = 1.5e-6f * r->ry, sz = 1.5e-6f * r->rz;
     int ok[8];
     for (int i = 0; i < 8; i++) {
-        float t1 = (n->lo[0][i] - ox) * ix, t2 = (n->hi[0][i] - ox) * ix; const float mx = orc_maxf(fabsf(t1), fabsf(t2)); float e = 1e-5f * mx + px;
-        float tn = orc_minf(t1, t2) - e, tf = orc_maxf(t1, t2) + e;
-        t1 = (n->lo[1][i] - oy) * iy; t2 = (n->hi[1][i] - oy) * iy; const float my = orc_maxf(fabsf(t1), fabsf(t2)); e = 1e-5f * my + py;
-        tn = orc_maxf(tn, orc_minf(t1, t2) - e); tf = orc_minf(tf, orc_maxf(t1, t2) + e);
-        t1 = (n->lo[2][i] - oz) * iz; t2 = (n->hi[2][i] - oz) * iz; const float mz = orc_maxf(fabsf(t1), fabsf(t2)); e = 1e-5f * mz + pz;
-        tn = orc_maxf(tn, orc_minf(t1, t2) - e); tf = orc_minf(tf, orc_maxf(t1, t2) + e);
-        tnear[i] = tn;
+        const float x1 = (n->lo[0][i] - ox) * ix, x2 = (n->hi[0][i] - ox) * ix, mx = orc_maxf(fabsf(x1), fabsf(x2));
+        const float y1 = (n->lo[1][i] - oy) * iy, y2 = (n->hi[1][i] - oy) * iy, my = orc_maxf(fabsf(y1), fabsf(y2));
+        const float z1 = (n->lo[2][i] - oz) * iz, z2 = (n->hi[2][i] - oz) * iz, mz = orc_maxf(fabsf(z1), fabsf(z2));
         float far_ = 0.0f;   /* (m >= 0: max(0, m) = m for a dominant axis, and an axis that is not dominant contributes 0) */
         far_ = orc_maxf(far_, fx != 0.0f ? mx : 0.0f);
         far_ = orc_maxf(far_, fy != 0.0f ? my : 0.0f);
         far_ = orc_maxf(far_, fz != 0.0f ? mz : 0.0f);
-        ok[i] = (tn <= tf) & (tf >= -1.5e-6f * far_) & (tn <= tmax + 1.5e-6f * far_);   /* (both ends of the ray's range carry the slack: see above) */
+        float e = 1e-5f * mx + px + sx * far_;
+        float tn = orc_minf(x1, x2) - e, tf = orc_maxf(x1, x2) + e;
+        e = 1e-5f * my + py + sy * far_;
+        tn = orc_maxf(tn, orc_minf(y1, y2) - e); tf = orc_minf(tf, orc_maxf(y1, y2) + e);
+        e = 1e-5f * mz + pz + sz * far_;
+        tn = orc_maxf(tn, orc_minf(z1, z2) - e); tf = orc_minf(tf, orc_maxf(z1, z2) + e);
+        tnear[i] = tn;
+        ok[i] = (tn <= tf) & (tf >= 0.0f) & (tn <= tmax);   /* (every axis interval carries its slack already) */
     }
     unsigned m = 0;
     for (int i = 0; i < n->nchild; i++) m |= (unsigned)(ok[i] != 0) << i;
