@@ -118,6 +118,9 @@ __device__ __forceinline__ f3 estimate_direct_mis(const Frame& frame, const LSam
     return F3(0.0f, 0.0f, 0.0f);
 }
 
+#ifndef MSNE_ENV_TOP_LDS
+#define MSNE_ENV_TOP_LDS 1   // (0: the descent reads every level from memory, as before round 6 — tools/variant_rates.py)
+#endif
 #ifndef SHADE_WPS
 #define SHADE_WPS 4          // resident waves per SIMD the TEXTURED k_shade is register-allocated for: 128 registers with the descriptors fetched where they are used (19 spilled;
                              // stand-in with 64^2 / 1024^2 textures: shade 55.9 -> 54.0 / 60.7 -> 59.5 ms per 64-step batch against 3 waves at 166 registers; round 3, with the
@@ -160,6 +163,8 @@ __global__ __launch_bounds__(SHADE_BLOCK, shade_spec_wps(SPEC, TEX)) void k_shad
     // thread that shades the path after the sort picks it up there, instead of gathering 16-B pieces from a permuted index
     __shared__ float4 s_ro[SHADE_BLOCK], s_rd[SHADE_BLOCK], s_tp[SHADE_BLOCK], s_lr[SHADE_BLOCK];
     __shared__ uint2 s_sq[SHADE_BLOCK];
+    __shared__ float4 s_envtop[ENV_TOP_QUADS];   // the top of the environment's sampling pyramid (shade.h env_top_stage); read after the first barrier of the loop below
+    if (MSNE_ENV_TOP_LDS && SPEC != 1 && SPEC != 2 && env_n != 0u) env_top_stage(sc.env, s_envtop, threadIdx.x, SHADE_BLOCK);
     uint32_t acc = 0;   // TRUNC: what the truncated kernel folds its loads into
     for (uint32_t base_i = blockIdx.x * SHADE_BLOCK; base_i < n_pad; base_i += gridDim.x * SHADE_BLOCK) {
         uint32_t cat = CAT_NONE;
@@ -360,7 +365,7 @@ __global__ __launch_bounds__(SHADE_BLOCK, shade_spec_wps(SPEC, TEX)) void k_shad
             if (SPEC != 2 && !delta) {   // the random numbers of every sample are drawn whether or not it gets a queue entry
                 for (uint32_t k = 0; k < env_n; k++) {   // integrator.hlsl:141-144
                     f2 rand; rand.x = rng_float(rng); rand.y = rng_float(rng);
-                    const LSample ls = env_sample_unoccluded(sc.env, rand);
+                    const LSample ls = env_sample_unoccluded(sc.env, rand, MSNE_ENV_TOP_LDS ? s_envtop : nullptr);
                     const uint32_t e_ = queue_slot(q + k * stride, kq);
                     if (ls.pdf > 0.0f) {
                         const f3 so = offset_along_normal(attrs.position, face_forward(attrs.triangleFrame.n, ls.dirWs));

@@ -352,7 +352,18 @@ __device__ __forceinline__ f3 env_rgb_load(const EnvView& e, uint32_t x, uint32_
     return F3(p.x, p.y, p.z);
 }
 // EnvMap::sample light.hlsl:47-80 without its shadow ray (the caller enqueues it when pdf > 0)
-__device__ __forceinline__ LSample env_sample_unoccluded(const EnvView& e, f2 rand) {
+// `top`: the quads of the descent's first stored levels — the 1x1, 2x2, 4x4 and 8x8 quad grids, ENV_TOP_QUADS float4 in that order — staged in LDS by the caller
+// (k_shade: 1.3 KB of the 5 KB its workgroup has left), or nullptr.  The descent is a chain of dependent fetches, one per level, and every lane of the machine walks
+// the same few texels at its top: four of the eight round trips of a 256^2 map are then LDS reads.  Same values, same operations.
+constexpr uint32_t ENV_TOP_LEVELS = 4u, ENV_TOP_QUADS = 1u + 4u + 16u + 64u;
+__device__ __forceinline__ void env_top_stage(const EnvView& e, float4* top, uint32_t tid, uint32_t nthreads) {   // (the caller synchronises before the first sample)
+    if (e.mip_count < 2u) return;
+    for (uint32_t i = tid; i < ENV_TOP_QUADS; i += nthreads) {
+        const uint32_t k = i < 1u ? 0u : (i < 5u ? 1u : (i < 21u ? 2u : 3u)), first = k == 0u ? 0u : (k == 1u ? 1u : (k == 2u ? 5u : 21u));   // grid k is 2^k quads wide
+        if (k + 2u <= e.mip_count) top[i] = e.quads[e.quad_offset[e.mip_count - 2u - k] + (i - first)];
+    }
+}
+__device__ __forceinline__ LSample env_sample_unoccluded(const EnvView& e, f2 rand, const float4* top = nullptr) {
     const uint32_t size = e.size, mipCount = e.mip_count;
     uint32_t ix = 0, iy = 0;
     // One level of the descent reads the 2x2 quad at (2 ix, 2 iy): the last level is the single texel e.top and three reads out of bounds (0);
@@ -360,7 +371,11 @@ __device__ __forceinline__ LSample env_sample_unoccluded(const EnvView& e, f2 ra
     float4 q = make_float4(e.top, 0.0f, 0.0f, 0.0f);
     float chosen = e.top;   // the texel the descent stands on: after level 0 it is luminanceTexture[idx]
     for (uint32_t level = mipCount; level-- > 0;) {
-        if (level + 1 != mipCount) q = e.quads[e.quad_offset[level] + (size_t)iy * ((size >> level) >> 1) + ix];   // (ix, iy) still name the parent texel here
+        if (level + 1 != mipCount) {   // (ix, iy) still name the parent texel here
+            const uint32_t k = mipCount - 2u - level, w = (size >> level) >> 1;   // the quad grid of this level is w = 2^k quads wide
+            if (top && k < ENV_TOP_LEVELS) q = top[(k == 0u ? 0u : (k == 1u ? 1u : (k == 2u ? 5u : 21u))) + iy * w + ix];
+            else q = e.quads[e.quad_offset[level] + (size_t)iy * w + ix];
+        }
         ix *= 2; iy *= 2;
         const float px = q.x + q.y;
         const float py = q.z + q.w;
