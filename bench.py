@@ -136,6 +136,13 @@ def valu_calibration():
     return json.load(open(f)) if os.path.exists(f) else None
 
 
+def l1_tag_calibration():
+    """profiles/*_l1_tag_calibration.json (newest): the largest L1 tag-access rate per clock per CU any variant of tools/gather_microbench.hip reached under the counters"""
+    d = os.path.join(ROOT, "profiles")
+    fs = sorted(f for f in os.listdir(d) if f.endswith("_l1_tag_calibration.json"))
+    return (json.load(open(os.path.join(d, fs[-1]))), fs[-1]) if fs else (None, None)
+
+
 def gpu_count_without_hip():
     """GPUs this process may use, counted WITHOUT bringing up a HIP / HSA runtime in it (the parent of the ranks must not hold one): the visibility masks if set,
     else the KFD topology (a node with SIMDs is a GPU)."""
@@ -470,6 +477,21 @@ def main():
                     "hbm_algorithmic_frac": hbm["frac"], "hbm_algorithmic": hbm}
         else:
             roof = dict(hbm, bound="hbm", kernel=dom)
+        # the other candidate the round-5 verdict named: the L1's tag rate.  Tag accesses per unit (committed PMC pass) x units per launch / (launch duration x the
+        # clock the counters file records x 256 CUs), against the largest rate the gather microbenchmark reached (profiles/*_l1_tag_calibration.json).  `bound` names
+        # whichever resource the kernel uses the larger fraction of.
+        tcal, tcal_file = l1_tag_calibration()
+        mp = (ck or {}).get("memory_pipeline") or {}
+        if tcal and mp.get("l1_tag_accesses_per_unit") and avg_ms > 0:
+            clk = mp.get("clock_ghz") or 2.4
+            per_clk = mp["l1_tag_accesses_per_unit"] * (kun[dom] / nl) / (avg_ms * 1e-3) / (clk * 1e9) / 256.0
+            roof["l1_tag"] = {"accesses_per_clk_per_cu": per_clk, "peak": tcal["peak_l1_tag_accesses_per_clk_per_cu"], "frac": per_clk / tcal["peak_l1_tag_accesses_per_clk_per_cu"],
+                              "accesses_per_unit": mp["l1_tag_accesses_per_unit"], "from": {"accesses": "profiles/" + cnt_file, "peak": "profiles/" + tcal_file}}
+            if roof.get("bound") == "valu" and roof["l1_tag"]["frac"] > roof["frac"]:
+                roof["bound"] = "l1_tag"
+        # which fields of this object are measured in THIS run and which come from committed profiles of the same command
+        roof["measured_in_this_run"] = ["kernel", "avg_launch_ms", "launches", "units_per_launch", "achieved (its time base)", "hbm_algorithmic*"]
+        roof["from_committed_counters"] = ["issue_cycles_per_unit*", "wave_instructions_per_unit", "class_per_unit", "lanes_per_instruction", "traffic (bytes per unit)", "memory_pipeline", "l1_tag.accesses_per_unit", "peak_clock_ghz"]
         if cnt:
             roof["counters_source_hash"] = cnt.get("source_hash"); roof["counters_steps"] = cnt.get("steps")
             roof["counters_stale"] = cnt.get("source_hash") != source_hash()       # per-ray instruction counts were taken on other kernel sources than the ones running now

@@ -397,6 +397,19 @@ __device__ __forceinline__ void grid_no_axis_much_finer(uint8_t e[3]) {
     const int em = max((int)e[0], max((int)e[1], (int)e[2]));
     for (int k = 0; k < 3; k++) if ((int)e[k] < em - 2) e[k] = (uint8_t)(em - 2);
 }
+// Every child box is grown by 1e-4 of its own largest extent, on every side, before it is quantised.  What the watertight test's t is worth depends on the TRIANGLE:
+// its weights are differences of products, and a needle (15.8 x 0.028) or a ray 1.4 degrees off the plane puts the computed hit point eps x size x (aspect ratio, or
+// 1 / sin) away from the true one ALONG THE RAY — in round 6's sweeps +3.7e-4 / +6.8e-4 for true distances of -1.5e-4 / -2.4e-3, hits the search over every triangle takes
+// (the test oracle's box test carries the same term; tests/test_oracle.py::test_hull_films_with_and_without_boxes).  No bound exists in what a node knows, but the error is
+// always a fraction of the triangle's size and a triangle is no larger than a box that holds it: 1e-4 covers amplifications up to ~1600.  Children of a child are grown by
+// less than it is, so boxes stay nested; the grid's three quanta of headroom (>= 1.2e-2 of the extent) hold it.
+#ifndef MSNE_BOX_GROWTH
+#define MSNE_BOX_GROWTH 1e-4f   // (0: measurements only — tools/variant_rates.py)
+#endif
+__device__ __forceinline__ float box_growth(const Box& b) {
+    const float g = fmaxf(fmaxf(b.hi[0] - b.lo[0], b.hi[1] - b.lo[1]), b.hi[2] - b.lo[2]);
+    return (g > 0.0f && g < 3.0e38f) ? MSNE_BOX_GROWTH * g : 0.0f;   // (an empty or unbounded box: as it is)
+}
 __device__ __forceinline__ float grid_origin(float lo, uint8_t ex) {
     const float o = lo - u2f((uint32_t)ex << 23);
     return (o == o && o > -3.0e38f) ? o : lo;   // (a box at the end of the range or not a number: as it is)
@@ -484,8 +497,9 @@ __global__ void k_collapse(const CollapseWork* work, uint32_t nwork, CollapseWor
             // outward by at least 1e-3 quantum: a ray that runs exactly in a face plane of the TRUE box (axis-parallel, reciprocal
             // 1e30) then sees the quantised plane at +-(1e-3 * scale * 1e30), far above the ~1e-5 * scale * 1e30 rounding noise of
             // q*a + b in the traversal; a child on the node's own lower face quantises to 0: one quantum below it (grid_origin)
-            float ql = floorf((cb[i].lo[k] - origin) * inv_s[k] - 1e-3f);
-            float qh = ceilf((cb[i].hi[k] - origin) * inv_s[k] + 1e-3f);
+            const float grow = box_growth(cb[i]);
+            float ql = floorf((cb[i].lo[k] - grow - origin) * inv_s[k] - 1e-3f);
+            float qh = ceilf((cb[i].hi[k] + grow - origin) * inv_s[k] + 1e-3f);
             ql = fminf(fmaxf(ql, 0.0f), 255.0f); qh = fminf(fmaxf(qh, 0.0f), 255.0f);
             nd.qlo[k][s] = (uint8_t)ql; nd.qhi[k][s] = (uint8_t)qh;
         }
@@ -1162,9 +1176,10 @@ __global__ void k_tlas_links(const Node8* nodes, uint32_t node_begin, uint32_t n
 
 // the quantisation of k_collapse, for one child box on a node's grid; false when the box does not fit the grid (the node has to be re-gridded)
 __device__ __forceinline__ bool quantise_child(const float origin[3], const uint8_t e[3], const Box& b, uint8_t ql[3], uint8_t qh[3]) {
+    const float grow = box_growth(b);
     for (int k = 0; k < 3; k++) {
         const float inv_s = u2f((uint32_t)(254 - e[k]) << 23);
-        const float lo = floorf((b.lo[k] - origin[k]) * inv_s - 1e-3f), hi = ceilf((b.hi[k] - origin[k]) * inv_s + 1e-3f);
+        const float lo = floorf((b.lo[k] - grow - origin[k]) * inv_s - 1e-3f), hi = ceilf((b.hi[k] + grow - origin[k]) * inv_s + 1e-3f);
         if (!(lo >= 0.0f) || !(hi <= 255.0f) || !(hi >= 0.0f) || !(lo <= 255.0f)) return false;   // (NaN or an empty box: does not fit any grid)
         ql[k] = (uint8_t)lo; qh[k] = (uint8_t)hi;
     }

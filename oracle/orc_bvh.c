@@ -333,11 +333,17 @@ static inline unsigned box_hit8(const orc_wnode *n, const orc_rayb *r, float tma
         far_ = orc_maxf(far_, fx != 0.0f ? mx : 0.0f);
         far_ = orc_maxf(far_, fy != 0.0f ? my : 0.0f);
         far_ = orc_maxf(far_, fz != 0.0f ? mz : 0.0f);
-        float e = 1e-5f * mx + px + sx * far_;
+        /* ... and 1e-4 of the box's own largest extent, as a length, on every side: the amplification above has no bound in what a NODE knows — a needle of a triangle
+         * (15.8 x 0.028, seed 6226272: t = +3.7e-4 for a true -1.5e-4 at 24 degrees from its plane) amplifies by its aspect ratio as a grazing ray does by 1 / sin —
+         * but the error is always a fraction of the TRIANGLE's size, and a triangle is no larger than a box that holds it: 1e-4 covers amplifications up to ~1600.
+         * The product's builder grows its boxes by the same 1e-4 before it quantises them (bvh_build.hip quantise_child). */
+        float g = orc_maxf(orc_maxf(n->hi[0][i] - n->lo[0][i], n->hi[1][i] - n->lo[1][i]), n->hi[2][i] - n->lo[2][i]);
+        g = g > 0.0f && g < 3e38f ? 1e-4f * g : 0.0f;   /* (an empty slot's inverted box, a box at the end of the range: no growth) */
+        float e = 1e-5f * mx + px + sx * far_ + g * fabsf(ix);
         float tn = orc_minf(x1, x2) - e, tf = orc_maxf(x1, x2) + e;
-        e = 1e-5f * my + py + sy * far_;
+        e = 1e-5f * my + py + sy * far_ + g * fabsf(iy);
         tn = orc_maxf(tn, orc_minf(y1, y2) - e); tf = orc_minf(tf, orc_maxf(y1, y2) + e);
-        e = 1e-5f * mz + pz + sz * far_;
+        e = 1e-5f * mz + pz + sz * far_ + g * fabsf(iz);
         tn = orc_maxf(tn, orc_minf(z1, z2) - e); tf = orc_minf(tf, orc_maxf(z1, z2) + e);
         tnear[i] = tn;
         ok[i] = (tn <= tf) & (tf >= 0.0f) & (tn <= tmax);   /* (every axis interval carries its slack already) */

@@ -1,27 +1,41 @@
 """The counters pass of tools/run_gather_microbench.sh as a table: per variant of tools/gather_microbench.hip (one dispatch each, W = 6, pools of 16 KiB and 2 MiB),
-L1 tag accesses per clock per CU (TCP_TOTAL_CACHE_ACCESSES_sum / GRBM_GUI_ACTIVE / CUs), per lane-load, L1 -> L2 requests per lane-load, TA / TD busy.
-    python tools/gather_counters.py DIR_OF_THE_PMC_RUN LOG_OF_THE_PMC_RUN"""
-import csv, glob, os, re, sys
-from collections import defaultdict, OrderedDict
-d, log = sys.argv[1], sys.argv[2]
+L1 tag accesses per clock per CU (TCP_TOTAL_CACHE_ACCESSES_sum / (GRBM_GUI_ACTIVE / 8 XCDs) / 256 CUs), per lane-load, L1 -> L2 requests per lane-load, TA / TD busy —
+and, as JSON on the last line, the largest tag rate any variant reached: the measured ceiling bench.py holds k_trace_*'s tag rate against.
+    python tools/gather_counters.py DIR_OF_THE_PMC_RUN [OUT.json]"""
+import csv, glob, json, os, re, sys
+from collections import OrderedDict
+d = sys.argv[1]
 rows = OrderedDict()
 for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
     for r in csv.DictReader(open(f)):
+        if "k_gather<" not in r["Kernel_Name"]:
+            continue                                    # (the program's memsets and copies are dispatches too)
         k = (int(r["Dispatch_Id"]), r["Kernel_Name"])
         e = rows.setdefault(k, {"ns": int(r["End_Timestamp"]) - int(r["Start_Timestamp"]), "grid": int(r.get("Grid_Size", 0) or 0)})
         e[r["Counter_Name"]] = e.get(r["Counter_Name"], 0.0) + float(r["Counter_Value"])
-# the program prints its variants in dispatch order: pair them up
-names = [l.split("  W=")[0].strip() + "  " + l.split("KiB")[0].split()[-1] + " KiB" for l in open(log) if " wave-fetches/us/CU" in l]
-rates = [float(re.search(r"([\d.]+) wave-fetches/us/CU", l).group(1)) for l in open(log) if " wave-fetches/us/CU" in l]
-CUS = 256
-print("# one dispatch per variant under rocprofv3 --pmc (W = 6 waves per SIMD, 400 dependent hops per lane); tag = TCP_TOTAL_CACHE_ACCESSES_sum")
-print("%-44s %9s %11s %12s %13s %8s %8s %9s" % ("variant", "fetch/us", "tag/clk/CU", "tag/laneload", "L2req/laneload", "TA busy", "TD busy", "clock GHz"))
-disp = sorted(rows.items())
-for i, ((did, kname), e) in enumerate(disp):
+SHAPE = {(5, 80): "node 5x16B @80B", (4, 64): "4x16B @64B", (8, 128): "node 8x16B @128B", (3, 48): "tri 3x16B @48B", (1, 16): "1x16B"}
+FETCH = ["lane", "coop", "dlds"]; SPREAD = ["rand", "g8", "uni"]
+CUS, ITERS = 256, 400
+seen = {}
+print("# one dispatch per variant under rocprofv3 --pmc (W = 6 waves per SIMD, %d dependent hops per lane); tag = TCP_TOTAL_CACHE_ACCESSES_sum; clock = GRBM_GUI_ACTIVE / 8 / duration" % ITERS)
+print("%-20s %-5s %-5s %9s %10s %11s %13s %15s %8s %8s %7s" % ("record", "fetch", "lanes", "pool", "fetch/us/CU", "tag/clk/CU", "tag/lane-load", "L2req/lane-load", "TA busy", "TD busy", "GHz"))
+best = (0.0, None)
+for (did, kname), e in sorted(rows.items()):
     m = re.search(r"k_gather<(\d+), (\d+), (\d+), (\d+)>", kname)
-    nloads = int(m.group(1)) if m else 1
-    laneloads = e["grid"] * 400.0 * nloads if e["grid"] else float("nan")
-    act = e.get("GRBM_GUI_ACTIVE", float("nan")) / 8.0      # (the counter sums the 8 XCDs: tools/profile_counters.py)
+    n, stride, fetch, spread = (int(x) for x in m.groups())
+    key = (n, stride, fetch, spread); seen[key] = seen.get(key, 0) + 1
+    pool = "2 MiB" if (spread == 2 or seen[key] % 2 == 0) else "16 KiB"      # (the program's order: 16 KiB then 2 MiB; `uni` only 2 MiB; the 4x16B shape runs twice)
+    laneloads = e["grid"] * float(ITERS) * n
+    act = e.get("GRBM_GUI_ACTIVE", float("nan")) / 8.0
     tag = e.get("TCP_TOTAL_CACHE_ACCESSES_sum", float("nan"))
-    print("%-44s %9.1f %11.3f %12.3f %13.3f %8.3f %8.3f %9.3f" % (names[i] if i < len(names) else kname[:44], rates[i] if i < len(rates) else float("nan"), tag / act / CUS, tag / laneloads,
-          e.get("TCP_TCC_READ_REQ_sum", float("nan")) / laneloads, e.get("TA_TA_BUSY_sum", float("nan")) / act / CUS, e.get("TD_TD_BUSY_sum", float("nan")) / act / CUS, act / e["ns"]))
+    rate = tag / act / CUS
+    if rate == rate and rate > best[0]:
+        best = (rate, "%s %s %s %s" % (SHAPE.get((n, stride), "%dx16B" % n), FETCH[fetch], SPREAD[spread], pool))
+    print("%-20s %-5s %-5s %9s %10.1f %11.3f %13.3f %15.3f %8.3f %8.3f %7.3f" % (SHAPE.get((n, stride), "%dx16B @%dB" % (n, stride)), FETCH[fetch], SPREAD[spread], pool,
+          e["grid"] / 64.0 * ITERS / CUS / (e["ns"] * 1e-3), rate, tag / laneloads, e.get("TCP_TCC_READ_REQ_sum", float("nan")) / laneloads,
+          e.get("TA_TA_BUSY_sum", float("nan")) / act / CUS, e.get("TD_TD_BUSY_sum", float("nan")) / act / CUS, act / e["ns"]))
+cal = {"peak_l1_tag_accesses_per_clk_per_cu": best[0], "variant": best[1],
+       "from": "tools/gather_microbench.hip under rocprofv3 --pmc TCP_TOTAL_CACHE_ACCESSES_sum GRBM_GUI_ACTIVE (tools/run_gather_microbench.sh): the largest rate any variant reached"}
+print(json.dumps(cal))
+if len(sys.argv) > 2:
+    json.dump(cal, open(sys.argv[2], "w"), indent=1)

@@ -10,6 +10,6 @@ timeout 600 /tmp/gather_microbench > "$R/gpurun_out/${TAG}_gather_microbench.txt
 cd /tmp && export TMPDIR=/tmp
 rm -rf "$R/gpurun_out/${TAG}_gather_pmc"
 timeout 300 rocprofv3 --pmc TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum TA_TA_BUSY_sum TD_TD_BUSY_sum GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d "$R/gpurun_out/${TAG}_gather_pmc" -o p -- /tmp/gather_microbench pmc > "$R/gpurun_out/${TAG}_gather_pmc.log" 2>&1 || echo "pmc pass failed"
-python3 "$R/tools/gather_counters.py" "$R/gpurun_out/${TAG}_gather_pmc" "$R/gpurun_out/${TAG}_gather_pmc.log" > "$R/gpurun_out/${TAG}_gather_counters.txt" 2>&1
+python3 "$R/tools/gather_counters.py" "$R/gpurun_out/${TAG}_gather_pmc" "$R/gpurun_out/${TAG}_l1_tag_calibration.json" > "$R/gpurun_out/${TAG}_gather_counters.txt" 2>&1
 rm -rf "$R/gpurun_out/${TAG}_gather_pmc"
 tail -n 40 "$R/gpurun_out/${TAG}_gather_counters.txt"
