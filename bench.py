@@ -40,9 +40,17 @@ HBM_PEAK = 8.0e12  # B/s, /opt/skills/guides/MI355X_MICROARCH.md "HBM3E peak BW"
 KERNELS = ("k_trace_closest", "k_trace_shadow", "k_shade")
 
 
+_STANDIN = None
+
+
 def build_scene(ctx, a):
     if a.scene == "s2":
         return scenes.s2(ctx, extent=(a.width, a.height))
+    if a.scene == "standin":     # configs[2]'s workload on the substituted asset, through the GLB and EXR importers (GPU contexts only: the oracle is fed by tests/)
+        global _STANDIN
+        _STANDIN = _STANDIN or standin_files()
+        lens, _ = ctx.load_glb(_STANDIN[0]); ctx.set_background_exr(_STANDIN[1])
+        return ctx.create_sensor(a.width, a.height), lens
     return scenes.s1(ctx, extent=(a.width, a.height), env=a.env)
 
 
@@ -64,15 +72,8 @@ def other_config(a, dev, scene, env):
     the substituted asset (textured k_shade instantiation, image environment with the mip descent, GLB + EXR importers)."""
     b = argparse.Namespace(scene=scene, env=env, width=a.width, height=a.height, steps=a.steps)
     c = api.Context(device=dev)
-    if scene == "standin":
-        glb, exr = standin_files()
-        lens, _ = c.load_glb(glb); c.set_background_exr(exr)
-        sensor = c.create_sensor(a.width, a.height)
-        name = ("configs[2] stand-in (asset substituted): 983 052 textured triangles in 54 instances, 196 PNG textures, 2048x1024 PIZ HDR environment"
-                ", %dx%d, %d spp, max_bounces 8, env+mesh NEE with MIS" % (a.width, a.height, a.steps))
-    else:
-        sensor, lens = build_scene(c, b)
-        name = workload_name(b)
+    sensor, lens = build_scene(c, b)
+    name = workload_name(b)
     c.set_pipeline(samples_per_run=1, max_bounces=8, env_samples_per_bounce=1, mesh_samples_per_bounce=1)
     c.render(sensor, lens, launches=0, readback=False)
     c.set_profiling(kernel_events=False, traversal_counters=False)
@@ -102,7 +103,13 @@ def cpu_baseline(a):
 
     def run(threads, W, H, spp):
         c = orc.Context(threads=threads)
-        s, l = build_scene(c, argparse.Namespace(scene=a.scene, env=a.env, width=W, height=H))
+        if a.scene == "standin":     # the oracle reads no files itself: the parity tests' loader feeds it the same GLB and EXR (tests/io_common.py oracle_load)
+            global _STANDIN
+            from tests import io_common as io
+            _STANDIN = _STANDIN or standin_files()
+            l, _ = io.oracle_load(orc, c, _STANDIN[0], _STANDIN[1]); s = c.create_sensor(W, H)
+        else:
+            s, l = build_scene(c, argparse.Namespace(scene=a.scene, env=a.env, width=W, height=H))
         c.set_pipeline(samples_per_run=1, max_bounces=8, env_samples_per_bounce=1, mesh_samples_per_bounce=1)
         c.render(s, l, launches=1)          # builds the BVH, touches memory
         c.reset_counters()
@@ -217,7 +224,7 @@ def run_group(a):
         np.save(a.dump_film, g.sensor_data(sensor))
     rates = [rays / t / 1e6 for t in times]
     print(json.dumps({
-        "metric": "Mrays/sec, 1M-tri scene @1080p" if a.scene == "s1" else "Mrays/sec, 10M-tri instanced scene @1080p",
+        "metric": "Mrays/sec, 1M-tri scene @1080p" if a.scene == "s1" else ("Mrays/sec, 10M-tri instanced scene @1080p" if a.scene == "s2" else "Mrays/sec, 1M-tri textured interior (asset substituted) @1080p"),
         "value": rays / dt / 1e6, "unit": "Mrays/s", "n_gpus": a.gpus, "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3,
         "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": workload_name(a), "sharding": "16x16 image tiles, tile t -> member t mod %d, one gather of the packed film (MsneGroup, one process)" % a.gpus},
@@ -229,6 +236,9 @@ def run_group(a):
 
 
 def workload_name(a):
+    if a.scene == "standin":
+        return ("configs[2] stand-in (asset substituted): 983 052 textured triangles in 54 instances, 196 PNG textures, 2048x1024 PIZ HDR environment"
+                ", %dx%d, %d spp, max_bounces 8, env+mesh NEE with MIS" % (a.width, a.height, a.steps))
     return (("S1: 7x7 order-5 icospheres (1 003 520 tris) + ground + emissive quad" if a.scene == "s1" else
              "S2: 500 instances of one order-5 icosphere (10 240 000 instanced tris), glass / GGX")
             + ", %dx%d, %d spp, max_bounces 8, env+mesh NEE with MIS, %s env" % (a.width, a.height, a.steps, a.env))
@@ -244,7 +254,7 @@ def main():
     ap.add_argument("--repeats", type=int, default=5)
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
-    ap.add_argument("--scene", default="s1", choices=["s1", "s2"])
+    ap.add_argument("--scene", default="s1", choices=["s1", "s2", "standin"])
     ap.add_argument("--env", default="constant", choices=["constant", "sky"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-other-configs", action="store_true", help="skip the secondary single-GPU configurations (S2, S1 under the sky) reported next to the headline")
@@ -506,7 +516,7 @@ def main():
                 roof["memory_pipeline"] = dict(ck["memory_pipeline"], **{"from": "profiles/" + cnt_file})
         rates = [rays / t / 1e6 for t in times]
         out = {
-            "metric": "Mrays/sec, 1M-tri scene @1080p" if a.scene == "s1" else "Mrays/sec, 10M-tri instanced scene @1080p",
+            "metric": "Mrays/sec, 1M-tri scene @1080p" if a.scene == "s1" else ("Mrays/sec, 10M-tri instanced scene @1080p" if a.scene == "s2" else "Mrays/sec, 1M-tri textured interior (asset substituted) @1080p"),
             "value": rays / dt / 1e6, "unit": "Mrays/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3,
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",

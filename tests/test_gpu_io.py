@@ -176,11 +176,19 @@ def test_config1_cornell_glb_offline_64spp(tmp_path, orc):
 # is not available ("asset substituted"): tests/io_common.py:write_bathroom_standin writes a ~1 M-triangle TEXTURED
 # interior (196 PNG textures, normal maps, metallic-roughness maps, node hierarchy, glass, emissive strength + emissive texture)
 # and a 2048x1024 PIZ-compressed HDR environment. ----
-def _oracle_tiles(orc, glb, exr, extent, spp, tiles, film, pipe, nan_tiles=None):
+def _oracle_tiles(orc, glb, exr, extent, spp, tiles, film, pipe, nan_tiles=None, second_source=()):
+    """`second_source`: tiles for which the oracle is NOT fed through the product's importer (tests/shim) but through tests/second_source_glb.py — the glTF rules of
+    World.zig:44-349 / Camera.zig:26-51 restated in Python: at the size of configs[2] / [3] a rule the product's importer got wrong shows as a different film"""
     tx, ty = (extent[0] + 63) // 64, (extent[1] + 63) // 64
     for t in tiles:
         oc = orc.Context(threads=usable_cores(), shard_index=t, shard_count=tx * ty)
-        ol, _ = io.oracle_load(orc, oc, glb, exr)
+        if t in second_source:
+            import ctypes as C
+            import second_source_glb
+            ol = second_source_glb.load(oc, glb)
+            assert io.shim(orc).ShimSetBackgroundExr(C.c_void_p(oc.h), exr.encode()) == 0
+        else:
+            ol, _ = io.oracle_load(orc, oc, glb, exr)
         s = oc.create_sensor(*extent)
         oc.set_pipeline(**pipe)
         oc.render(s, ol, launches=spp)
@@ -204,7 +212,8 @@ def _nan_tiles(film, limit=6):
 
 def test_config2_asset_substituted_textured_interior_1080p_256spp(tmp_path, orc):
     """configs[2] (asset substituted): `offline` renders the textured interior at 1920x1080, 256 spp, full MIS, max_bounces 1024
-    (the CLI's defaults, offline/main.zig:106-111); three 64x64 tiles of the EXR are bit-identical to the oracle fed the same files"""
+    (the CLI's defaults, offline/main.zig:106-111); three 64x64 tiles of the EXR are bit-identical to the oracle fed the same files — one of them with the
+    oracle's scene built by the SECOND glTF source instead of the product's importer"""
     glb, exr, out = str(tmp_path / "bath.glb"), str(tmp_path / "sky.exr"), str(tmp_path / "out.exr")
     meta = io.write_bathroom_standin(glb, exr)
     assert meta["triangles"] > 900000 and meta["textures"] >= 64
@@ -218,7 +227,7 @@ def test_config2_asset_substituted_textured_interior_1080p_256spp(tmp_path, orc)
     assert film.shape == (1080, 1920, 4) and n_nan <= 64 and 0.05 < float(film[..., :3][ok].mean()) < 5.0
     # three fixed tiles and every tile (up to six) that holds a NaN pixel: bit-identical to the oracle, NaNs included
     _oracle_tiles(orc, glb, exr, (1920, 1080), 256, sorted(set((8 * 30 + 14, 11 * 30 + 9, 14 * 30 + 22)) | set(nan_tiles)), film,
-                  dict(samples_per_run=1, max_bounces=1024, env_samples_per_bounce=1, mesh_samples_per_bounce=1), nan_tiles)
+                  dict(samples_per_run=1, max_bounces=1024, env_samples_per_bounce=1, mesh_samples_per_bounce=1), nan_tiles, second_source=(11 * 30 + 9,))
     print("configs[2]: ASSET SUBSTITUTED (Salle de bain is not available: tests/io_common.py:write_bathroom_standin); %d NaN pixels, their tiles %s equal the oracle's\n" % (n_nan, nan_tiles) + r.stdout)
 
 
@@ -236,7 +245,7 @@ def test_config3_asset_substituted_4k_1024spp_sharded_eight_members_on_one_gpu(t
     nan_tiles, n_nan = _nan_tiles(film, limit=3)
     assert film.shape == (2160, 3840, 4) and n_nan <= 256
     _oracle_tiles(orc, glb, exr, (3840, 2160), 1024, sorted(set((17 * 60 + 28, 25 * 60 + 41, 33 * 60 + 59)) | set(nan_tiles)), film,
-                  dict(samples_per_run=1, max_bounces=8, env_samples_per_bounce=1, mesh_samples_per_bounce=1), nan_tiles)
+                  dict(samples_per_run=1, max_bounces=8, env_samples_per_bounce=1, mesh_samples_per_bounce=1), nan_tiles, second_source=(25 * 60 + 41,))
     print("configs[3]: ASSET SUBSTITUTED, and 8 members on ONE GPU (device-copy gather instead of ncclGather); 1024 spp; %d NaN pixels, their tiles %s equal the oracle's\n" % (n_nan, nan_tiles) + r.stdout)
 
 

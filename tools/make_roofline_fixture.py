@@ -17,7 +17,7 @@ from oracle import orc          # noqa: E402  (tools/ is test infrastructure: it
 from moonshine_amd import scenes  # noqa: E402
 
 ap = argparse.ArgumentParser()
-ap.add_argument("scene", choices=["s1", "s1_sky", "s2", "cornell"])
+ap.add_argument("scene", choices=["s1", "s1_sky", "s2", "cornell", "standin"])
 ap.add_argument("--width", type=int, default=480)
 ap.add_argument("--height", type=int, default=270)
 ap.add_argument("--spp", type=int, default=4)
@@ -33,6 +33,12 @@ elif a.scene == "s1_sky":
     s, l = scenes.s1(c, extent=(a.width, a.height), env="sky")
 elif a.scene == "s2":
     s, l = scenes.s2(c, extent=(a.width, a.height))
+elif a.scene == "standin":      # configs[2]'s stand-in (tests/io_common.py write_bathroom_standin), loaded the way the parity tests load it
+    import tempfile
+    from tests import io_common as io
+    d = tempfile.mkdtemp(); glb, exr = os.path.join(d, "bath.glb"), os.path.join(d, "sky.exr")
+    io.write_bathroom_standin(glb, exr)
+    l, _ = io.oracle_load(orc, c, glb, exr); s = c.create_sensor(a.width, a.height)
 else:
     s, l = scenes.cornell(c, extent=(a.width, a.height))
 nee = (0, 1) if a.scene == "cornell" else (1, 1)
