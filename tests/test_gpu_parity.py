@@ -968,10 +968,17 @@ def test_rays_at_the_hulls_of_far_scaled_and_sheared_instances(orc, gpu_api, see
     _check_rays(oc, gc, hull_rays.hull_rays(world, seed))
     if baked:
         return
-    updates = gc.accel_stats()["tlas_updates"]
+    st0 = gc.accel_stats()
     hull_rays.hull_move((oc, gc), seed, parts, world)                               # five instances moved: the product re-fits, with new slacks and spheres
     _check_rays(oc, gc, hull_rays.hull_rays(world, seed + 1)[::2])
-    assert gc.accel_stats()["tlas_updates"] == updates + 1                          # (in place, not a rebuild)
+    st1 = gc.accel_stats()
+    # in place, not a rebuild — unless a ray of this set starts beyond what the culling volumes were grown for, or an instance was carried beyond it (round 6:
+    # HdMoonshine::need_origin): then everything is re-baked, which is a TLAS rebuild.  One or the other, once.
+    assert (st1["tlas_updates"] - st0["tlas_updates"], st1["rebuilds"] - st0["rebuilds"]) in ((1, 0), (0, 1))
+    hull_rays.hull_move((oc, gc), seed + 5, parts, world)
+    _check_rays(oc, gc, hull_rays.hull_rays(world, seed + 2, far=1.0)[::3])         # rays from inside the scene's reach: only an instance carried far out re-bakes
+    st2 = gc.accel_stats()
+    assert (st2["tlas_updates"] - st1["tlas_updates"], st2["rebuilds"] - st1["rebuilds"]) in ((1, 0), (0, 1))
 
 
 @pytest.mark.gpu
@@ -1065,9 +1072,9 @@ def test_camera_far_outside_the_baked_reach(orc, gpu_api, seed, far):
     eye = rs.normal(size=3); eye = eye / np.linalg.norm(eye) * reach * far * 1.7
     fwd = ctr - eye; dist = np.linalg.norm(fwd); fwd = fwd / dist
     up = np.array([0, 0, 1.0]) if abs(fwd[2]) < 0.9 else np.array([0, 1.0, 0])
-    films = []
+    films = []; aperture = float(rs.choice([0.0, 0.5 * r]))
     for c, s_ in zip((oc, gc), sn):
-        lens = c.create_lens(c.make_lens(tuple(eye), tuple(fwd), tuple(up), float(2.0 * np.arctan(1.5 * r / dist)), float(rs.choice([0.0, 0.5 * r])), float(dist)))
+        lens = c.create_lens(c.make_lens(tuple(eye), tuple(fwd), tuple(up), float(2.0 * np.arctan(1.5 * r / dist)), aperture, float(dist)))
         c.set_pipeline(samples_per_run=2, max_bounces=3, env_samples_per_bounce=1, mesh_samples_per_bounce=0)
         c.render(s_, lens, launches=2); films.append(c.sensor_data(s_).copy())
     same = (films[0].view(np.uint32) == films[1].view(np.uint32)) | (np.isnan(films[0]) & np.isnan(films[1]))
