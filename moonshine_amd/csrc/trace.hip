@@ -252,7 +252,13 @@ __device__ __forceinline__ void step_node(Lane& L, const SceneView& sc, const St
         miss8 = __builtin_amdgcn_alignbit(miss8, f2u(__builtin_fmaf(f, 1.00001f, -n)), 31);   // (miss8 << 1) | sign
     }
     const uint32_t hits8 = ~miss8 & 0xffu;
-#if defined(TRACE_COUNT_EMPTY)   // measurement: node visits none of whose children the ray hits — all of them (1) or those made with a hit already found (2) — in the upper half of the visit counter
+#if defined(TRACE_COUNT_EMPTY)   // measurement: node visits none of whose children the ray hits — all of them (1), those made with a hit already found (2), or (3) those
+    // that a bound carried in the stack entry could have culled at the pop: the NODE'S OWN entry distance (its grid from the origin plane to plane 255, the side the
+    // ray enters by) lies beyond the limit the visit tested against — in the upper half of the visit counter (tools/empty_visits.py, profiles/r06_stale_visits.txt)
+    if (TRACE_COUNT_EMPTY == 3) {
+        const float ex_ = __builtin_fmaf(L.id.x < 0.0f ? 255.0f : 0.0f, ax, bx), ey_ = __builtin_fmaf(L.id.y < 0.0f ? 255.0f : 0.0f, ay, by), ez_ = __builtin_fmaf(L.id.z < 0.0f ? 255.0f : 0.0f, az, bz);
+        if (STATS && fmaxf(fmaxf(ex_, ey_), ez_) > tlimit * 1.00001f) nv += (1ull << 32);
+    } else
     if (STATS && !(hits8 & (w0.w >> 24 | (w1.z & 0xffu))) && (TRACE_COUNT_EMPTY == 1 || (!ANY_HIT && L.best.inst != MAX_UINT))) nv += (1ull << 32);
 #endif
     // empty slots (inverted boxes) can pass the slack test when the node is tiny against its distance: imask / lmask drop them

@@ -1,4 +1,5 @@
-"""Node visits none of whose children the ray hits (a library built with -DTRACE_COUNT_EMPTY=1: all of them; =2: those made with a closest hit already found), per ray, S1 and S2 at 480x270:
+"""Node visits none of whose children the ray hits (a library built with -DTRACE_COUNT_EMPTY=1: all of them; =2: those made with a closest hit already found; =3: visits whose node lies, as a whole, beyond
+the limit the visit tests against — what a bound carried in the stack entry could cull when the entry is popped), per ray, S1 and S2 at 480x270:
     MSNE_LIB=moonshine_amd/libmoonshine_amd_cnt.so python tools/empty_visits.py   (profiles/r05_tri_density.txt section 8)"""
 import os, sys
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
