@@ -96,6 +96,8 @@ static uint32_t collapse(const bnode *bn, uint32_t root, orc_wnode *wn, uint32_t
         w.lo[0][i] = c->box.lo.x; w.lo[1][i] = c->box.lo.y; w.lo[2][i] = c->box.lo.z;
         w.hi[0][i] = c->box.hi.x; w.hi[1][i] = c->box.hi.y; w.hi[2][i] = c->box.hi.z;
         if (c->count > 0) { w.child[i] = c->first; w.count[i] = (uint8_t)c->count; }
+        const float g = orc_maxf(orc_maxf(c->box.hi.x - c->box.lo.x, c->box.hi.y - c->box.lo.y), c->box.hi.z - c->box.lo.z);
+        w.grow[i] = (g > 0.0f && g < 3e38f) ? 1e-4f * g : 0.0f;   /* (an empty or unbounded box: no growth) — box_hit8 */
     }
     for (int i = 0; i < nch; i++) if (bn[ch[i]].count == 0) w.child[i] = collapse(bn, ch[i], wn, nw);
     wn[id] = w;
@@ -336,9 +338,8 @@ static inline unsigned box_hit8(const orc_wnode *n, const orc_rayb *r, float tma
         /* ... and 1e-4 of the box's own largest extent, as a length, on every side: the amplification above has no bound in what a NODE knows — a needle of a triangle
          * (15.8 x 0.028, seed 6226272: t = +3.7e-4 for a true -1.5e-4 at 24 degrees from its plane) amplifies by its aspect ratio as a grazing ray does by 1 / sin —
          * but the error is always a fraction of the TRIANGLE's size, and a triangle is no larger than a box that holds it: 1e-4 covers amplifications up to ~1600.
-         * The product's builder grows its boxes by the same 1e-4 before it quantises them (bvh_build.hip quantise_child). */
-        float g = orc_maxf(orc_maxf(n->hi[0][i] - n->lo[0][i], n->hi[1][i] - n->lo[1][i]), n->hi[2][i] - n->lo[2][i]);
-        g = g > 0.0f && g < 3e38f ? 1e-4f * g : 0.0f;   /* (an empty slot's inverted box, a box at the end of the range: no growth) */
+         * The product's builder grows its boxes by the same 1e-4 before it quantises them (bvh_build.hip box_growth). */
+        const float g = n->grow[i];   /* (computed when the node is made: collapse()) */
         float e = 1e-5f * mx + px + sx * far_ + g * fabsf(ix);
         float tn = orc_minf(x1, x2) - e, tf = orc_maxf(x1, x2) + e;
         e = 1e-5f * my + py + sy * far_ + g * fabsf(iy);

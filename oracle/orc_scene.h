@@ -31,6 +31,7 @@ typedef struct {
 typedef struct { v3 v0, v1, v2; uint32_t geo, prim; } orc_tri;          /* object space */
 typedef struct {
     float lo[3][8], hi[3][8];   /* [axis][child]: the eight box tests of a visit are one loop the compiler vectorises (slots >= nchild hold zeros and are ignored) */
+    float grow[8];              /* 1e-4 of the child box's largest extent (0 for an empty or unbounded box): orc_bvh.c box_hit8 */
     uint32_t child[8];      /* internal: node index; leaf: first item */
     uint8_t  count[8];      /* 0 = internal, else number of items in the leaf */
     uint8_t  nchild;
