@@ -1262,12 +1262,19 @@ __global__ void k_clock_probe(unsigned long long* out, uint32_t spins) {
 }
 double MsneProbeClockGhz(int device) {
     struct Probe { hipStream_t s = nullptr; unsigned long long* d = nullptr; };
-    static std::mutex mu; static std::map<int, Probe> probes;
-    std::lock_guard<std::mutex> g(mu);
+    // one stream and 32 bytes per device that was ever probed, kept for the life of the process ON PURPOSE: a static destructor would call into HIP after the runtime
+    // has begun to shut down (the order of the two at exit is not ours), which is worse than 32 bytes
+    struct Probes { std::mutex mu; std::map<int, Probe> of; };
+    static Probes probes;
+    std::lock_guard<std::mutex> g(probes.mu);
     if (hipSetDevice(device) != hipSuccess) return -1.0;
-    Probe& p = probes[device];
-    if (!p.s && (hipStreamCreateWithFlags(&p.s, hipStreamNonBlocking) != hipSuccess || hipMalloc(&p.d, 32) != hipSuccess)) { p.s = nullptr; return -1.0; }
+    Probe& p = probes.of[device];
+    if (!p.s) {
+        if (hipStreamCreateWithFlags(&p.s, hipStreamNonBlocking) != hipSuccess) { p.s = nullptr; return -1.0; }
+        if (hipMalloc(&p.d, 32) != hipSuccess) { (void)hipStreamDestroy(p.s); p.s = nullptr; p.d = nullptr; return -1.0; }   // (nothing is kept of a probe that is half made)
+    }
     hipLaunchKernelGGL(k_clock_probe, dim3(1), dim3(64), 0, p.s, p.d, 60000u);
+    if (hipGetLastError() != hipSuccess) return -1.0;
     unsigned long long h[3] = { 0, 0, 0 };
     if (hipMemcpyAsync(h, p.d, 24, hipMemcpyDeviceToHost, p.s) != hipSuccess || hipStreamSynchronize(p.s) != hipSuccess || h[1] == 0) return -1.0;
     return (double)h[0] / (double)h[1] * 0.1;
