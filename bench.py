@@ -61,6 +61,8 @@ def standin_files():
     import tempfile
     from tests import io_common as io
     d = tempfile.mkdtemp(prefix="msne_standin_")
+    import atexit, shutil
+    atexit.register(shutil.rmtree, d, ignore_errors=True)      # 26 MB of scratch: gone when the process ends
     glb, exr = os.path.join(d, "bath.glb"), os.path.join(d, "sky.exr")
     io.write_bathroom_standin(glb, exr)
     return glb, exr
