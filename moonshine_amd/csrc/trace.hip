@@ -222,7 +222,16 @@ __device__ __forceinline__ void step_node(Lane& L, const SceneView& sc, const St
     const float ax = u2f(ex << 23) * L.id.x, ay = u2f(ey << 23) * L.id.y, az = u2f(ez << 23) * L.id.z;
     // (+0 through the SAME instruction: the hit bit below is a sign bit, and a ray that starts exactly in the plane of a flat box against its direction has a plane
     // distance of 0 * negative = -0, whose sign would read as a miss — the oracle's `tf >= 0` takes it: tests/test_gpu_parity.py::test_rays_at_the_hulls_..., seed 14)
-    const float bx = __builtin_fmaf(nox - L.o.x, L.id.x, 0.0f), by = __builtin_fmaf(noy - L.o.y, L.id.y, 0.0f), bz = __builtin_fmaf(noz - L.o.z, L.id.z, 0.0f);
+    float bx = __builtin_fmaf(nox - L.o.x, L.id.x, 0.0f), by = __builtin_fmaf(noy - L.o.y, L.id.y, 0.0f), bz = __builtin_fmaf(noz - L.o.z, L.id.z, 0.0f);
+    // A distance to the grid's origin plane that OVERFLOWED says nothing — and as +-infinity it would say something: with a finite step a every plane of the axis then
+    // lies at -infinity (exit before entry: a miss) although the true distances are finite.  It happens where a node is astronomically large against the ray's
+    // reciprocal direction: an instance whose culling pad came out as 1e37 (a sheared transform that loses every digit, round 6's sweep: tests/test_gpu_parity.py
+    // ::test_rays_at_the_hulls_..., seeds 6709891 and 6711985 — 19 of 180 rays lost every instance that shared a TLAS node with it), coordinates beyond 3e8 under an
+    // axis-parallel ray (1 / d = 1e30).  x * 0 + x is x for every finite x and not a number for an infinite one: the axis then decides nothing (v_min / v_max pass
+    // the other operand on), which is the conservative answer.
+#if !defined(TRACE_B_OVERFLOW_IS_INFINITE)   // (measurements only: the kernels without the three instructions)
+    bx = __builtin_fmaf(bx, 0.0f, bx); by = __builtin_fmaf(by, 0.0f, by); bz = __builtin_fmaf(bz, 0.0f, bz);
+#endif
     // byte planes: qlo[0] = w2.xy, qlo[1] = w2.zw, qlo[2] = w3.xy, qhi[0] = w3.zw, qhi[1] = w4.xy, qhi[2] = w4.zw.
     // a = scale * id has the sign of id, so the entry plane of an axis is qlo when id >= 0 and qhi otherwise
     // (the choice made by ADDRESS instead — a 128-B node on a 128-B boundary with every axis' planes as {lo, hi, lo}, three 16-B loads at offset 0 or 8 by the ray's
