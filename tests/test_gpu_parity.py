@@ -2052,8 +2052,11 @@ def test_bench_gather_path_with_two_ranks(tmp_path):
     r1 = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--dump-film", one] + args, capture_output=True, text=True, timeout=900)
     assert r1.returncode == 0, r1.stderr[-2000:]
     env = dict(os.environ, MSNE_BENCH_BACKEND="gloo")
-    r2 = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", "29611",
-                         os.path.join(root, "bench.py"), "--gpus", "2", "--dump-film", two] + args, capture_output=True, text=True, timeout=900, env=env)
+    import socket
+    with socket.socket() as so:      # a port nobody holds right now (a fixed one hung this test for its whole 900-s limit when another job on the box had it: round 6)
+        so.bind(("127.0.0.1", 0)); port = so.getsockname()[1]
+    r2 = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(port),
+                         os.path.join(root, "bench.py"), "--gpus", "2", "--dump-film", two] + args, capture_output=True, text=True, timeout=300, env=env)
     assert r2.returncode == 0, r2.stderr[-3000:]
     a, b = np.load(one), np.load(two)
     assert np.array_equal(a.view(np.uint32), b.view(np.uint32))

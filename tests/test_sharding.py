@@ -58,7 +58,10 @@ def test_two_rank_gloo_gather(tmp_path, orc):
     script = tmp_path / "worker.py"
     script.write_text(WORKER)
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="1")
+    import socket
+    with socket.socket() as so:      # a port nobody holds right now (a fixed one makes the rendezvous wait for whoever has it)
+        so.bind(("127.0.0.1", 0)); port = so.getsockname()[1]
     out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
-                          "--master-port", "29533", str(script), ROOT], capture_output=True, text=True, env=env, timeout=600)
+                          "--master-port", str(port), str(script), ROOT], capture_output=True, text=True, env=env, timeout=600)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
     assert "SHARDED_OK" in out.stdout
