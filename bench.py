@@ -376,15 +376,25 @@ def main():
         ctx.reset_stats(); sync()
         th = threading.Thread(target=probe, daemon=True); th.start()
         marks = [time.perf_counter()]
-        while marks[-1] - marks[0] < a.sustain_seconds:
+        while True:
+            # how long to go on is rank 0's call, told to everybody: every batch ends in a collective (the gather), and ranks that counted batches by their own clocks
+            # would sooner or later disagree by one — and wait for each other for ever (round 6: the two-rank test hung exactly so)
+            go = torch.tensor([1.0 if marks[-1] - marks[0] < a.sustain_seconds else 0.0], dtype=torch.float64, device="cuda")
+            if world > 1:
+                dist.broadcast(go, src=0)
+            if float(go[0]) == 0.0:
+                break
             ctx.clear_sensor(sensor)
             ctx.render(sensor, lens, launches=a.steps, readback=False)
             gather()
             marks.append(time.perf_counter())
         sync()
         stop.set(); th.join()
-        ss = ctx.stats(); nb = len(marks) - 1
-        rays_batch = (ss["closest_rays"] + ss["shadow_rays"]) / float(nb)
+        ss = ctx.stats(); nb = max(len(marks) - 1, 1)
+        rays_all = torch.tensor([float(ss["closest_rays"] + ss["shadow_rays"])], dtype=torch.float64, device="cuda")
+        if world > 1:
+            dist.all_reduce(rays_all, op=dist.ReduceOp.SUM)      # the whole job's rays, not this rank's share
+        rays_batch = float(rays_all[0]) / float(nb)
         total_s = marks[-1] - marks[0]
         wins, w0, k0 = [], marks[0], 0      # rate of every whole 1-s window: batches completed in it / its length
         for k in range(1, len(marks)):
@@ -543,7 +553,7 @@ def main():
                                "samples": warm["samples"] + st["samples"] + sa["samples"]},
         }
         if sustained is not None:
-            out["sustained"] = sustained     # this rank's batches (at N > 1 every rank runs the same loop, gather included)
+            out["sustained"] = sustained     # rank 0's clock over the whole job's rays (at N > 1 every rank runs the same number of batches, gather included)
         if world == 1 and a.scene == "s1" and a.env == "constant" and not a.no_other_configs:
             # the other single-GPU configurations of BASELINE.json, measured after the headline (a second or two): configs[4] (S2) and S1 under the image environment
             out["other_configs"] = {"s2": other_config(a, dev, "s2", "constant"), "s1_sky": other_config(a, dev, "s1", "sky"), "standin": other_config(a, dev, "standin", "image")}
