@@ -366,7 +366,7 @@ def test_lattice_rays_with_and_without_boxes(orc, seed):
     bad = _same_hits(c, rays, 2)
     assert not bad, bad[:3]
     c.set_exhaustive_search(0)
-    assert sum(1 for r in rays[:300] if c.trace_closest(r[:3], r[3:6], float(r[6]))[0]) > 2        # (the rays do hit things)
+    assert sum(1 for r in rays[:300] if c.trace_closest(r[:3], r[3:6], float(r[6]))[0]) >= 1       # (the rays do hit things; at a scale of 2^-62 as few as two of 300: seed 24871 of a 140 000-case sweep)
 
 
 @pytest.mark.parametrize("seed", __import__("seeds").seeds(list(range(6)) + [6100112, 6100853], 16))
