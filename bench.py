@@ -262,6 +262,7 @@ def main():
     ap.add_argument("--no-other-configs", action="store_true", help="skip the secondary single-GPU configurations (S2, S1 under the sky) reported next to the headline")
     ap.add_argument("--sustain-seconds", type=float, default=3.0,
                     help="after the timed repeats: back-to-back K-step batches for at least this long, reported as `sustained` (rate per 1-s window, shader clock at both ends); 0 = off")
+    ap.add_argument("--no-gpu-visits", action="store_true", help="skip the extra pass that counts the GPU's own node visits / triangle tests per ray (profiling runs: its kernels would be counted)")
     ap.add_argument("--dump-film", default=None, help="rank 0 saves the assembled film of the last repeat here (.npy): parity tests of the gather path")
     a = ap.parse_args()
 
@@ -358,6 +359,26 @@ def main():
     for kind, ms in ctx.launch_times():
         per_bounce[kind][seen[kind] % (NB - 1 if kind == 1 else NB)] += ms; seen[kind] += 1
     ctx.set_profiling(kernel_events=False, traversal_counters=False)
+
+    # ... and once more with the traversal kernels' COUNTING instantiations (outside the timed region, never part of `value`): the GPU's own node visits and triangle tests
+    # per ray in THIS run — a quantity of the roofline object that is observed here and not read from a committed file (`roofline.gpu_visits`).  Plain device
+    # synchronisation only: a rank that fails here must not leave the others in a barrier.
+    gpu_visits = None
+    if not a.no_gpu_visits:
+        try:
+            ctx.reset_stats(); ctx.set_profiling(kernel_events=False, traversal_counters=True)
+            ctx.clear_sensor(sensor); torch.cuda.synchronize()
+            ctx.render(sensor, lens, launches=a.steps, readback=False); torch.cuda.synchronize()
+            sv = ctx.stats(); tc = ctx.traversal_counters()
+            cr, sr = max(float(sv["closest_rays"]), 1.0), max(float(sv["shadow_rays"]), 1.0)
+            gpu_visits = {"node_visits_per_closest_ray": tc["closest_node_visits"] / cr, "triangle_tests_per_closest_ray": tc["closest_tri_tests"] / cr,
+                          "node_visits_per_shadow_ray": tc["shadow_node_visits"] / sr, "triangle_tests_per_shadow_ray": tc["shadow_tri_tests"] / sr,
+                          "bytes_per_closest_ray": tc["closest_node_visits"] / cr * 80.0 + tc["closest_tri_tests"] / cr * 48.0 + 48.0,
+                          "from": "this run: one extra pass of the same %d steps with the traversal kernels' counting instantiations (MsneSetProfiling traversal_counters)" % a.steps}
+        except Exception as e:      # (a diagnostic must not cost the line)
+            gpu_visits = {"error": str(e)}
+        ctx.set_profiling(kernel_events=False, traversal_counters=False)
+        ctx.reset_stats()
 
     # A render is seconds of launches (offline/main.zig:131-165), the timed region above a burst of tens of milliseconds: with --sustain-seconds S the same K-step batch
     # runs back to back for at least S seconds.  Per-batch wall times give the rate per 1-s window; the shader clock is probed by one wave on a stream of its own
@@ -519,6 +540,9 @@ def main():
             roof["counters_stale"] = cnt.get("source_hash") != source_hash()       # per-ray instruction counts were taken on other kernel sources than the ones running now
         roof.update({"units_per_launch": kun[dom] / nl, "avg_launch_ms": avg_ms, "launches": nl, "traffic": None,
                      "timing": "HIP events around every launch of the kernel in an extra pass of the same K steps with the kernels in stream order (exclusive durations)"})
+        if gpu_visits is not None:
+            roof["gpu_visits"] = gpu_visits
+            roof["measured_in_this_run"].append("gpu_visits")
         if ck:
             roof["traffic"] = ck["hbm_bytes_per_unit"] * kun[dom] / nl           # HBM bytes per launch: PMC figure per unit (committed) x this run's units
             roof["traffic_from"] = "profiles/" + cnt_file + " (FETCH_SIZE x2 + WRITE_SIZE per unit, measured by rocprofv3 on this command) x this run's units per launch"

@@ -12,7 +12,7 @@ cd /tmp && export TMPDIR=/tmp
 export MSNE_SERIAL=1
 O=$R/gpurun_out/${TAG}_${SCENE}
 SC=${SCENE%_sky}; ENVARG=""; [ "$SC" != "$SCENE" ] && ENVARG="--env sky"
-ARGS="--scene $SC $ENVARG --no-cpu-baseline --no-other-configs --sustain-seconds 0 --repeats 2 $*"
+ARGS="--scene $SC $ENVARG --no-cpu-baseline --no-other-configs --sustain-seconds 0 --no-gpu-visits --repeats 2 $*"
 echo "MSNE_SERIAL=1 bench.py $ARGS" > ${O}_cmd.txt
 pmc() {  # name, counters...
     n=$1; shift
