@@ -259,7 +259,7 @@ def main():
     ap.add_argument("--scene", default="s1", choices=["s1", "s2", "standin"])
     ap.add_argument("--env", default="constant", choices=["constant", "sky"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-other-configs", action="store_true", help="skip the secondary single-GPU configurations (S2, S1 under the sky) reported next to the headline")
+    ap.add_argument("--no-other-configs", action="store_true", help="skip the secondary single-GPU configurations (S2, S1 under the sky, the configs[2] stand-in) reported next to the headline")
     ap.add_argument("--sustain-seconds", type=float, default=3.0,
                     help="after the timed repeats: back-to-back K-step batches for at least this long, reported as `sustained` (rate per 1-s window, shader clock at both ends); 0 = off")
     ap.add_argument("--no-gpu-visits", action="store_true", help="skip the extra pass that counts the GPU's own node visits / triangle tests per ray (profiling runs: its kernels would be counted)")
